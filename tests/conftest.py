@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
+GOLDEN_CASES = ['n6_p1', 'n5_p4', 'n5_p2_ecstr', 'n4_p6_pbc', 'n9_p1']
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(params=GOLDEN_CASES)
+def golden(request):
+    import numpy as np
+
+    g = dict(np.load(os.path.join(GOLDEN_DIR, request.param + '.npz')))
+    g['name'] = request.param
+    return g
