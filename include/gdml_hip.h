@@ -1,0 +1,195 @@
+/*
+ * gdml_hip.h -- C ABI of libgdml_hip.so: the MI355X (gfx950) implementation of sGDML's
+ * kernel linear-algebra hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one
+ * NumPy / SciPy / PyTorch call site of the reference (cited as file:line relative to the
+ * reference repository root); the Python classes in sgdml_amd/ bind them with ctypes and
+ * keep the reference's public API (GDMLTrain / GDMLPredict / Analytic / Iterative).
+ *
+ * Conventions
+ *   - plain C: opaque context pointer, host pointers to float64 / int64 row-major (C-order)
+ *     arrays owned by the caller unless a parameter is documented as a DEVICE pointer;
+ *   - every function returns 0 on success or a negative gdml_status; it never throws and
+ *     never calls exit(); gdml_last_error() returns a human-readable description;
+ *   - one context per GPU; a context is not thread-safe, different contexts are independent;
+ *   - all arithmetic is IEEE float64 (the reference computes in float64 everywhere:
+ *     sgdml/torchtools.py:49, sgdml/train.py:1484, sgdml/predict.py:80);
+ *   - N = atoms, D = N(N-1)/2 descriptor entries in np.tril_indices(N,-1) order
+ *     (sgdml/utils/desc.py:264), M = training points, P = permutations, dim_i = 3N.
+ */
+#ifndef GDML_HIP_H
+#define GDML_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gdml_ctx gdml_ctx;
+
+typedef enum {
+  GDML_OK = 0,
+  GDML_ERR_INVALID = -1,     /* bad argument (maps to ValueError / AssertionError)        */
+  GDML_ERR_HIP = -2,         /* HIP runtime error                                          */
+  GDML_ERR_OOM = -3,         /* device allocation failed (reference: OOM re-batching,
+                                sgdml/torchtools.py:349-387; here the host decides)        */
+  GDML_ERR_STATE = -4,       /* call order violated (e.g. solve before assemble)          */
+  GDML_ERR_NOT_PD = -5,      /* Cholesky met a non-positive pivot (LinAlgError analogue,
+                                sgdml/solvers/analytic.py:101)                            */
+  GDML_ERR_UNSUPPORTED = -6, /* size beyond what this build's kernels support             */
+  GDML_ERR_COMM = -7         /* RCCL failure                                               */
+} gdml_status;
+
+/* ---- library / context --------------------------------------------------------------- */
+
+/* ABI version of this header (bumped on any signature change). */
+int gdml_abi_version(void);
+
+/* Number of visible HIP devices (reference: torch.cuda.device_count(), train.py:1464). */
+int gdml_device_count(int* n_out);
+
+/* Create / destroy the per-GPU context: owns one compute stream, one copy stream, all
+ * device buffers and (after gdml_comm_init) the RCCL communicator. */
+int gdml_ctx_create(int device, gdml_ctx** ctx_out);
+int gdml_ctx_destroy(gdml_ctx* ctx);
+
+/* Last error text of a context (ctx may be NULL: text of the last failed gdml_ctx_create). */
+const char* gdml_last_error(const gdml_ctx* ctx);
+
+/* Block until all work queued on the context's streams has finished. */
+int gdml_sync(gdml_ctx* ctx);
+
+/* Device memory currently held by the context, and free/total HBM of its device (bytes). */
+int gdml_mem_info(gdml_ctx* ctx, int64_t* held, int64_t* free_b, int64_t* total_b);
+
+/* Elapsed milliseconds (HIP events on the compute stream) of the most recent call of the
+ * named phase: "desc", "assemble", "factor", "solve", "predict", "matvec", "precon".
+ * Also returns how many kernel launches the phase issued. */
+int gdml_phase_ms(gdml_ctx* ctx, const char* phase, double* ms_out, int64_t* launches_out);
+
+/* ---- descriptors  (replaces Desc.from_R, sgdml/utils/desc.py:288-365, :208-239) --------
+ * R (M,3N) -> R_desc (M,D) = 1/|r_i - r_j|, R_d_desc (M,D,3) = (r_i - r_j)/d^3.
+ * lat / lat_inv: 3x3 row-major lattice (columns = vectors) and its inverse, or both NULL;
+ * with a lattice the pair differences are wrapped to the minimum image first
+ * (desc.py:44-77, round-half-even like np.around). */
+int gdml_desc_from_R(gdml_ctx* ctx, const double* R, int64_t M, int N, const double* lat,
+                     const double* lat_inv, double* R_desc_out, double* R_d_desc_out);
+
+/* ---- training set residency (replaces the H2D copies at sgdml/train.py:1447-1448) -------
+ * tril_perms is the (P,D) descriptor-permutation table, i.e. the un-linearised form of
+ * tril_perms_lin (train.py:897-904): tril_perms[p][k] = tril_perms_lin[k*P+p] - p*D.  Each
+ * row must be induced by an atom permutation (Desc.perm, desc.py:509-539); the library
+ * recovers the atom permutations and rejects anything else with GDML_ERR_INVALID. */
+int gdml_train_upload(gdml_ctx* ctx, const double* R_desc, const double* R_d_desc, int64_t M,
+                      int N, const int64_t* tril_perms, int P);
+
+/* ---- kernel matrix assembly (replaces GDMLTrain._assemble_kernel_mat, train.py:1260-1535,
+ *      worker train.py:97-302, torch backend torchtools.py:110-392) -----------------------
+ * Builds the UN-negated kernel matrix with rows = 3N*M (+M if use_E_cstr) and the selected
+ * columns, element order exactly as train.py:1535, into a device buffer owned by the
+ * context (it stays there for gdml_chol_factor / gdml_nystroem_*), and optionally copies
+ * it to K_host_out (row stride ldk doubles, at least n_cols) when that is not NULL.
+ *   col_kind GDML_COLS_ALL    : all columns (col_a, col_b, idx ignored)
+ *   col_kind GDML_COLS_POINTS : columns of training points [col_a, col_b)  (whole 3N blocks;
+ *                               the reference's slice path train.py:1357-1374)
+ *   col_kind GDML_COLS_INDEX  : n_idx sorted unique global column indices idx[] (may include
+ *                               energy-constraint columns >= 3N*M; train.py:1376-1407)
+ * alloc_extra_rows: extra (uninitialised) rows appended to the device matrix and to the
+ * host copy's shape contract (train.py:1418,1484). */
+enum { GDML_COLS_ALL = 0, GDML_COLS_POINTS = 1, GDML_COLS_INDEX = 2 };
+int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind, int64_t col_a,
+                    int64_t col_b, const int64_t* idx, int64_t n_idx, int64_t alloc_extra_rows,
+                    double* K_host_out, int64_t ldk);
+
+/* Shape of the device-resident matrix produced by the last gdml_assemble_K. */
+int gdml_K_shape(gdml_ctx* ctx, int64_t* n_rows, int64_t* n_cols, int64_t* extra_rows);
+
+/* ---- analytic solve (replaces Analytic.solve, sgdml/solvers/analytic.py:65-99) ----------
+ * Requires a square device-resident K from gdml_assemble_K(GDML_COLS_ALL).
+ * gdml_chol_factor: A = -K + lam*I, in-place blocked Cholesky A = L L^T on fp64 MFMA.
+ *   *info = 0 ok; > 0: leading minor of that order is not positive definite (LAPACK dpotrf
+ *   convention, what scipy.linalg.cho_factor raises LinAlgError for, analytic.py:94-101);
+ *   the function then returns GDML_ERR_NOT_PD and K is destroyed (re-assemble to retry).
+ * gdml_chol_solve: alphas = -(A^-1 y)   (analytic.py:97-99).
+ * n_refine > 0 adds that many steps of iterative refinement with the matrix-free kernel
+ * operator (needs the training set of gdml_train_upload; 0 = exactly LAPACK semantics). */
+int gdml_chol_factor(gdml_ctx* ctx, double lam, int* info);
+int gdml_chol_solve(gdml_ctx* ctx, const double* y, int64_t n, int n_refine, double* alphas_out);
+
+/* ---- prediction (replaces GDMLPredict.__init__/set_alphas/predict,
+ *      sgdml/predict.py:426-447, :551-601, :1146-1294; worker :84-245; torch :877-1046) ----
+ * gdml_predict_upload_model: training descriptors R_desc (M,D) [note: the model file stores
+ *   its transpose, train.py:807], R_d_desc_alpha (M,D), tril_perms (P,D), sig, optional
+ *   alphas_E (M) (NULL if the model has no energy constraints).  Builds the permuted tables
+ *   of predict.py:426-441 on the device.
+ * gdml_set_alphas: training-mode re-targeting (predict.py:551-601): needs the Jacobians of
+ *   gdml_train_upload; computes J_m alpha_m on the device (desc.py:368-385).
+ * gdml_predict: R (B,3N) host geometries, or R == NULL for the training-set mode
+ *   (predict.py:1221-1233) which uses the descriptors of gdml_train_upload.  Outputs are
+ *   UNSCALED (host applies std and c exactly as predict.py:1286-1288): E_out (B) may be NULL
+ *   (return_E=False), F_out (B,3N). */
+int gdml_predict_upload_model(gdml_ctx* ctx, const double* R_desc, const double* R_d_desc_alpha,
+                              int64_t M, int N, const int64_t* tril_perms, int P, double sig,
+                              const double* alphas_E);
+int gdml_set_alphas(gdml_ctx* ctx, const double* alphas_F, const double* alphas_E);
+int gdml_predict(gdml_ctx* ctx, const double* R, int64_t B, const double* lat,
+                 const double* lat_inv, double* E_out, double* F_out);
+
+/* Device-resident variant used by benchmarks and MD loops: R_dev / E_dev / F_dev are DEVICE
+ * pointers (hipMalloc'd by the caller or gdml_dev_alloc); nothing crosses PCIe. */
+int gdml_predict_dev(gdml_ctx* ctx, const double* R_dev, int64_t B, const double* lat,
+                     const double* lat_inv, double* E_dev, double* F_dev);
+
+/* Kernel mat-vec  out = K v - lam v  through the prediction contraction (replaces
+ * Iterative._K_vec, sgdml/solvers/iterative.py:183-204).  n = 3NM (+M with E constraints). */
+int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, const double* v, int64_t n,
+                       double* out);
+
+/* ---- iterative solver (replaces sgdml/solvers/iterative.py) ------------------------------
+ * gdml_nystroem_factor (iterative.py:208-351 + :414-471): requires the (n+m) x m matrix of
+ *   gdml_assemble_K(GDML_COLS_INDEX, idx, m, alloc_extra_rows = m).  Computes on the device
+ *   L^-1 K_mn (m x n) with the jitter-escalation semantics of _cho_factor_stable, keeps it
+ *   resident as the preconditioner, returns the leverage scores (column squared norms,
+ *   iterative.py:107-109) in lev_scores_out (n) and optionally the factor in
+ *   LinvKmn_host_out (m x n row-major, may be NULL).  *info: 0 ok, 1 = second Cholesky
+ *   needed the QR fallback branch (not implemented: GDML_ERR_NOT_PD).
+ * gdml_precon_apply: out = (L^T L v - v)/lam  (iterative.py:120-140).
+ * gdml_pcg: preconditioned CG for (-K + lam I) x = y with scipy.sparse.linalg.cg semantics
+ *   (iterative.py:740-752: rtol*||y||, atol = 0, x0 optional).  cb(iter, resid, x_host, user)
+ *   is called every cb_every iterations (0 = never) with the current iterate copied to the
+ *   host; a non-zero return stops the solve (used for CGRestartException, iterative.py:729).
+ *   info_out: 0 converged, 1 maxiter reached, 2 stopped by callback. */
+typedef int (*gdml_pcg_cb)(int64_t iter, double resid, const double* x_host, void* user);
+int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* idx, int64_t m,
+                         double* lev_scores_out, double* LinvKmn_host_out, int* info);
+int gdml_precon_apply(gdml_ctx* ctx, double lam, const double* v, int64_t n, double* out);
+int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const double* x0,
+             int64_t n, double rtol, int64_t maxiter, int use_precon, gdml_pcg_cb cb,
+             int64_t cb_every, void* user, double* x_out, int64_t* iters_out, double* resid_out,
+             int* info_out);
+
+/* ---- multi-GPU (new: the reference has no collective) ----------------------
+ * One process per GPU.  Rank 0 calls gdml_comm_unique_id (128 bytes) and ships it to the
+ * other ranks by any host channel (bench.py uses torch.distributed's store); every rank then
+ * calls gdml_comm_init.  After that gdml_assemble_K / gdml_chol_* / gdml_pcg operate on the
+ * rank's block-column shard and use RCCL (broadcast of panels, all-gather / all-reduce of CG
+ * vectors) over xGMI. */
+int gdml_comm_unique_id(void* id128_out);
+int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world);
+int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out);
+
+/* ---- raw device buffers for callers that keep data resident -------------------------- */
+int gdml_dev_alloc(gdml_ctx* ctx, int64_t bytes, void** dev_out);
+int gdml_dev_free(gdml_ctx* ctx, void* dev);
+int gdml_memcpy_h2d(gdml_ctx* ctx, void* dev, const void* host, int64_t bytes);
+int gdml_memcpy_d2h(gdml_ctx* ctx, void* host, const void* dev, int64_t bytes);
+
+/* Device pointer + leading dimension of the resident kernel matrix / factor (for tests). */
+int gdml_K_dev(gdml_ctx* ctx, double** K_dev_out, int64_t* ld_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDML_HIP_H */

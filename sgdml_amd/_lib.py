@@ -1,0 +1,310 @@
+"""ctypes binding of libgdml_hip.so (include/gdml_hip.h).  No compute happens in Python."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgdml_hip.so')
+
+GDML_OK = 0
+ERR_INVALID, ERR_HIP, ERR_OOM, ERR_STATE, ERR_NOT_PD, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6, -7
+COLS_ALL, COLS_POINTS, COLS_INDEX = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+PCG_CB = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, _dp, _vp)
+
+# name -> (restype, argtypes).  Must list every symbol declared in include/gdml_hip.h.
+SIGNATURES = {
+    'gdml_abi_version': (C.c_int, []),
+    'gdml_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'gdml_ctx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    'gdml_ctx_destroy': (C.c_int, [_vp]),
+    'gdml_last_error': (C.c_char_p, [_vp]),
+    'gdml_sync': (C.c_int, [_vp]),
+    'gdml_mem_info': (C.c_int, [_vp, _ip, _ip, _ip]),
+    'gdml_phase_ms': (C.c_int, [_vp, C.c_char_p, _dp, _ip]),
+    'gdml_desc_from_R': (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
+    'gdml_train_upload': (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_int]),
+    'gdml_assemble_K': (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64,
+                                  C.c_int64, _vp, C.c_int64]),
+    'gdml_K_shape': (C.c_int, [_vp, _ip, _ip, _ip]),
+    'gdml_chol_factor': (C.c_int, [_vp, C.c_double, C.POINTER(C.c_int)]),
+    'gdml_chol_solve': (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp]),
+    'gdml_predict_upload_model': (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_double, _vp]),
+    'gdml_set_alphas': (C.c_int, [_vp, _vp, _vp]),
+    'gdml_predict': (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
+    'gdml_predict_dev': (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
+    'gdml_kernel_matvec': (C.c_int, [_vp, C.c_double, C.c_int, _vp, C.c_int64, _vp]),
+    'gdml_nystroem_factor': (C.c_int, [_vp, C.c_double, _vp, C.c_int64, _vp, _vp, C.POINTER(C.c_int)]),
+    'gdml_precon_apply': (C.c_int, [_vp, C.c_double, _vp, C.c_int64, _vp]),
+    'gdml_pcg': (C.c_int, [_vp, C.c_double, C.c_int, _vp, _vp, C.c_int64, C.c_double, C.c_int64, C.c_int,
+                           PCG_CB, C.c_int64, _vp, _vp, _ip, _dp, C.POINTER(C.c_int)]),
+    'gdml_comm_unique_id': (C.c_int, [_vp]),
+    'gdml_comm_init': (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    'gdml_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'gdml_dev_alloc': (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    'gdml_dev_free': (C.c_int, [_vp, _vp]),
+    'gdml_memcpy_h2d': (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    'gdml_memcpy_d2h': (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    'gdml_K_dev': (C.c_int, [_vp, C.POINTER(_vp), _ip]),
+}
+
+_lib = None
+
+
+class GDMLHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgdml_hip.so (built by __graft_entry__.build() / make -C sgdml_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libgdml_hip.so not found at {} -- build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` or `make -C sgdml_amd/csrc`. There is no CPU fallback.'.format(LIB_PATH)
+        )
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # raises AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+
+
+def tril_perms_from_lin(tril_perms_lin, dim_d):
+    """Undo the linearisation of sgdml/train.py:903-904: returns the (P,D) int64 table."""
+    lin = np.asarray(tril_perms_lin, dtype=np.int64).ravel()
+    n_perms = lin.size // dim_d
+    return np.ascontiguousarray(lin.reshape(dim_d, n_perms).T - np.arange(n_perms)[:, None] * dim_d)
+
+
+class Context(object):
+    """One gdml_ctx (one GPU, own streams and device buffers)."""
+
+    def __init__(self, device=None):
+        self._h = None
+        lib = load()
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0'))
+            n = C.c_int(0)
+            lib.gdml_device_count(C.byref(n))
+            if n.value > 0:
+                device %= n.value
+        h = _vp()
+        rc = lib.gdml_ctx_create(int(device), C.byref(h))
+        if rc != GDML_OK:
+            msg = lib.gdml_last_error(None).decode()
+            raise GDMLHipError('cannot create GPU context (device {}): {}'.format(device, msg))
+        self._lib = lib
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h is not None:
+            self._lib.gdml_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- error mapping (SURVEY.md section 8b "Error conventions")
+    def _check(self, rc):
+        if rc == GDML_OK:
+            return
+        msg = self._lib.gdml_last_error(self._h).decode()
+        if rc == ERR_INVALID:
+            raise ValueError(msg)
+        if rc == ERR_OOM:
+            raise MemoryError(msg)
+        if rc == ERR_NOT_PD:
+            raise np.linalg.LinAlgError(msg)
+        if rc == ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise GDMLHipError('[{}] {}'.format(rc, msg))
+
+    def sync(self):
+        self._check(self._lib.gdml_sync(self._h))
+
+    def mem_info(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.gdml_mem_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def phase_ms(self, name):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self._lib.gdml_phase_ms(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def desc_from_R(self, R, n_atoms, lat_and_inv=None):
+        R = f64(R).reshape(-1, 3 * n_atoms)
+        M = R.shape[0]
+        D = n_atoms * (n_atoms - 1) // 2
+        xd = np.empty((M, D))
+        gd = np.empty((M, D, 3))
+        lat = lat_inv = None
+        if lat_and_inv is not None:
+            lat, lat_inv = f64(lat_and_inv[0]), f64(lat_and_inv[1])
+        self._check(self._lib.gdml_desc_from_R(self._h, _ptr(R), M, n_atoms, _ptr(lat), _ptr(lat_inv),
+                                               _ptr(xd), _ptr(gd)))
+        return xd, gd
+
+    def train_upload(self, R_desc, R_d_desc, tril_perms):
+        R_desc, R_d_desc, tril_perms = f64(R_desc), f64(R_d_desc), i64(tril_perms)
+        M, D = R_desc.shape
+        n_atoms = int((1 + np.sqrt(8 * D + 1)) / 2)
+        if R_d_desc.shape != (M, D, 3):
+            raise ValueError('R_d_desc must be the compressed (M,D,3) Jacobian')
+        self._check(self._lib.gdml_train_upload(self._h, _ptr(R_desc), _ptr(R_d_desc), M, n_atoms,
+                                                _ptr(tril_perms), tril_perms.shape[0]))
+        self.n_train, self.n_atoms = M, n_atoms
+
+    def assemble_K(self, sig, use_E_cstr=False, points=None, idx=None, alloc_extra_rows=0, to_host=False):
+        """Returns the host copy (rows+extra, cols) if to_host else None (matrix stays on the GPU)."""
+        kind, a, b, ip, n_idx = COLS_ALL, 0, 0, None, 0
+        if points is not None:
+            kind, (a, b) = COLS_POINTS, points
+        elif idx is not None:
+            idx = i64(idx)
+            kind, ip, n_idx = COLS_INDEX, _ptr(idx), idx.size
+        if not to_host:
+            self._check(self._lib.gdml_assemble_K(self._h, float(sig), int(bool(use_E_cstr)), kind, a, b, ip,
+                                                  n_idx, int(alloc_extra_rows), None, 0))
+            return None
+        # two-step: the shape is only known to the library -> query after a device-only assembly
+        n_rows = self.n_train * 3 * self.n_atoms + (self.n_train if use_E_cstr else 0)
+        if kind == COLS_ALL:
+            n_cols = n_rows
+        elif kind == COLS_POINTS:
+            n_cols = (min(b, self.n_train) - min(a, self.n_train)) * 3 * self.n_atoms + \
+                     (max(b, self.n_train) - max(a, self.n_train))
+        else:
+            n_cols = n_idx
+        K = np.empty((n_rows + alloc_extra_rows, n_cols))
+        self._check(self._lib.gdml_assemble_K(self._h, float(sig), int(bool(use_E_cstr)), kind, a, b, ip,
+                                              n_idx, int(alloc_extra_rows), _ptr(K), n_cols))
+        return K
+
+    def K_shape(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.gdml_K_shape(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def K_to_host(self):
+        """Copy of the resident matrix / factor (tests only)."""
+        rows, cols, extra = self.K_shape()
+        p, ld = _vp(), C.c_int64()
+        self._check(self._lib.gdml_K_dev(self._h, C.byref(p), C.byref(ld)))
+        buf = np.empty((rows + extra, ld.value))
+        self._check(self._lib.gdml_memcpy_d2h(self._h, _ptr(buf), p, buf.nbytes))
+        return buf[:, :cols]
+
+    def chol_factor(self, lam):
+        info = C.c_int(0)
+        self._check(self._lib.gdml_chol_factor(self._h, float(lam), C.byref(info)))
+        return info.value
+
+    def chol_solve(self, y, n_refine=0):
+        y = f64(y).ravel()
+        out = np.empty_like(y)
+        self._check(self._lib.gdml_chol_solve(self._h, _ptr(y), y.size, int(n_refine), _ptr(out)))
+        return out
+
+    def predict_upload_model(self, R_desc, R_d_desc_alpha, tril_perms, sig, alphas_E=None):
+        R_desc, R_d_desc_alpha, tril_perms = f64(R_desc), f64(R_d_desc_alpha), i64(tril_perms)
+        alphas_E = f64(alphas_E)
+        M, D = R_desc.shape
+        n_atoms = int((1 + np.sqrt(8 * D + 1)) / 2)
+        self._check(self._lib.gdml_predict_upload_model(self._h, _ptr(R_desc), _ptr(R_d_desc_alpha), M, n_atoms,
+                                                        _ptr(tril_perms), tril_perms.shape[0], float(sig),
+                                                        _ptr(alphas_E)))
+        self.model_n_train, self.model_n_atoms = M, n_atoms
+
+    def set_alphas(self, alphas_F, alphas_E=None):
+        alphas_F, alphas_E = f64(alphas_F).ravel(), f64(alphas_E)
+        self._check(self._lib.gdml_set_alphas(self._h, _ptr(alphas_F), _ptr(alphas_E)))
+
+    def predict(self, R=None, lat_and_inv=None, return_E=True):
+        n_atoms = self.model_n_atoms
+        if R is None:
+            B = self.n_train
+        else:
+            R = f64(R).reshape(-1, 3 * n_atoms)
+            B = R.shape[0]
+        E = np.empty(B) if return_E else None
+        F = np.empty((B, 3 * n_atoms))
+        lat = lat_inv = None
+        if lat_and_inv is not None:
+            lat, lat_inv = f64(lat_and_inv[0]), f64(lat_and_inv[1])
+        self._check(self._lib.gdml_predict(self._h, _ptr(R), B, _ptr(lat), _ptr(lat_inv), _ptr(E), _ptr(F)))
+        return E, F
+
+    def kernel_matvec(self, lam, use_E_cstr, v):
+        v = f64(v).ravel()
+        out = np.empty_like(v)
+        self._check(self._lib.gdml_kernel_matvec(self._h, float(lam), int(bool(use_E_cstr)), _ptr(v), v.size,
+                                                 _ptr(out)))
+        return out
+
+    def nystroem_factor(self, lam, idx, want_factor=False):
+        idx = i64(idx)
+        n_rows, _, _ = self.K_shape()
+        lev = np.empty(n_rows)
+        fac = np.empty((idx.size, n_rows)) if want_factor else None
+        info = C.c_int(0)
+        self._check(self._lib.gdml_nystroem_factor(self._h, float(lam), _ptr(idx), idx.size, _ptr(lev),
+                                                   _ptr(fac), C.byref(info)))
+        return lev, fac, info.value
+
+    def precon_apply(self, lam, v):
+        v = f64(v).ravel()
+        out = np.empty_like(v)
+        self._check(self._lib.gdml_precon_apply(self._h, float(lam), _ptr(v), v.size, _ptr(out)))
+        return out
+
+    def pcg(self, lam, use_E_cstr, y, x0=None, rtol=1e-4, maxiter=1000, use_precon=True, callback=None,
+            cb_every=1):
+        y = f64(y).ravel()
+        n = y.size
+        x0 = f64(x0)
+        x = np.empty(n)
+        iters, resid, info = C.c_int64(), C.c_double(), C.c_int()
+        exc = []
+
+        def _cb(it, res, xp, _user):
+            try:
+                xk = np.ctypeslib.as_array(xp, shape=(n,))
+                return int(bool(callback(int(it), float(res), xk)))
+            except BaseException as e:  # propagate after the C call returns
+                exc.append(e)
+                return 1
+
+        cb = PCG_CB(_cb) if callback is not None else C.cast(None, PCG_CB)
+        rc = self._lib.gdml_pcg(self._h, float(lam), int(bool(use_E_cstr)), _ptr(y), _ptr(x0), n, float(rtol),
+                                int(maxiter), int(bool(use_precon)), cb, int(cb_every if callback else 0), None,
+                                _ptr(x), C.byref(iters), C.byref(resid), C.byref(info))
+        if exc:
+            raise exc[0]
+        self._check(rc)
+        return x, info.value, iters.value, resid.value

@@ -1,0 +1,482 @@
+// Kernel-matrix assembly on gfx950.
+//
+// Replaces GDMLTrain._assemble_kernel_mat / _assemble_kernel_mat_wkr (sgdml/train.py:97-302,
+// :1260-1535) and GDMLTorchAssemble (sgdml/torchtools.py:110-392).
+//
+// Math, un-negated, per block (i,j), d_p = x_i - P_p x_j, n_p = sqrt5 |d_p|,
+// b_p = 5 exp(-n_p/sig)/(3 sig^4), c_p = (sig^2 + sig n_p) b_p:
+//     K_ij = sum_p [ 5 b_p (J_i^T d_p)(J_j^pT d_p)^T  -  c_p J_i^T J_j^p ]
+// The reference forms the dense D x 3N matrices and multiplies (2 D (3N)^2 flops per block).
+// Here the 6-nonzeros-per-row structure of the Jacobians is used instead:
+//   v_p = J_i^T d_p, u_p = J_j^pT d_p                  (3N-vectors, N-1 terms per entry)
+//   (J_i^T J_j^p)[(a,.),(b,.)] = G_i(a,a') (x) G_j(b,pi_p a)      if a' = pi_p^-1(b) != a
+//                              = sum_m G_i(a,m) (x) G_j(b,pi_p m) if pi_p(a) = b  ("diagonal")
+// with G_x(a,m) = d(desc{a,m})/d r_a = (r_m - r_a)/d^3 = +-g_x[pair(a,m)], so every output element
+// costs 2 FMAs per permutation and the kernel is bound by the HBM write of K (8 (3N)^2 bytes per
+// block).
+//
+// Work decomposition: one workgroup = one column point j x a chunk of row points i.
+// x_j, g_j stay in LDS; per i the workgroup stages x_i, g_i in LDS, computes d/u/v/diag
+// cooperatively, then every thread owns one output column c and 3*AC consecutive rows, so that a
+// wavefront writes contiguous 3N-double row segments of K.
+#include "common.h"
+
+struct AsmArgs {
+  const double* x;
+  const double* g;
+  const int32_t* tp;
+  const int32_t* perm;
+  const int32_t* pinv;
+  int64_t M;
+  int N, D, P;
+  double sig;
+  int use_E;
+  const int32_t* jlist;   // n_j column points (null: j = j0 + blockIdx.x)
+  const int32_t* colmap;  // (n_j, 3N) output column per block column, -1 = skip (null: dense)
+  int64_t j0;
+  int64_t col0;  // dense mode: output column of point j0
+  int i_chunk;
+  double* K;
+  int64_t ld;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* red, int tid, int nwaves) {
+  v = wave_sum(v);
+  __syncthreads();  // protects red[] reuse
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < nwaves; ++w) s += red[w];
+  return s;
+}
+
+template <int AC>
+__global__ void __launch_bounds__(768) assemble_kernel(AsmArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int N = A.N, D = A.D, P = A.P, N3 = 3 * N;
+  double* xj = smem;           // D
+  double* gj = xj + D;         // 3D  [k][3]
+  double* xi = gj + 3 * D;     // D
+  double* gi = xi + D;         // 3D
+  double* dv = gi + 3 * D;     // D
+  double* u = dv + D;          // 3N
+  double* vv = u + N3;         // 3N
+  double* dg = vv + N3;        // 9N
+  double* red = dg + 9 * N;    // 32
+
+  const int tid = threadIdx.x, T = blockDim.x, nwaves = T >> 6;
+  const int64_t jb = blockIdx.x;
+  const int64_t j = A.jlist ? A.jlist[jb] : A.j0 + jb;
+  const int64_t i_beg = (int64_t)blockIdx.y * A.i_chunk;
+  const int64_t i_end = (i_beg + A.i_chunk < A.M) ? i_beg + A.i_chunk : A.M;
+
+  const int n_chunks = (N + AC - 1) / AC;
+  const int item = tid;
+  const bool active = item < n_chunks * N3;
+  const int chunk = active ? item / N3 : 0;
+  const int c = active ? item - chunk * N3 : 0;
+  const int b = c / 3, beta = c - 3 * b;
+  int64_t outcol = -1;
+  if (active) outcol = A.colmap ? (int64_t)A.colmap[jb * N3 + c] : A.col0 + jb * N3 + c;
+
+  for (int k = tid; k < D; k += T) xj[k] = A.x[j * D + k];
+  for (int k = tid; k < 3 * D; k += T) gj[k] = A.g[j * 3 * D + k];
+
+  const double sig = A.sig;
+  const double inv_sig = 1.0 / sig;
+  const double sqrt5 = 2.23606797749978969641;
+  const double base_div = 5.0 / (3.0 * sig * sig * sig * sig);
+  const double e_fact = 5.0 / (3.0 * sig * sig * sig);
+
+  for (int64_t i = i_beg; i < i_end; ++i) {
+    __syncthreads();  // previous iteration's readers of xi/gi are done
+    for (int k = tid; k < D; k += T) xi[k] = A.x[i * D + k];
+    for (int k = tid; k < 3 * D; k += T) gi[k] = A.g[i * 3 * D + k];
+
+    double acc[AC][3];
+#pragma unroll
+    for (int aa = 0; aa < AC; ++aa) acc[aa][0] = acc[aa][1] = acc[aa][2] = 0.0;
+    double erow = 0.0;
+
+    for (int p = 0; p < P; ++p) {
+      const int32_t* tp = A.tp + (size_t)p * D;
+      const int32_t* perm = A.perm + (size_t)p * N;
+      const int32_t* pinv = A.pinv + (size_t)p * N;
+      __syncthreads();  // xi/gi staged; previous perm's phase B done
+      // ---- A1: d_p and its squared norm
+      double part = 0.0;
+      for (int k = tid; k < D; k += T) {
+        double dk = xi[k] - xj[tp[k]];
+        dv[k] = dk;
+        part += dk * dk;
+      }
+      const double nrm2 = block_sum(part, red, tid, nwaves);  // contains the barrier after dv[]
+      // ---- A2: u_p (3N), v_p (3N), diagonal blocks (9N)
+      for (int t = tid; t < 15 * N; t += T) {
+        if (t < N3) {
+          int bb = t / 3, be = t - 3 * bb;
+          int ap = pinv[bb];
+          double s = 0.0;
+          for (int m = 0; m < N; ++m) {
+            if (m == ap) continue;
+            int q = perm[m];
+            double gv = gj[pair_idx(bb, q) * 3 + be];
+            s += dv[pair_idx(ap, m)] * (bb < q ? gv : -gv);
+          }
+          u[t] = s;
+        } else if (t < 2 * N3) {
+          int tt = t - N3;
+          int a = tt / 3, al = tt - 3 * a;
+          double s = 0.0;
+          for (int m = 0; m < N; ++m) {
+            if (m == a) continue;
+            int k = pair_idx(a, m);
+            double gv = gi[k * 3 + al];
+            s += dv[k] * (a < m ? gv : -gv);
+          }
+          vv[tt] = s;
+        } else {
+          int tt = t - 2 * N3;
+          int a = tt / 9, r = tt - 9 * a;
+          int al = r / 3, be = r - 3 * al;
+          int pa = perm[a];
+          double s = 0.0;
+          for (int m = 0; m < N; ++m) {
+            if (m == a) continue;
+            int q = perm[m];
+            double g1 = gi[pair_idx(a, m) * 3 + al];
+            double g2 = gj[pair_idx(pa, q) * 3 + be];
+            double pr = g1 * g2;
+            s += ((a < m) == (pa < q)) ? pr : -pr;
+          }
+          dg[tt] = s;
+        }
+      }
+      __syncthreads();
+      // ---- B: accumulate this thread's outputs
+      const double nrm = sqrt5 * sqrt(nrm2);
+      const double ex = exp(-nrm * inv_sig);
+      const double bp = ex * base_div;
+      const double cp = (sig * sig + sig * nrm) * bp;
+      if (active) {
+        const double uc_raw = u[c];
+        const double uc = 5.0 * bp * uc_raw;
+        const int ap = pinv[b];
+#pragma unroll
+        for (int aa = 0; aa < AC; ++aa) {
+          const int a = chunk * AC + aa;
+          if (a < N) {
+            double t0, t1, t2;
+            if (a != ap) {
+              const int k = pair_idx(a, ap);
+              const int q = perm[a];
+              double w = cp * gj[pair_idx(b, q) * 3 + beta];
+              w = ((a < ap) == (b < q)) ? -w : w;
+              t0 = gi[k * 3 + 0] * w;
+              t1 = gi[k * 3 + 1] * w;
+              t2 = gi[k * 3 + 2] * w;
+            } else {
+              t0 = -cp * dg[a * 9 + 0 + beta];
+              t1 = -cp * dg[a * 9 + 3 + beta];
+              t2 = -cp * dg[a * 9 + 6 + beta];
+            }
+            acc[aa][0] += vv[3 * a + 0] * uc + t0;
+            acc[aa][1] += vv[3 * a + 1] * uc + t1;
+            acc[aa][2] += vv[3 * a + 2] * uc + t2;
+          }
+        }
+        if (A.use_E && chunk == 0) erow -= e_fact * (nrm + sig) * ex * uc_raw;  // train.py:235-248
+      }
+    }
+    // ---- write the block: row (3N i + 3a + alpha), column outcol
+    if (active && outcol >= 0) {
+#pragma unroll
+      for (int aa = 0; aa < AC; ++aa) {
+        const int a = chunk * AC + aa;
+        if (a < N) {
+          double* dst = A.K + ((int64_t)i * N3 + 3 * a) * A.ld + outcol;
+          dst[0] = acc[aa][0];
+          dst[A.ld] = acc[aa][1];
+          dst[2 * A.ld] = acc[aa][2];
+        }
+      }
+      if (A.use_E && chunk == 0) A.K[(A.M * N3 + i) * A.ld + outcol] = erow;
+    }
+  }
+}
+
+// Energy-constraint columns (train.py:250-300): for E column of point jj and every i,
+//   K[3N i + c, col] = -sum_p w_p (d_p^T J_i^p)[c],  d_p = x_jj - P_p x_i,
+//   K[3N M + i, col] = -sum_p (1 + n/sig (1 + n/(3 sig))) exp(-n/sig)
+struct EColArgs {
+  const double* x;
+  const double* g;
+  const int32_t* tp;
+  const int32_t* perm;
+  const int32_t* pinv;
+  int64_t M;
+  int N, D, P;
+  double sig;
+  const int32_t* jj_list;   // n_e points whose E column is requested
+  const int32_t* out_cols;  // output column for each
+  double* K;
+  int64_t ld;
+};
+
+__global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int N = A.N, D = A.D, N3 = 3 * N;
+  double* xq = smem;        // D  (x_jj)
+  double* xi = xq + D;      // D
+  double* gi = xi + D;      // 3D
+  double* dv = gi + 3 * D;  // D
+  double* red = dv + D;     // 32
+  const int tid = threadIdx.x, T = blockDim.x, nwaves = T >> 6;
+  const int64_t jj = A.jj_list[blockIdx.x];
+  const int64_t col = A.out_cols[blockIdx.x];
+  const int64_t i = blockIdx.y;
+  for (int k = tid; k < D; k += T) {
+    xq[k] = A.x[jj * D + k];
+    xi[k] = A.x[i * D + k];
+  }
+  for (int k = tid; k < 3 * D; k += T) gi[k] = A.g[i * 3 * D + k];
+  const double sig = A.sig, inv_sig = 1.0 / sig;
+  const double sqrt5 = 2.23606797749978969641;
+  const double e_fact = 5.0 / (3.0 * sig * sig * sig);
+  double out0 = 0.0, out1 = 0.0;  // up to 2 outputs per thread (3N <= 512)
+  double ee = 0.0;
+  for (int p = 0; p < A.P; ++p) {
+    const int32_t* tp = A.tp + (size_t)p * D;
+    const int32_t* perm = A.perm + (size_t)p * N;
+    const int32_t* pinv = A.pinv + (size_t)p * N;
+    __syncthreads();
+    double part = 0.0;
+    for (int k = tid; k < D; k += T) {
+      double dk = xq[k] - xi[tp[k]];
+      dv[k] = dk;
+      part += dk * dk;
+    }
+    const double nrm2 = block_sum(part, red, tid, nwaves);
+    const double nrm = sqrt5 * sqrt(nrm2);
+    const double ex = exp(-nrm * inv_sig);
+    const double w = e_fact * (nrm + sig) * ex;
+    for (int r = 0; r < 2; ++r) {
+      int t = tid + r * T;
+      if (t < N3) {
+        int bb = t / 3, be = t - 3 * bb;
+        int ap = pinv[bb];
+        double s = 0.0;
+        for (int m = 0; m < N; ++m) {
+          if (m == ap) continue;
+          int q = perm[m];
+          double gv = gi[pair_idx(bb, q) * 3 + be];
+          s += dv[pair_idx(ap, m)] * (bb < q ? gv : -gv);
+        }
+        if (r == 0)
+          out0 -= w * s;
+        else
+          out1 -= w * s;
+      }
+    }
+    ee -= (1.0 + (nrm * inv_sig) * (1.0 + nrm / (3.0 * sig))) * ex;
+  }
+  if (tid < N3) A.K[(i * N3 + tid) * A.ld + col] = out0;
+  if (tid + T < N3) A.K[(i * N3 + tid + T) * A.ld + col] = out1;
+  if (tid == 0) A.K[(A.M * N3 + i) * A.ld + col] = ee;
+}
+
+template <int AC>
+static void launch_asm(gdml_ctx* ctx, const AsmArgs& A, dim3 grid, int T, size_t lds) {
+  hipFuncSetAttribute((const void*)assemble_kernel<AC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)lds);
+  hipLaunchKernelGGL(assemble_kernel<AC>, grid, dim3(T), lds, ctx->stream, A);
+}
+
+static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
+  const int N = A.N, D = A.D;
+  static const int acs[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+  int AC = 24;
+  for (int v : acs) {
+    int items = ((N + v - 1) / v) * 3 * N;
+    if (items <= 768) {
+      AC = v;
+      break;
+    }
+  }
+  int items = ((N + AC - 1) / AC) * 3 * N;
+  if (items > 768)
+    return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assembly kernel supports up to %d atoms", 64);
+  int T = ((items + 63) / 64) * 64;
+  size_t lds = (size_t)(9 * D + 15 * N + 32) * 8;
+  if (lds > 160 * 1024)
+    return gdml_fail(ctx, GDML_ERR_UNSUPPORTED,
+                     "assembly kernel needs %zu bytes of LDS for N=%d (limit 160 KiB)", lds, N);
+  // choose the i-chunk so that the grid has >= ~8 workgroups per CU
+  int i_chunk = 16;
+  while (i_chunk > 1 && n_j * ((A.M + i_chunk - 1) / i_chunk) < 4096) i_chunk >>= 1;
+  A.i_chunk = i_chunk;
+  dim3 grid((unsigned)n_j, (unsigned)((A.M + i_chunk - 1) / i_chunk));
+  switch (AC) {
+#define CASE(v) \
+  case v:       \
+    launch_asm<v>(ctx, A, grid, T, lds); \
+    break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24)
+#undef CASE
+  }
+  ctx->launch_counter++;
+  HIP_CHECK(ctx, hipGetLastError());
+  return GDML_OK;
+}
+
+extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind,
+                               int64_t col_a, int64_t col_b, const int64_t* idx, int64_t n_idx,
+                               int64_t alloc_extra_rows, double* K_host_out, int64_t ldk) {
+  if (!ctx) return GDML_ERR_INVALID;
+  TrainSet& ts = ctx->ts;
+  if (!ts.x) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_assemble_K: call gdml_train_upload first");
+  if (!(sig > 0) || alloc_extra_rows < 0)
+    return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_assemble_K: bad sig / alloc_extra_rows");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int64_t M = ts.M;
+  const int N = ts.N, N3 = 3 * N;
+  const int64_t n_ff = M * N3;
+  const int64_t n_rows = n_ff + (use_E_cstr ? M : 0);
+
+  // ---- resolve the column selection into: dense point range, or (jlist, colmap), + E columns
+  std::vector<int32_t> jlist, colmap, e_pts, e_cols;
+  int64_t n_cols = 0, j0 = 0, n_j = 0;
+  bool dense = true;
+  if (col_kind == GDML_COLS_ALL) {
+    j0 = 0;
+    n_j = M;
+    n_cols = n_rows;
+    if (use_E_cstr)
+      for (int64_t e = 0; e < M; ++e) {
+        e_pts.push_back((int32_t)e);
+        e_cols.push_back((int32_t)(n_ff + e));
+      }
+  } else if (col_kind == GDML_COLS_POINTS) {
+    // reference slice path (train.py:1357-1374): points [col_a, col_b) of the 2M-long list
+    int64_t lim = M + (use_E_cstr ? M : 0);
+    if (col_a < 0 || col_b < col_a || col_b > lim)
+      return gdml_fail(ctx, GDML_ERR_INVALID, "point range [%lld,%lld) out of [0,%lld]",
+                       (long long)col_a, (long long)col_b, (long long)lim);
+    j0 = col_a;
+    int64_t jf_end = col_b < M ? col_b : M;
+    n_j = jf_end > col_a ? jf_end - col_a : 0;
+    n_cols = n_j * N3;
+    for (int64_t e = (col_a > M ? col_a : M); e < col_b; ++e) {
+      e_pts.push_back((int32_t)(e - M));
+      e_cols.push_back((int32_t)n_cols++);
+    }
+  } else if (col_kind == GDML_COLS_INDEX) {
+    if (!idx || n_idx < 1) return gdml_fail(ctx, GDML_ERR_INVALID, "empty column index list");
+    if (n_idx > n_rows)
+      return gdml_fail(ctx, GDML_ERR_INVALID, "Columns indexed beyond range.");  // train.py:1351
+    dense = false;
+    int64_t prev = -1;
+    for (int64_t q = 0; q < n_idx; ++q) {
+      int64_t cidx = idx[q];
+      if (cidx <= prev || cidx >= n_rows)
+        return gdml_fail(ctx, GDML_ERR_INVALID,
+                         "column indices must be sorted, unique and < %lld (train.py:1341-1345)",
+                         (long long)n_rows);
+      prev = cidx;
+      if (cidx < n_ff) {
+        int32_t pt = (int32_t)(cidx / N3);
+        if (jlist.empty() || jlist.back() != pt) {
+          jlist.push_back(pt);
+          colmap.insert(colmap.end(), N3, -1);
+        }
+        colmap[(jlist.size() - 1) * N3 + (cidx % N3)] = (int32_t)q;
+      } else {
+        e_pts.push_back((int32_t)(cidx - n_ff));
+        e_cols.push_back((int32_t)q);
+      }
+    }
+    n_j = (int64_t)jlist.size();
+    n_cols = n_idx;
+  } else {
+    return gdml_fail(ctx, GDML_ERR_INVALID, "unknown col_kind %d", col_kind);
+  }
+  if (!e_pts.empty() && !use_E_cstr)
+    return gdml_fail(ctx, GDML_ERR_INVALID, "energy columns requested without use_E_cstr");
+  if (K_host_out && ldk < n_cols)
+    return gdml_fail(ctx, GDML_ERR_INVALID, "ldk (%lld) < n_cols (%lld)", (long long)ldk,
+                     (long long)n_cols);
+
+  // ---- (re)allocate the device matrix
+  const int64_t tot_rows = n_rows + alloc_extra_rows;
+  const int64_t ld = n_cols;
+  if (ctx->K) {
+    GDML_TRY(ctx_free(ctx, ctx->K));
+    ctx->K = nullptr;
+  }
+  GDML_TRY(ctx_alloc(ctx, (void**)&ctx->K, tot_rows * ld * 8));
+  ctx->K_rows = n_rows;
+  ctx->K_cols = n_cols;
+  ctx->K_extra = alloc_extra_rows;
+  ctx->K_ld = ld;
+  ctx->K_factored = false;
+  ctx->K_sig = sig;
+  ctx->K_use_E = use_E_cstr;
+
+  int32_t *d_jlist = nullptr, *d_colmap = nullptr, *d_ep = nullptr, *d_ec = nullptr;
+  if (!dense && n_j > 0) {
+    GDML_TRY(ctx_alloc(ctx, (void**)&d_jlist, n_j * 4));
+    GDML_TRY(ctx_alloc(ctx, (void**)&d_colmap, n_j * N3 * 4));
+    HIP_CHECK(ctx, hipMemcpyAsync(d_jlist, jlist.data(), n_j * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(ctx, hipMemcpyAsync(d_colmap, colmap.data(), n_j * N3 * 4, hipMemcpyHostToDevice,
+                                  ctx->stream));
+  }
+  if (!e_pts.empty()) {
+    GDML_TRY(ctx_alloc(ctx, (void**)&d_ep, e_pts.size() * 4));
+    GDML_TRY(ctx_alloc(ctx, (void**)&d_ec, e_cols.size() * 4));
+    HIP_CHECK(ctx, hipMemcpyAsync(d_ep, e_pts.data(), e_pts.size() * 4, hipMemcpyHostToDevice,
+                                  ctx->stream));
+    HIP_CHECK(ctx, hipMemcpyAsync(d_ec, e_cols.data(), e_cols.size() * 4, hipMemcpyHostToDevice,
+                                  ctx->stream));
+  }
+
+  phase_begin(ctx);
+  int rc = GDML_OK;
+  if (n_j > 0) {
+    AsmArgs A;
+    A.x = ts.x; A.g = ts.g; A.tp = ts.tp; A.perm = ts.perm; A.pinv = ts.pinv;
+    A.M = M; A.N = N; A.D = ts.D; A.P = ts.P; A.sig = sig; A.use_E = use_E_cstr;
+    A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.col0 = 0; A.i_chunk = 8;
+    A.K = ctx->K; A.ld = ld;
+    rc = assemble_dispatch(ctx, A, n_j);
+  }
+  if (rc == GDML_OK && !e_pts.empty()) {
+    if (N3 > 512) rc = gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "E-constraint columns need 3N <= 512");
+    else {
+      EColArgs E;
+      E.x = ts.x; E.g = ts.g; E.tp = ts.tp; E.perm = ts.perm; E.pinv = ts.pinv;
+      E.M = M; E.N = N; E.D = ts.D; E.P = ts.P; E.sig = sig;
+      E.jj_list = d_ep; E.out_cols = d_ec; E.K = ctx->K; E.ld = ld;
+      size_t lds = (size_t)(6 * ts.D + 32) * 8;
+      hipFuncSetAttribute((const void*)ecol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds);
+      hipLaunchKernelGGL(ecol_kernel, dim3((unsigned)e_pts.size(), (unsigned)M), dim3(256), lds,
+                         ctx->stream, E);
+      ctx->launch_counter++;
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "ecol launch: %s", hipGetErrorString(e));
+    }
+  }
+  if (rc == GDML_OK) rc = phase_end(ctx, "assemble");
+  if (d_jlist) ctx_free(ctx, d_jlist);
+  if (d_colmap) ctx_free(ctx, d_colmap);
+  if (d_ep) ctx_free(ctx, d_ep);
+  if (d_ec) ctx_free(ctx, d_ec);
+  GDML_TRY(rc);
+
+  if (K_host_out) {
+    HIP_CHECK(ctx, hipMemcpy2DAsync(K_host_out, ldk * 8, ctx->K, ld * 8, n_cols * 8, n_rows,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return GDML_OK;
+}

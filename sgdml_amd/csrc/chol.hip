@@ -1,0 +1,516 @@
+// Analytic solve on gfx950: blocked fp64 Cholesky on the MFMA pipe + triangular solves.
+//
+// Replaces scipy.linalg.cho_factor / cho_solve as called by Analytic.solve
+// (sgdml/solvers/analytic.py:94-99; LAPACK dpotrf/dpotrs underneath) and the Cholesky / TRSM /
+// SYRK steps of Iterative._nystroem_cholesky_factor (sgdml/solvers/iterative.py:263-345).
+//
+// Storage: row-major, LOWER triangle referenced (A = L L^T, L overwrites the lower triangle; the
+// strict upper triangle is scratch and may be overwritten with garbage).
+//
+// Right-looking blocked algorithm, outer panel width NB (512), inner width 64:
+//   for each panel:   for each 64-wide sub-block:  potrf64 (one workgroup, LDS)
+//                                                  trsm64  (rows below, substitution in LDS)
+//                                                  gemm_nt (K=64 update of the rest of the panel)
+//                     syrk: trailing -= P P^T with gemm_nt (K=NB) on v_mfma_f64_16x16x4_f64
+// n^3/3 of the flops are in gemm_nt; everything else is O(n^2 NB).
+#include "common.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// C[M x N] -= A[M x K] * B[N x K]^T     (row-major, leading dimensions lda/ldb/ldc)
+// lower != 0: C is square-symmetric-updated, only tiles with tile_row >= tile_col are computed.
+// Workgroup: 256 threads = 4 waves (2 x 2), tile 128 x 128, each wave 64 x 64 = 4 x 4 MFMA tiles.
+// LDS: [row][BK+2] doubles per operand and stage (pitch 18 => conflict-free ds_read_b64 of the
+// MFMA operand pattern lane -> (row = l&15, k = l>>4), and conflict-free 16-byte row writes).
+// ------------------------------------------------------------------------------------------
+#define GT 128
+#define GBK 16
+#define GPITCH 18
+
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t M, N, K, lda, ldb, ldc;
+  int lower;
+  int tiles_m, tiles_n;
+  int64_t n_super;  // number of 8x8 super tiles enumerated
+  int super_n;      // super-tile columns
+};
+
+__device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int64_t ld,
+                                               int64_t row0, int64_t nrows, int64_t k0, int64_t K,
+                                               int tid, d2 (&r)[4]) {
+  // 128 rows x 16 k = 1024 chunks of 2 doubles; thread t -> chunks t, t+256, ...: row = c/8, kc = c%8
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    int cidx = tid + 256 * s;
+    int row = cidx >> 3, kc = (cidx & 7) * 2;
+    int64_t gr = row0 + row, gk = k0 + kc;
+    d2 v = {0.0, 0.0};
+    if (gr < nrows) {
+      const double* p = G + gr * ld + gk;
+      if (gk + 1 < K)
+        v = *reinterpret_cast<const d2*>(p);
+      else if (gk < K)
+        v.x = p[0];
+    }
+    r[s] = v;
+  }
+}
+
+__device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid, const d2 (&r)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    int cidx = tid + 256 * s;
+    int row = cidx >> 3, kc = (cidx & 7) * 2;
+    *reinterpret_cast<d2*>(S + row * GPITCH + kc) = r[s];
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
+  // ---- block -> tile mapping: XCD-aware 8x8 super tiles (block b runs on XCD b % 8)
+  const int64_t b = blockIdx.x;
+  const int64_t xcd = b & 7, loc = b >> 3;
+  const int64_t s = (loc >> 6) * 8 + xcd;
+  const int within = (int)(loc & 63);
+  if (s >= g.n_super) return;
+  int64_t SI, SJ;
+  if (g.lower) {
+    // s = SI (SI+1)/2 + SJ
+    SI = (int64_t)((sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
+    while (SI * (SI + 1) / 2 > s) --SI;
+    while ((SI + 1) * (SI + 2) / 2 <= s) ++SI;
+    SJ = s - SI * (SI + 1) / 2;
+  } else {
+    SI = s / g.super_n;
+    SJ = s - SI * g.super_n;
+  }
+  const int64_t ti = SI * 8 + (within >> 3), tj = SJ * 8 + (within & 7);
+  if (ti >= g.tiles_m || tj >= g.tiles_n) return;
+  if (g.lower && tj > ti) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t row0 = ti * GT, col0 = tj * GT;
+  const int li = lane & 15, lk = lane >> 4;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t nk = (g.K + GBK - 1) / GBK;
+  d2 ra[4], rb[4];
+  gemm_load_tile(g.A, g.lda, row0, g.M, 0, g.K, tid, ra);
+  gemm_load_tile(g.B, g.ldb, col0, g.N, 0, g.K, tid, rb);
+  gemm_store_tile(lds[0][0], tid, ra);
+  gemm_store_tile(lds[0][1], tid, rb);
+  __syncthreads();
+
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    if (kt + 1 < nk) {
+      gemm_load_tile(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
+      gemm_load_tile(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
+    }
+    const double* As = lds[cur][0] + (wm * 64 + li) * GPITCH + lk;
+    const double* Bs = lds[cur][1] + (wn * 64 + li) * GPITCH + lk;
+#pragma unroll
+    for (int ks = 0; ks < GBK; ks += 4) {
+      double a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[i * 16 * GPITCH + ks];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Bs[j * 16 * GPITCH + ks];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      gemm_store_tile(lds[cur ^ 1][0], tid, ra);
+      gemm_store_tile(lds[cur ^ 1][1], tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C -= acc.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t gc = col0 + wn * 64 + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
+        if (gr < g.M && gc < g.N) {
+          double* p = g.C + gr * g.ldc + gc;
+          *p -= acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+static int launch_gemm_nt_sub(gdml_ctx* ctx, const double* A, int64_t lda, const double* B,
+                              int64_t ldb, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                              int lower) {
+  if (M <= 0 || N <= 0 || K <= 0) return GDML_OK;
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.lower = lower;
+  g.tiles_m = (int)((M + GT - 1) / GT);
+  g.tiles_n = (int)((N + GT - 1) / GT);
+  int64_t sm = (g.tiles_m + 7) / 8, sn = (g.tiles_n + 7) / 8;
+  g.super_n = (int)sn;
+  g.n_super = lower ? sm * (sm + 1) / 2 : sm * sn;
+  int64_t groups = (g.n_super + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
+  int64_t blocks = groups * 512;
+  hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g);
+  ctx->launch_counter++;
+  HIP_CHECK(ctx, hipGetLastError());
+  return GDML_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// potrf on a w x w (w <= 64) diagonal block, in place (lower).  One workgroup of 256 threads.
+// info (device int): set to (global 1-based index of the failing pivot) if a pivot is <= 0 or NaN
+// and info was 0 (LAPACK dpotrf convention).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
+                                                      int64_t global_off, int* __restrict__ info) {
+  __shared__ double L[64 * 65];
+  __shared__ int fail;
+  const int tid = threadIdx.x;
+  if (tid == 0) fail = 0;
+  for (int e = tid; e < w * w; e += 256) {
+    int r = e / w, c = e - r * w;
+    L[r * 65 + c] = (c <= r) ? A[r * ld + c] : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < w; ++j) {
+    const double d = L[j * 65 + j];
+    if (!(d > 0.0)) {  // also catches NaN
+      if (tid == 0) {
+        fail = 1;
+        atomicCAS(info, 0, (int)(global_off + j + 1));
+      }
+      break;  // d is uniform across the workgroup
+    }
+    const double dj = sqrt(d);
+    const double inv = 1.0 / dj;
+    __syncthreads();
+    if (tid == 0) L[j * 65 + j] = dj;
+    for (int r = j + 1 + tid; r < w; r += 256) L[r * 65 + j] *= inv;
+    __syncthreads();
+    const int rem = w - j - 1;
+    for (int e = tid; e < rem * rem; e += 256) {
+      int r = j + 1 + e / rem, c = j + 1 + e % rem;
+      if (c <= r) L[r * 65 + c] -= L[r * 65 + j] * L[c * 65 + j];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int e = tid; e < w * w; e += 256) {
+    int r = e / w, c = e - r * w;
+    if (c <= r) A[r * ld + c] = L[r * 65 + c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// X[r, 0:w] <- X[r, 0:w] * L^-T for m rows (L = w x w lower block at Ld, w <= 64).  Exact forward
+// substitution per row (no explicit inverse): one thread owns one row, holds it in registers
+// (fully unrolled), L is broadcast from LDS.  x_c = (x_c - sum_{k<c} x_k L[c][k]) / L[c][c].
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ Ld,
+                                                     double* __restrict__ X, int64_t ld, int w,
+                                                     int64_t m) {
+  __shared__ __attribute__((aligned(16))) double Ls[64 * 64];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    int r = e >> 6, c = e & 63;
+    double v = (r == c) ? 1.0 : 0.0;  // identity padding for w < 64
+    if (r < w && c < w && c <= r) v = Ld[r * ld + c];
+    Ls[e] = v;
+  }
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+  if (r >= m) return;
+  double* xr = X + r * ld;
+  double x[64];
+  const bool al16 = ((reinterpret_cast<uintptr_t>(xr) & 15) == 0) && (w == 64);
+  if (al16) {
+#pragma unroll
+    for (int c = 0; c < 64; c += 2) {
+      d2 v = *reinterpret_cast<const d2*>(xr + c);
+      x[c] = v.x;
+      x[c + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 64; ++c) x[c] = (c < w) ? xr[c] : 0.0;
+  }
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    double s = x[c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) s -= x[k] * Ls[c * 64 + k];
+    x[c] = s / Ls[c * 64 + c];
+  }
+  if (al16) {
+#pragma unroll
+    for (int c = 0; c < 64; c += 2) {
+      d2 v = {x[c], x[c + 1]};
+      *reinterpret_cast<d2*>(xr + c) = v;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 64; ++c)
+      if (c < w) xr[c] = x[c];
+  }
+}
+
+// A <- -A + lam I on the lower triangle (analytic.py:65,82), tiled copy-free.
+__global__ void __launch_bounds__(256) negate_shift_kernel(double* __restrict__ A, int64_t n,
+                                                           int64_t ld, double lam) {
+  const int64_t r = blockIdx.x;
+  double* row = A + r * ld;
+  for (int64_t c = threadIdx.x; c <= r; c += 256) {
+    double v = -row[c];
+    if (c == r) v += lam;
+    row[c] = v;
+  }
+}
+
+int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out) {
+  HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  const int64_t NB = 512;
+  for (int64_t k0 = 0; k0 < n; k0 += NB) {
+    const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
+    for (int64_t jj = 0; jj < nb; jj += 64) {
+      const int64_t c0 = k0 + jj;
+      const int w = (int)((nb - jj < 64) ? nb - jj : 64);
+      double* Ad = A + c0 * ld + c0;
+      hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, ctx->stream, Ad, ld, w, c0,
+                         ctx->d_info);
+      ctx->launch_counter++;
+      const int64_t m = n - c0 - w;
+      if (m > 0) {
+        double* X = A + (c0 + w) * ld + c0;
+        hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0,
+                           ctx->stream, Ad, X, ld, w, m);
+        ctx->launch_counter++;
+        const int64_t ncols = k0 + nb - (c0 + w);
+        if (ncols > 0) {
+          // rest of the panel:  C[c0+w:n, c0+w:k0+nb] -= X[c0+w:n, :] X[c0+w:k0+nb, :]^T
+          GDML_TRY(launch_gemm_nt_sub(ctx, X, ld, X, ld, A + (c0 + w) * ld + (c0 + w), ld, m, ncols,
+                                      w, 0));
+        }
+      }
+    }
+    const int64_t t0 = k0 + nb;
+    if (t0 < n) {
+      const double* P = A + t0 * ld + k0;
+      GDML_TRY(launch_gemm_nt_sub(ctx, P, ld, P, ld, A + t0 * ld + t0, ld, n - t0, n - t0, nb, 1));
+    }
+  }
+  HIP_CHECK(ctx, hipGetLastError());
+  int info = 0;
+  HIP_CHECK(ctx, hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (info_out) *info_out = info;
+  return GDML_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Triangular solves with the factor (cho_solve, analytic.py:97-99), blocked by 64.
+// Forward  L z = b : per block J the kernel first solves the 64x64 diagonal system in LDS (every
+// workgroup redundantly: 32 KB from L2), then updates its rows below: b[r] -= L[r,J] z_J.
+// Backward L^T x = z : per block I (from the bottom) solve L_II^T x_I = z_I, then
+// z[c] -= sum_{r in I} L[r,c] x[r] for the columns c left of the block (one thread per column).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) trsv_fwd_kernel(const double* __restrict__ L, int64_t ld,
+                                                       int64_t n, int64_t c0, int w,
+                                                       double* __restrict__ b,
+                                                       double* __restrict__ z_out) {
+  __shared__ double Ls[64 * 65];
+  __shared__ double z[64];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < w * w; e += 256) {
+    int r = e / w, c = e - r * w;
+    Ls[r * 65 + c] = L[(c0 + r) * ld + c0 + c];
+  }
+  if (tid < w) z[tid] = b[c0 + tid];
+  __syncthreads();
+  // column-oriented substitution, 64 lanes of wave 0 (others wait)
+  for (int c = 0; c < w; ++c) {
+    if (tid == c) z[c] = z[c] / Ls[c * 65 + c];
+    __syncthreads();
+    if (tid > c && tid < w) z[tid] -= Ls[tid * 65 + c] * z[c];
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid < w) z_out[c0 + tid] = z[tid];
+  // rows below: one wave per row, lanes over the w columns
+  const int lane = tid & 63, wave = tid >> 6;
+  const int64_t first = c0 + w;
+  const double zl = lane < w ? z[lane] : 0.0;
+  for (int64_t r = first + (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+    double v = lane < w ? L[r * ld + c0 + lane] * zl : 0.0;
+    v = wave_sum(v);
+    if (lane == 0) b[r] -= v;
+  }
+}
+
+__global__ void __launch_bounds__(256) trsv_bwd_kernel(const double* __restrict__ L, int64_t ld,
+                                                       int64_t c0, int w, double* __restrict__ b,
+                                                       double* __restrict__ x_out) {
+  __shared__ double Ls[64 * 65];
+  __shared__ double x[64];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < w * w; e += 256) {
+    int r = e / w, c = e - r * w;
+    Ls[r * 65 + c] = L[(c0 + r) * ld + c0 + c];
+  }
+  if (tid < w) x[tid] = b[c0 + tid];
+  __syncthreads();
+  // L^T x = z : x_c = (z_c - sum_{r>c} L[r][c] x_r) / L[c][c], c descending
+  for (int c = w - 1; c >= 0; --c) {
+    if (tid == c) x[c] = x[c] / Ls[c * 65 + c];
+    __syncthreads();
+    if (tid < c) x[tid] -= Ls[c * 65 + tid] * x[c];
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid < w) x_out[c0 + tid] = x[tid];
+  // columns left of the block
+  for (int64_t c = (int64_t)blockIdx.x * 256 + tid; c < c0; c += (int64_t)gridDim.x * 256) {
+    double s = 0.0;
+    for (int r = 0; r < w; ++r) s += L[(c0 + r) * ld + c] * x[r];
+    b[c] -= s;
+  }
+}
+
+// d_b: right-hand side (destroyed), d_z: scratch (n), d_x: solution (n).  All device vectors.
+int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_b,
+                      double* d_z, double* d_x) {
+  for (int64_t c0 = 0; c0 < n; c0 += 64) {
+    int w = (int)((n - c0 < 64) ? n - c0 : 64);
+    int64_t rows = n - c0 - w;
+    int grid = (int)((rows + 3) / 4);
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(trsv_fwd_kernel, dim3(grid), dim3(256), 0, ctx->stream, L, ld, n, c0, w, d_b,
+                       d_z);
+    ctx->launch_counter++;
+  }
+  int64_t last = ((n - 1) / 64) * 64;
+  for (int64_t c0 = last; c0 >= 0; c0 -= 64) {
+    int w = (int)((n - c0 < 64) ? n - c0 : 64);
+    int grid = (int)((c0 + 255) / 256);
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(trsv_bwd_kernel, dim3(grid), dim3(256), 0, ctx->stream, L, ld, c0, w, d_z,
+                       d_x);
+    ctx->launch_counter++;
+  }
+  HIP_CHECK(ctx, hipGetLastError());
+  return GDML_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int gdml_chol_factor(gdml_ctx* ctx, double lam, int* info) {
+  if (!ctx) return GDML_ERR_INVALID;
+  if (!ctx->K) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_factor: assemble K first");
+  if (ctx->K_rows != ctx->K_cols)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_factor: resident K is %lld x %lld, not square",
+                     (long long)ctx->K_rows, (long long)ctx->K_cols);
+  if (ctx->K_factored) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_factor: already factored");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int64_t n = ctx->K_rows;
+  phase_begin(ctx);
+  hipLaunchKernelGGL(negate_shift_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->K, n,
+                     ctx->K_ld, lam);
+  ctx->launch_counter++;
+  int inf = 0;
+  GDML_TRY(chol_factor_device(ctx, ctx->K, n, ctx->K_ld, &inf));
+  GDML_TRY(phase_end(ctx, "factor"));
+  if (info) *info = inf;
+  ctx->K_lam = lam;
+  if (inf != 0) {
+    ctx->K_factored = false;
+    return gdml_fail(ctx, GDML_ERR_NOT_PD,
+                     "%d-th leading minor of the array is not positive definite", inf);
+  }
+  ctx->K_factored = true;
+  return GDML_OK;
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(double* __restrict__ x, int64_t n, double s) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) x[t] *= s;
+}
+__global__ void __launch_bounds__(256) axpy_kernel(double* __restrict__ y, const double* __restrict__ x,
+                                                   int64_t n, double a) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) y[t] += a * x[t];
+}
+// r = y - (-(Kx - lam x))... helper: r = y + kv  where kv = K x - lam x  (A x = -(K x - lam x))
+__global__ void __launch_bounds__(256) resid_kernel(const double* __restrict__ y,
+                                                    const double* __restrict__ kv, int64_t n,
+                                                    double* __restrict__ r) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) r[t] = y[t] + kv[t];
+}
+
+int operator_model_from_trainset(gdml_ctx* ctx, double sig);
+
+extern "C" int gdml_chol_solve(gdml_ctx* ctx, const double* y, int64_t n, int n_refine,
+                               double* alphas_out) {
+  if (!ctx || !y || !alphas_out) return GDML_ERR_INVALID;
+  if (!ctx->K || !ctx->K_factored)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_solve: no Cholesky factor resident");
+  if (n != ctx->K_rows) return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_chol_solve: n mismatch");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  void* buf = nullptr;
+  GDML_TRY(ctx_alloc(ctx, &buf, 6 * n * 8));
+  double* dx = (double*)buf;   // solution
+  double* dy = dx + n;         // right-hand side (kept)
+  double* db = dy + n;         // work copy of a right-hand side (destroyed by the solve)
+  double* dz = db + n;         // forward-substitution result
+  double* dr = dz + n;         // refinement correction
+  double* dkv = dr + n;        // K x - lam x
+  int rc = GDML_OK;
+  hipError_t e = hipMemcpyAsync(dy, y, n * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(db, dy, n * 8, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "copy: %s", hipGetErrorString(e));
+  if (rc == GDML_OK) {
+    phase_begin(ctx);
+    rc = chol_solve_device(ctx, ctx->K, n, ctx->K_ld, db, dz, dx);
+  }
+  if (rc == GDML_OK && n_refine > 0) rc = operator_model_from_trainset(ctx, ctx->K_sig);
+  for (int it = 0; rc == GDML_OK && it < n_refine; ++it) {
+    // r = y - A x,  A x = -(K x - lam x)  =>  r = y + (K x - lam x)
+    rc = matvec_device(ctx, ctx->K_lam, ctx->K_use_E, dx, n, dkv);
+    if (rc != GDML_OK) break;
+    hipLaunchKernelGGL(resid_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, dy, dkv, n, db);
+    rc = chol_solve_device(ctx, ctx->K, n, ctx->K_ld, db, dz, dr);
+    if (rc != GDML_OK) break;
+    hipLaunchKernelGGL(axpy_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, dx, dr, n, 1.0);
+  }
+  if (rc == GDML_OK) {
+    hipLaunchKernelGGL(scale_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, dx, n, -1.0);
+    rc = phase_end(ctx, "solve");
+  }
+  if (rc == GDML_OK) {
+    e = hipMemcpyAsync(alphas_out, dx, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+  }
+  int rc2 = ctx_free(ctx, buf);
+  return rc != GDML_OK ? rc : rc2;
+}

@@ -1,0 +1,137 @@
+// Internal definitions shared by the HIP translation units of libgdml_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gdml_hip.h"
+
+#define GDML_MAX_ATOMS 128
+
+struct PhaseStat {
+  double ms = 0.0;
+  int64_t launches = 0;
+};
+
+// Device-resident training set (gdml_train_upload).
+struct TrainSet {
+  int64_t M = 0;
+  int N = 0, D = 0, P = 0;
+  double* x = nullptr;       // (M,D)    descriptors
+  double* g = nullptr;       // (M,D,3)  compressed Jacobians
+  int32_t* tp = nullptr;     // (P,D)    descriptor permutations
+  int32_t* perm = nullptr;   // (P,N)    atom permutations  pi_p
+  int32_t* pinv = nullptr;   // (P,N)    inverse atom permutations
+  std::vector<int32_t> h_tp, h_perm, h_pinv;
+};
+
+// Device-resident model for prediction (gdml_predict_upload_model).
+struct Model {
+  int64_t M = 0;
+  int N = 0, D = 0, P = 0;
+  double sig = 0;
+  double* xp = nullptr;    // (M*P,D) permuted training descriptors (predict.py:426-431)
+  double* jap = nullptr;   // (M*P,D) permuted J_m alpha_m          (predict.py:433-441)
+  double* ja = nullptr;    // (M,D)   unpermuted J alpha (scratch for set_alphas)
+  double* aE = nullptr;    // (M*P)   alphas_E repeated per perm (predict.py:443-447) or null
+  int32_t* tp = nullptr;   // (P,D)
+  bool has_aE = false;
+};
+
+struct gdml_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  int64_t held = 0;
+  std::map<void*, int64_t> allocs;
+  std::map<std::string, PhaseStat> phases;
+  int64_t launch_counter = 0;
+
+  TrainSet ts;
+  Model model;
+
+  // kernel matrix / Cholesky factor
+  double* K = nullptr;
+  int64_t K_rows = 0, K_cols = 0, K_extra = 0, K_ld = 0;
+  bool K_factored = false;
+  double K_lam = 0, K_sig = 0;
+  int K_use_E = 0;
+
+  // Nystroem preconditioner L^-1 K_mn (m x n)
+  double* precon = nullptr;
+  int64_t precon_m = 0, precon_n = 0;
+
+  // scratch
+  double* scratch = nullptr;
+  int64_t scratch_bytes = 0;
+  double* slot[4] = {nullptr, nullptr, nullptr, nullptr};  // cached work buffers (ctx_slot)
+  int64_t slot_bytes[4] = {0, 0, 0, 0};
+  int* d_info = nullptr;
+
+  // comm
+  void* comm = nullptr;  // ncclComm_t
+  int rank = 0, world = 1;
+};
+
+int gdml_fail(gdml_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_CHECK(ctx, call)                                                              \
+  do {                                                                                    \
+    hipError_t e__ = (call);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return gdml_fail(ctx, e__ == hipErrorOutOfMemory ? GDML_ERR_OOM : GDML_ERR_HIP,     \
+                       "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
+                       __LINE__);                                                         \
+  } while (0)
+
+#define GDML_TRY(expr)          \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != GDML_OK) return rc__; \
+  } while (0)
+
+// context-tracked allocation helpers (ctx.hip)
+int ctx_alloc(gdml_ctx* ctx, void** p, int64_t bytes);
+int ctx_free(gdml_ctx* ctx, void* p);
+int ctx_scratch(gdml_ctx* ctx, int64_t bytes, double** out);
+void phase_begin(gdml_ctx* ctx);
+int phase_end(gdml_ctx* ctx, const char* name);
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers -----------------------------------------------------------------
+// index of the descriptor entry for the unordered atom pair {a,b}, a != b
+__device__ __forceinline__ int pair_idx(int a, int b) {
+  int hi = a > b ? a : b;
+  int lo = a > b ? b : a;
+  return (hi * (hi - 1)) / 2 + lo;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// internal cross-TU entry points
+int assemble_launch(gdml_ctx* ctx, double sig, int use_E_cstr, const int32_t* d_jlist,
+                    int64_t n_j, const int32_t* d_colmap, int64_t col0_all);
+int desc_device(gdml_ctx* ctx, const double* d_R, int64_t M, int N, const double* lat,
+                const double* lat_inv, double* d_x, double* d_g);
+int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_t B, double* d_E,
+                   double* d_F);
+int set_alphas_device(gdml_ctx* ctx, const double* d_alphas_F, const double* d_alphas_E);
+int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, int64_t n,
+                  double* d_out);
+int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info);
+int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_b,
+                      double* d_z, double* d_x);
+int operator_model_from_trainset(gdml_ctx* ctx, double sig);
+int ctx_slot(gdml_ctx* ctx, int slot, int64_t bytes, double** out);

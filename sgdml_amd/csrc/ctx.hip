@@ -1,0 +1,217 @@
+// Context, memory, phase timers, raw buffer helpers.
+#include <stdarg.h>
+
+#include "common.h"
+
+static std::string g_create_err;
+
+int gdml_fail(gdml_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_err = buf;
+  return code;
+}
+
+extern "C" int gdml_abi_version(void) { return 1; }
+
+extern "C" int gdml_device_count(int* n_out) {
+  if (!n_out) return GDML_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *n_out = 0;
+    return gdml_fail(nullptr, GDML_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *n_out = n;
+  return GDML_OK;
+}
+
+extern "C" int gdml_ctx_create(int device, gdml_ctx** ctx_out) {
+  if (!ctx_out) return GDML_ERR_INVALID;
+  *ctx_out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return gdml_fail(nullptr, GDML_ERR_HIP, "no HIP device visible (%s)",
+                     e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n)
+    return gdml_fail(nullptr, GDML_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+  gdml_ctx* ctx = new gdml_ctx();
+  ctx->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev0)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+      (e = hipMalloc((void**)&ctx->d_info, 64)) != hipSuccess) {
+    gdml_fail(nullptr, GDML_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    delete ctx;
+    return GDML_ERR_HIP;
+  }
+  *ctx_out = ctx;
+  return GDML_OK;
+}
+
+extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
+  if (!ctx) return GDML_OK;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  for (auto& kv : ctx->allocs) hipFree(kv.first);
+  ctx->allocs.clear();
+  if (ctx->d_info) hipFree(ctx->d_info);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+  delete ctx;
+  return GDML_OK;
+}
+
+extern "C" const char* gdml_last_error(const gdml_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" int gdml_sync(gdml_ctx* ctx) {
+  if (!ctx) return GDML_ERR_INVALID;
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
+  return GDML_OK;
+}
+
+extern "C" int gdml_mem_info(gdml_ctx* ctx, int64_t* held, int64_t* free_b, int64_t* total_b) {
+  if (!ctx) return GDML_ERR_INVALID;
+  size_t f = 0, t = 0;
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  HIP_CHECK(ctx, hipMemGetInfo(&f, &t));
+  if (held) *held = ctx->held;
+  if (free_b) *free_b = (int64_t)f;
+  if (total_b) *total_b = (int64_t)t;
+  return GDML_OK;
+}
+
+int ctx_alloc(gdml_ctx* ctx, void** p, int64_t bytes) {
+  *p = nullptr;
+  if (bytes <= 0) bytes = 8;
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(p, (size_t)bytes);
+  if (e != hipSuccess) {
+    *p = nullptr;
+    (void)hipGetLastError();
+    return gdml_fail(ctx, GDML_ERR_OOM, "hipMalloc(%lld bytes) failed: %s", (long long)bytes,
+                     hipGetErrorString(e));
+  }
+  ctx->allocs[*p] = bytes;
+  ctx->held += bytes;
+  return GDML_OK;
+}
+
+int ctx_free(gdml_ctx* ctx, void* p) {
+  if (!p) return GDML_OK;
+  auto it = ctx->allocs.find(p);
+  if (it == ctx->allocs.end()) return gdml_fail(ctx, GDML_ERR_INVALID, "free of unknown pointer");
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->held -= it->second;
+  ctx->allocs.erase(it);
+  HIP_CHECK(ctx, hipFree(p));
+  return GDML_OK;
+}
+
+int ctx_scratch(gdml_ctx* ctx, int64_t bytes, double** out) {
+  if (bytes > ctx->scratch_bytes) {
+    if (ctx->scratch) GDML_TRY(ctx_free(ctx, ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    int64_t want = bytes + bytes / 4;
+    GDML_TRY(ctx_alloc(ctx, (void**)&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return GDML_OK;
+}
+
+// Cached work buffer that only grows (avoids hipMalloc/hipFree in hot paths).
+int ctx_slot(gdml_ctx* ctx, int slot, int64_t bytes, double** out) {
+  if (bytes > ctx->slot_bytes[slot]) {
+    if (ctx->slot[slot]) GDML_TRY(ctx_free(ctx, ctx->slot[slot]));
+    ctx->slot[slot] = nullptr;
+    ctx->slot_bytes[slot] = 0;
+    int64_t want = bytes + bytes / 8;
+    GDML_TRY(ctx_alloc(ctx, (void**)&ctx->slot[slot], want));
+    ctx->slot_bytes[slot] = want;
+  }
+  *out = ctx->slot[slot];
+  return GDML_OK;
+}
+
+void phase_begin(gdml_ctx* ctx) {
+  ctx->launch_counter = 0;
+  (void)hipEventRecord(ctx->ev0, ctx->stream);
+}
+
+int phase_end(gdml_ctx* ctx, const char* name) {
+  HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  PhaseStat& s = ctx->phases[name];
+  s.ms = ms;
+  s.launches = ctx->launch_counter;
+  return GDML_OK;
+}
+
+extern "C" int gdml_phase_ms(gdml_ctx* ctx, const char* phase, double* ms_out,
+                             int64_t* launches_out) {
+  if (!ctx || !phase) return GDML_ERR_INVALID;
+  auto it = ctx->phases.find(phase);
+  if (it == ctx->phases.end()) return gdml_fail(ctx, GDML_ERR_STATE, "phase '%s' never ran", phase);
+  if (ms_out) *ms_out = it->second.ms;
+  if (launches_out) *launches_out = it->second.launches;
+  return GDML_OK;
+}
+
+extern "C" int gdml_dev_alloc(gdml_ctx* ctx, int64_t bytes, void** dev_out) {
+  if (!ctx || !dev_out) return GDML_ERR_INVALID;
+  return ctx_alloc(ctx, dev_out, bytes);
+}
+extern "C" int gdml_dev_free(gdml_ctx* ctx, void* dev) {
+  if (!ctx) return GDML_ERR_INVALID;
+  return ctx_free(ctx, dev);
+}
+extern "C" int gdml_memcpy_h2d(gdml_ctx* ctx, void* dev, const void* host, int64_t bytes) {
+  if (!ctx) return GDML_ERR_INVALID;
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  HIP_CHECK(ctx, hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return GDML_OK;
+}
+extern "C" int gdml_memcpy_d2h(gdml_ctx* ctx, void* host, const void* dev, int64_t bytes) {
+  if (!ctx) return GDML_ERR_INVALID;
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  HIP_CHECK(ctx, hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return GDML_OK;
+}
+
+extern "C" int gdml_K_dev(gdml_ctx* ctx, double** K_dev_out, int64_t* ld_out) {
+  if (!ctx) return GDML_ERR_INVALID;
+  if (!ctx->K) return gdml_fail(ctx, GDML_ERR_STATE, "no kernel matrix resident");
+  if (K_dev_out) *K_dev_out = ctx->K;
+  if (ld_out) *ld_out = ctx->K_ld;
+  return GDML_OK;
+}
+
+extern "C" int gdml_K_shape(gdml_ctx* ctx, int64_t* n_rows, int64_t* n_cols, int64_t* extra) {
+  if (!ctx) return GDML_ERR_INVALID;
+  if (!ctx->K) return gdml_fail(ctx, GDML_ERR_STATE, "no kernel matrix resident");
+  if (n_rows) *n_rows = ctx->K_rows;
+  if (n_cols) *n_cols = ctx->K_cols;
+  if (extra) *extra = ctx->K_extra;
+  return GDML_OK;
+}

@@ -1,0 +1,150 @@
+"""
+``GDMLPredict`` with the reference's public interface (sgdml/predict.py:248-1294), evaluated by
+the HIP prediction kernels (csrc/predict.hip).  Outputs, scaling (std, c) and the training-set
+mode (``predict()`` with cached descriptors, predict.py:1221-1233) follow the reference.
+"""
+import logging
+import sys
+
+import numpy as np
+
+from . import _lib
+from .utils.desc import Desc
+
+
+class GDMLPredict(object):
+    def __init__(
+        self,
+        model,
+        batch_size=None,
+        num_workers=None,
+        max_memory=None,
+        max_processes=None,
+        use_torch=False,
+        log_level=None,
+    ):
+        self.log = logging.getLogger(__name__)
+        if log_level is not None:
+            self.log.setLevel(log_level)
+
+        if 'type' not in model or not (model['type'] == 'm' or model['type'] == b'm'):
+            self.log.critical('The provided data structure is not a valid model.')
+            sys.exit()
+
+        self.n_atoms = model['z'].shape[0]
+        self.desc = Desc(self.n_atoms, max_processes=max_processes)
+
+        self.R_desc = None
+        self.R_d_desc = None
+
+        self.lat_and_inv = (
+            (np.asarray(model['lattice'], dtype=np.float64), np.linalg.inv(model['lattice']))
+            if 'lattice' in model
+            else None
+        )
+
+        R_desc_train = np.ascontiguousarray(np.asarray(model['R_desc'], dtype=np.float64).T)  # stored D x M
+        self.n_train = R_desc_train.shape[0]
+        self.sig = float(model['sig'])
+        self.std = float(model['std']) if 'std' in model else 1.0
+        self.c = float(model['c'])
+        self.n_perms = np.asarray(model['perms']).shape[0]
+        self.tril_perms_lin = np.asarray(model['tril_perms_lin'])
+        self._tril_perms = _lib.tril_perms_from_lin(self.tril_perms_lin, self.desc.dim)
+
+        # parameters of the reference's CPU pool; accepted and ignored (no pools on the GPU path)
+        self.max_memory, self.max_processes = max_memory, max_processes
+        self.use_torch = use_torch
+        self.bulk_mp, self.num_workers, self.chunk_size = False, 0, self.n_train
+        self.pool = None
+
+        self._ctx = _lib.Context()
+        self._ctx.predict_upload_model(
+            R_desc_train,
+            model['R_d_desc_alpha'],
+            self._tril_perms,
+            self.sig,
+            model['alphas_E'] if 'alphas_E' in model else None,
+        )
+        self._train_resident = False
+
+    def __del__(self):
+        ctx = getattr(self, '_ctx', None)
+        if ctx is not None:
+            ctx.close()
+
+    # ---- training-mode hooks (predict.py:510-601)
+
+    def set_R_desc(self, R_desc):
+        self.R_desc = R_desc
+        self._train_resident = False
+
+    def set_R_d_desc(self, R_d_desc):
+        self.R_d_desc = R_d_desc
+        self._train_resident = False
+
+    def _ensure_train_resident(self):
+        if self._train_resident:
+            return
+        if self.R_d_desc is None:
+            raise AssertionError('set_R_d_desc() must be called first')
+        R_desc = self.R_desc
+        if R_desc is None:
+            raise AssertionError('set_R_desc() must be called first')
+        self._ctx.train_upload(R_desc, self.R_d_desc, self._tril_perms)
+        self._train_resident = True
+
+    def set_alphas(self, alphas_F, alphas_E=None):
+        """Re-target the model with new coefficients (predict.py:551-601); J alpha runs on the GPU."""
+        self._ensure_train_resident()
+        self._ctx.set_alphas(alphas_F, alphas_E)
+
+    # ---- CPU-tuning API of the reference: no-ops here, like its torch path (predict.py:826-830)
+
+    def prepare_parallel(self, n_bulk=1, n_reps=1, return_is_from_cache=False):
+        return None
+
+    def set_opt_num_workers_and_batch_size_fast(self, n_bulk=1, n_reps=1):
+        return None
+
+    def _set_num_workers(self, num_workers=None, force_reset=False):
+        self.num_workers = 0
+
+    def _set_chunk_size(self, chunk_size=None):
+        self.chunk_size = self.n_train
+
+    def _set_batch_size(self, batch_size=None):
+        self._set_chunk_size(batch_size)
+
+    def _set_bulk_mp(self, bulk_mp=False):
+        self.bulk_mp = False
+
+    def get_GPU_batch(self):
+        return self.n_train
+
+    # ---- prediction
+
+    def predict(self, R=None, return_E=True):
+        """Energies (B,) and forces (B,3N) for geometries R (B,3N); R=None -> training-set mode."""
+        if R is not None:
+            R = np.asarray(R, dtype=np.float64)
+            if R.ndim == 1:
+                R = R[None, :]
+            E, F = self._ctx.predict(R.reshape(R.shape[0], -1), self.lat_and_inv, return_E=return_E)
+        else:
+            if self.R_desc is None or self.R_d_desc is None:
+                self.log.critical(
+                    'A reference to the training geometry descriptors and Jacobians needs to be set '
+                    'for this function to work without arguments.'
+                )
+                raise AssertionError('training descriptors not set')
+            self._ensure_train_resident()
+            E, F = self._ctx.predict(None, None, return_E=return_E)
+
+        F *= self.std  # predict.py:1286-1288
+        ret = (F,)
+        if return_E:
+            E *= self.std
+            E += self.c
+            ret = (E,) + ret
+        return ret

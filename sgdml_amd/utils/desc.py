@@ -1,0 +1,105 @@
+"""
+Descriptor helper with the reference's ``Desc`` interface (sgdml/utils/desc.py:242-539).
+
+``from_R`` runs on the GPU (gdml_desc_from_R).  The remaining methods are tiny host-side index
+utilities kept for API compatibility; the hot path never calls them (J v and J^T f are evaluated
+inside the HIP kernels: predict.hip / assemble.hip).
+"""
+import timeit
+
+import numpy as np
+
+from .. import _lib
+
+
+class Desc(object):
+    def __init__(self, n_atoms, max_processes=None):
+        self.n_atoms = n_atoms
+        self.dim_i = 3 * n_atoms
+        self.dim = (n_atoms * (n_atoms - 1)) // 2
+        self.tril_indices = np.tril_indices(n_atoms, k=-1)
+        self.dim_range = np.arange(self.dim)
+        self.max_processes = max_processes  # unused: no process pools on the GPU path
+        self._ctx = None
+
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = _lib.Context()
+        return self._ctx
+
+    def from_R(self, R, lat_and_inv=None, max_processes=None, callback=None):
+        """R (M,3N) -> R_desc (M,D), R_d_desc (M,D,3)   [desc.py:288-365]"""
+        R = np.asarray(R, dtype=np.float64)
+        if R.ndim == 1:
+            R = R[None, :]
+        M = R.shape[0]
+        start = timeit.default_timer()
+        R_desc, R_d_desc = self._context().desc_from_R(R.reshape(M, -1), self.n_atoms, lat_and_inv)
+        if callback is not None:
+            dur_s = timeit.default_timer() - start
+            callback(M, M, sec_disp_str='took {:.1f} s'.format(dur_s) if dur_s >= 0.1 else '')
+        return R_desc, R_d_desc
+
+    # -- host-side helpers (API compatibility) ------------------------------------------------
+
+    def d_desc_dot_vec(self, R_d_desc, vecs, overwrite_vecs=False):
+        """J v  (desc.py:368-385)."""
+        R_d_desc = np.asarray(R_d_desc)
+        if R_d_desc.ndim == 2:
+            R_d_desc = R_d_desc[None]
+        vecs = np.asarray(vecs)
+        if vecs.ndim == 1:
+            vecs = vecs[None]
+        i, j = self.tril_indices
+        v = vecs.reshape(vecs.shape[0], -1, 3)
+        return np.sum(R_d_desc * (v[:, j, :] - v[:, i, :]), axis=-1)
+
+    def vec_dot_d_desc(self, R_d_desc, vecs, out=None):
+        """J^T f  (desc.py:388-408)."""
+        R_d_desc = np.asarray(R_d_desc)
+        if R_d_desc.ndim == 2:
+            R_d_desc = R_d_desc[None]
+        vecs = np.asarray(vecs)
+        if vecs.ndim == 1:
+            vecs = vecs[None]
+        i, j = self.tril_indices
+        w = R_d_desc * vecs[..., None]
+        n = w.shape[0]
+        res = np.zeros((n, self.n_atoms, 3))
+        for a in range(n):
+            np.add.at(res[a], j, w[a])
+            np.subtract.at(res[a], i, w[a])
+        return res.reshape(n, -1)
+
+    def d_desc_from_comp(self, R_d_desc, out=None):
+        """(M,D,3) -> (M,D,3N)  (desc.py:422-471)."""
+        R_d_desc = np.asarray(R_d_desc)
+        if R_d_desc.ndim == 2:
+            R_d_desc = R_d_desc[None]
+        n = R_d_desc.shape[0]
+        i, j = self.tril_indices
+        full = np.zeros((n, self.dim, self.n_atoms, 3)) if out is None else out.reshape(n, self.dim, self.n_atoms, 3)
+        full[:, self.dim_range, j, :] = R_d_desc
+        full[:, self.dim_range, i, :] = -R_d_desc
+        return full.reshape(n, self.dim, self.dim_i)
+
+    def d_desc_to_comp(self, R_d_desc):
+        """(M,D,3N) -> (M,D,3)  (desc.py:473-507): entry of atom j_k."""
+        R_d_desc = np.asarray(R_d_desc)
+        if R_d_desc.ndim == 2:
+            R_d_desc = R_d_desc[None]
+        n = R_d_desc.shape[0]
+        i, j = self.tril_indices
+        full = R_d_desc.reshape(n, self.dim, self.n_atoms, 3)
+        return full[:, self.dim_range, j, :]
+
+    @staticmethod
+    def perm(perm):
+        """Atom permutation -> descriptor permutation (desc.py:509-539)."""
+        perm = np.asarray(perm)
+        n = len(perm)
+        i, j = np.tril_indices(n, -1)
+        idx = np.zeros((n, n), dtype=int)
+        idx[i, j] = np.arange(len(i))
+        idx = idx + idx.T
+        return idx[perm[i], perm[j]]

@@ -1,0 +1,119 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol declared in
+include/gdml_hip.h, the ctypes table matches the header, and the product path fails loudly
+(no CPU fallback) when no GPU is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sgdml_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'gdml_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(gdml_[a-zA-Z0-9_]+)\s*\(', src)) - {'gdml_pcg_cb'})
+
+
+def test_header_and_ctypes_table_agree():
+    assert _header_functions() == sorted(_lib.SIGNATURES.keys())
+
+
+def test_library_exports_every_header_symbol():
+    lib = _lib.load()
+    for name in _header_functions():
+        assert hasattr(lib, name), name
+    assert lib.gdml_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import ctypes as C
+
+    lib = _lib.load()
+    n = C.c_int(-1)
+    lib.gdml_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.GDMLHipError):
+        _lib.Context()
+    from sgdml_amd.train import GDMLTrain
+
+    t = GDMLTrain()
+    try:
+        with pytest.raises(_lib.GDMLHipError):
+            t._context()
+    finally:
+        t.__del__()
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'sgdml_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dp, f)).read()
+                assert 'oracle' not in txt.replace('no CPU fallback', ''), os.path.join(dp, f)
+
+
+def test_tril_perms_roundtrip():
+    from oracle import gdml_oracle as orc
+
+    perms = np.array([[0, 1, 2, 3, 4], [1, 0, 2, 3, 4], [0, 1, 3, 2, 4], [1, 0, 3, 2, 4]])
+    tp = orc.tril_perms_from_atom_perms(perms)
+    lin = orc.tril_perms_lin_from_tril_perms(tp)
+    assert np.array_equal(_lib.tril_perms_from_lin(lin, tp.shape[1]), tp)
+
+
+def test_desc_host_helpers_match_oracle():
+    from oracle import gdml_oracle as orc
+    from sgdml_amd.utils.desc import Desc
+
+    rs = np.random.RandomState(0)
+    N, M = 6, 4
+    R = rs.normal(size=(M, 3 * N)) * 2
+    xd, gd = orc.desc_from_R(R)
+    d = Desc(N)
+    v = rs.normal(size=(M, 3 * N))
+    np.testing.assert_allclose(d.d_desc_dot_vec(gd, v), orc.d_desc_dot_vec(gd, v), rtol=1e-13)
+    f = rs.normal(size=(M, d.dim))
+    np.testing.assert_allclose(d.vec_dot_d_desc(gd, f), orc.vec_dot_d_desc(gd, f), rtol=1e-13, atol=1e-14)
+    full = d.d_desc_from_comp(gd)
+    np.testing.assert_allclose(full, orc.d_desc_from_comp(gd))
+    np.testing.assert_allclose(d.d_desc_to_comp(full), gd)
+    p = np.array([2, 0, 1, 3, 5, 4])
+    assert np.array_equal(Desc.perm(p), orc.desc_perm(p))
+
+
+def test_draw_strat_sample_properties():
+    from sgdml_amd.train import GDMLTrain
+
+    t = GDMLTrain()
+    try:
+        np.random.seed(3)
+        T = np.random.normal(size=500)
+        idx = t.draw_strat_sample(T, 50)
+        assert len(idx) == 50 and len(set(idx.tolist())) == 50
+        excl = idx[:10]
+        idx2 = t.draw_strat_sample(T, 40, excl_idxs=excl)
+        assert len(idx2) == 40 and not set(idx2.tolist()) & set(excl.tolist())
+        assert np.array_equal(t.draw_strat_sample(T[:7], 7), np.arange(7))
+        with pytest.raises(Exception):
+            GDMLTrain()  # singleton, train.py:336-342
+    finally:
+        t.__del__()
+
+
+def test_dataset_md5_matches_reference_recipe():
+    import hashlib
+
+    from sgdml_amd.utils import io
+
+    rs = np.random.RandomState(1)
+    ds = {'z': np.arange(3), 'R': rs.normal(size=(4, 3, 3)), 'E': rs.normal(size=4), 'F': rs.normal(size=(4, 3, 3))}
+    h = hashlib.md5()
+    for k in ['z', 'R', 'E', 'F']:
+        h.update(hashlib.md5(ds[k].ravel()).digest())
+    assert io.dataset_md5(ds) == h.hexdigest().encode('utf-8')

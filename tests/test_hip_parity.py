@@ -1,0 +1,244 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference-generated golden
+fixtures and against the NumPy oracle on seeded inputs.  Tolerances (fp64, stated per test):
+  K        : max|dK| <= 1e-12 * max|K|                       
+  solve    : ||(-K + lam I)(-alpha) - y|| / ||y|| <= 1e-8    (cond ~ 1/lam, no elementwise alpha parity)
+  predict  : |dF| <= 1e-10 max|F| + cancellation floor       (see test_oracle_golden.cancel_floor)
+"""
+import numpy as np
+import pytest
+
+from oracle import gdml_oracle as orc
+from tests.test_oracle_golden import _lat, _model, _tril_perms, cancel_floor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from sgdml_amd import _lib
+
+    c = _lib.Context()
+    yield c
+    c.close()
+
+
+def test_desc(golden, ctx):
+    g = golden
+    M, N = g['R_train'].shape[:2]
+    xd, gd = ctx.desc_from_R(g['R_train'].reshape(M, -1), N, _lat(g))
+    np.testing.assert_allclose(xd, g['R_desc'], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(gd, g['R_d_desc'], rtol=1e-12, atol=1e-15)
+
+
+def test_K_full(golden, ctx):
+    g = golden
+    ctx.train_upload(g['R_desc'], g['R_d_desc'], _tril_perms(g))
+    K = ctx.assemble_K(float(g['sig']), bool(g['use_E_cstr']), to_host=True)
+    assert K.shape == g['K'].shape
+    assert np.abs(K - g['K']).max() <= 1e-12 * np.abs(g['K']).max()
+    # device-resident copy is the same matrix
+    assert np.array_equal(ctx.K_to_host(), K)
+
+
+def test_K_columns(golden, ctx):
+    g = golden
+    n = g['K'].shape[0]
+    ex = len(g['col_idxs'])
+    ctx.train_upload(g['R_desc'], g['R_d_desc'], _tril_perms(g))
+    Kc = ctx.assemble_K(float(g['sig']), bool(g['use_E_cstr']), idx=g['col_idxs'], alloc_extra_rows=ex, to_host=True)
+    assert Kc.shape == (n + ex, ex)
+    scale = np.abs(g['K']).max()
+    assert np.abs(Kc[:n] - g['K_cols']).max() <= 1e-12 * scale
+    N3 = 3 * g['R_train'].shape[1]
+    pts = g['K_slice'].shape[1] // N3
+    Ks = ctx.assemble_K(float(g['sig']), bool(g['use_E_cstr']), points=(0, pts), to_host=True)
+    assert np.abs(Ks - g['K_slice']).max() <= 1e-12 * scale
+
+
+def test_K_bad_columns(golden, ctx):
+    g = golden
+    ctx.train_upload(g['R_desc'], g['R_d_desc'], _tril_perms(g))
+    with pytest.raises(ValueError):
+        ctx.assemble_K(float(g['sig']), False, idx=np.array([3, 2]))  # unsorted (train.py:1345)
+    with pytest.raises(ValueError):
+        ctx.assemble_K(float(g['sig']), False, idx=np.array([0, 10**9]))
+
+
+def test_analytic_solve(golden, ctx):
+    g = golden
+    lam = float(g['lam'])
+    ctx.train_upload(g['R_desc'], g['R_d_desc'], _tril_perms(g))
+    ctx.assemble_K(float(g['sig']), bool(g['use_E_cstr']))
+    assert ctx.chol_factor(lam) == 0
+    alphas = ctx.chol_solve(g['y'])
+    A = -g['K'] + lam * np.eye(g['K'].shape[0])
+    r = A @ (-alphas) - g['y']
+    assert np.linalg.norm(r) / np.linalg.norm(g['y']) < 1e-8
+    # factor parity with LAPACK on the lower triangle
+    import scipy.linalg as sla
+
+    L = np.tril(ctx.K_to_host())
+    Lref = sla.cholesky(A, lower=True)
+    assert np.abs(L @ L.T - A).max() <= 1e-13 * np.abs(A).max()
+    assert np.abs(L - Lref).max() <= 1e-6 * np.abs(Lref).max()
+
+
+def test_predict(golden, ctx):
+    g = golden
+    m = _model(g)
+    tp = _tril_perms(g)
+    R_desc_train = np.ascontiguousarray(m['R_desc'].T)
+    ctx.predict_upload_model(R_desc_train, m['R_d_desc_alpha'], tp, float(g['sig']), m.get('alphas_E'))
+    fl = cancel_floor(g)
+    E, F = ctx.predict(g['R_test'].reshape(len(g['R_test']), -1), _lat(g))
+    E = E * m['std'] + m['c']
+    F = F * m['std']
+    assert np.abs(F - g['F_test']).max() <= 1e-10 * np.abs(g['F_test']).max() + fl
+    assert np.abs(E - g['E_test']).max() <= 1e-10 * max(1.0, np.abs(g['E_test']).max()) + fl * float(g['sig'])
+    # training-set mode
+    ctx.train_upload(g['R_desc'], g['R_d_desc'], tp)
+    E, F = ctx.predict(None)
+    E = E * m['std'] + m['c']
+    F = F * m['std']
+    assert np.abs(F - g['F_train_pred']).max() <= 1e-10 * np.abs(g['F_train_pred']).max() + fl
+    assert np.abs(E - g['E_train_pred']).max() <= 1e-10 * max(1.0, np.abs(g['E_train_pred']).max()) + fl * float(g['sig'])
+    # force-only call returns no energies
+    E2, F2 = ctx.predict(g['R_test'].reshape(len(g['R_test']), -1), _lat(g), return_E=False)
+    assert E2 is None and np.array_equal(F2 * m['std'], ctx.predict(g['R_test'].reshape(len(g['R_test']), -1), _lat(g))[1] * m['std'])
+
+
+def test_kernel_matvec(golden, ctx):
+    g = golden
+    tp = _tril_perms(g)
+    M = g['R_desc'].shape[0]
+    ctx.train_upload(g['R_desc'], g['R_d_desc'], tp)
+    ctx.predict_upload_model(g['R_desc'], np.zeros_like(g['R_desc']), tp, float(g['sig']),
+                             np.zeros(M) if bool(g['use_E_cstr']) else None)
+    Kv = ctx.kernel_matvec(float(g['lam']), bool(g['use_E_cstr']), g['v'])
+    assert np.abs(Kv - g['Kv']).max() <= 1e-11 * np.abs(g['Kv']).max()
+
+
+def test_dropin_train_predict(golden):
+    """End to end through the reference's public API: task -> GDMLTrain.train -> GDMLPredict."""
+    from sgdml_amd.predict import GDMLPredict
+    from sgdml_amd.train import GDMLTrain
+
+    g = golden
+    M, N = g['R_train'].shape[:2]
+    task = {
+        'type': 't', 'code_version': '1.0.3', 'dataset_name': np.array('synth'), 'dataset_theory': np.array('pair'),
+        'z': np.ones(N, dtype=int) * 6, 'R_train': g['R_train'], 'F_train': g['F_train'], 'E_train': g['E_train'],
+        'idxs_train': np.arange(M), 'md5_train': 'x', 'idxs_valid': np.arange(M, M + 7), 'md5_valid': 'x',
+        'sig': int(g['sig']), 'lam': float(g['lam']), 'use_E': True, 'use_E_cstr': bool(g['use_E_cstr']),
+        'use_sym': g['perms'].shape[0] > 1, 'perms': g['perms'],
+    }
+    if 'lattice' in g:
+        task['lattice'] = g['lattice']
+    trainer = GDMLTrain()
+    try:
+        model = trainer.train(task)
+    finally:
+        trainer.__del__()
+    assert model['solver_name'] == 'analytic' and model['type'] == 'm'
+    assert np.array_equal(model['tril_perms_lin'], g['tril_perms_lin'])
+    np.testing.assert_allclose(model['std'], float(g['y_std']), rtol=1e-14)
+    pred = GDMLPredict(model)
+    E, F = pred.predict(g['R_test'].reshape(len(g['R_test']), -1))
+    # alpha is conditioning-limited (lam = 1e-10): compare predictions loosely with the reference's
+    assert np.abs(F - g['F_test']).max() <= 2e-4 * np.abs(g['F_test']).max()
+    assert np.abs(E - g['E_test']).max() <= 2e-4 * max(1.0, np.abs(g['E_test']).max())
+    # and the model reproduces its own training forces (interpolation, lam tiny)
+    pred.set_R_desc(g['R_desc'])
+    pred.set_R_d_desc(g['R_d_desc'])
+    E_tr, F_tr = pred.predict()
+    assert np.abs(F_tr.reshape(g['F_train'].shape) - g['F_train']).max() <= 1e-5 * np.abs(g['F_train']).max()
+
+
+@pytest.mark.parametrize('N,M,P', [(21, 24, 1), (12, 30, 2), (33, 6, 1)])
+def test_K_and_predict_vs_oracle_seeded(ctx, N, M, P):
+    ds = orc.synth_dataset(N, M + 5, seed=N * 100 + M, jitter=0.2)
+    R = ds['R'].reshape(M + 5, -1)
+    perms = [list(range(N))]
+    if P == 2:
+        p2 = list(range(N))
+        p2[0], p2[1] = 1, 0
+        perms.append(p2)
+    tp = orc.tril_perms_from_atom_perms(np.array(perms))
+    lin = orc.tril_perms_lin_from_tril_perms(tp)
+    xd, gd = ctx.desc_from_R(R[:M], N)
+    xo, go = orc.desc_from_R(R[:M])
+    np.testing.assert_allclose(xd, xo, rtol=1e-13)
+    sig = 25.0
+    ctx.train_upload(xo, go, tp)
+    K = ctx.assemble_K(sig, False, to_host=True)
+    Ko = orc.assemble_K(xo, go, lin, sig)
+    assert np.abs(K - Ko).max() <= 1e-12 * np.abs(Ko).max()
+    assert np.abs(K - K.T).max() <= 1e-13 * np.abs(K).max()
+    rs = np.random.RandomState(5)
+    v = rs.normal(size=K.shape[0])
+    JA = orc.d_desc_dot_vec(go, v.reshape(M, -1))
+    ctx.predict_upload_model(xo, JA, tp, sig, None)
+    E, F = ctx.predict(R[M:])
+    xq, gq = orc.desc_from_R(R[M:])
+    Eo, Fo = orc.predict_from_desc(xq, gq, xo, JA, tp, sig)
+    assert np.abs(F - Fo).max() <= 1e-11 * np.abs(Fo).max()
+    assert np.abs(E - Eo).max() <= 1e-11 * np.abs(Eo).max()
+
+
+@pytest.mark.parametrize('n', [700, 1537])
+def test_cholesky_multi_panel(ctx, n):
+    """Factor sizes that span several 512-wide panels and a ragged last block."""
+    import ctypes as C
+
+    import scipy.linalg as sla
+    from sgdml_amd import _lib
+
+    rs = np.random.RandomState(n)
+    B = rs.normal(size=(n, n + 20))
+    A = B @ B.T / n + 0.5 * np.eye(n)
+    # drive the device factorisation directly on an uploaded matrix via a K-shaped problem:
+    # use N=2 atoms (3N=6) is not flexible enough -> call the raw entry through a fake training set
+    # is overkill; instead check through gdml_chol_factor by loading A as "-K": assemble a dummy K of
+    # the right size and overwrite it.
+    M = (n + 5) // 6
+    ds = orc.synth_dataset(2, M, seed=1)
+    xo, go = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = np.zeros((1, 1), dtype=np.int64)
+    ctx.train_upload(xo, go, tp)
+    ctx.assemble_K(10.0, False)
+    rows, cols, _ = ctx.K_shape()
+    n2 = rows
+    B = rs.normal(size=(n2, n2 + 20))
+    A = B @ B.T / n2 + 0.5 * np.eye(n2)
+    p, ld = C.c_void_p(), C.c_int64()
+    ctx._check(ctx._lib.gdml_K_dev(ctx._h, C.byref(p), C.byref(ld)))
+    buf = np.zeros((n2, ld.value))
+    buf[:, :n2] = -A
+    ctx._check(ctx._lib.gdml_memcpy_h2d(ctx._h, p, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+    assert ctx.chol_factor(0.0) == 0
+    L = np.tril(ctx.K_to_host())
+    Lref = sla.cholesky(A, lower=True)
+    assert np.abs(L - Lref).max() <= 1e-11 * np.abs(Lref).max()
+    y = rs.normal(size=n2)
+    x = -ctx.chol_solve(y)
+    assert np.linalg.norm(A @ x - y) <= 1e-11 * np.linalg.norm(y)
+
+
+def test_cholesky_not_pd_reports_lapack_info(ctx):
+    import ctypes as C
+
+    M = 40
+    ds = orc.synth_dataset(2, M, seed=1)
+    xo, go = orc.desc_from_R(ds['R'].reshape(M, -1))
+    ctx.train_upload(xo, go, np.zeros((1, 1), dtype=np.int64))
+    ctx.assemble_K(10.0, False)
+    n = ctx.K_shape()[0]
+    A = np.eye(n)
+    A[100, 100] = -1.0
+    p, ld = C.c_void_p(), C.c_int64()
+    ctx._check(ctx._lib.gdml_K_dev(ctx._h, C.byref(p), C.byref(ld)))
+    buf = np.zeros((n, ld.value))
+    buf[:, :n] = -A
+    ctx._check(ctx._lib.gdml_memcpy_h2d(ctx._h, p, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+    with pytest.raises(np.linalg.LinAlgError, match='101-th leading minor'):
+        ctx.chol_factor(0.0)
