@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""
+Benchmark of the sGDML hot path on MI355X (BASELINE.json metric: kernel-matrix build+solve
+wall-clock [s] and predict forces/s at N_train=1000, aspirin-sized = 21 atoms).
+
+One "step" = one pass of the hot path over one synthetic batch, with all inputs resident in HBM
+before the timed region starts:
+    assemble K (63 000 x 63 000 fp64, stays in HBM)  ->  in-place fp64 MFMA Cholesky of -K + lam I
+    ->  two triangular solves (alphas)  ->  batched force/energy prediction of B query geometries.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N=1: plain python)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 every rank trains an independent model of the reference's hyper-parameter grid
+(sgdml/cli.py:806: one task per sigma, no data-path collective) -> "scaling": "weak".
+
+Prints ONE JSON line (rank 0).  `value` = build+solve seconds per model (max over ranks).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TF = 78.6  # MI355X fp64 matrix peak (256 CU x 4 SIMD x 2.4 GHz x 32 flop/clk)
+
+
+def synth_geometries(n_atoms, n_frames, seed=0, jitter=0.3, n_conformers=4, spacing=1.4):
+    """Seeded synthetic frames: conformers of a jittered cubic-grid molecule,
+    labels from the analytic pair potential E = sum 1/d, F = -grad E."""
+    rng = np.random.RandomState(seed)
+    g = int(np.ceil(n_atoms ** (1.0 / 3.0))) + 1
+    grid = np.array([[a, b, c] for a in range(g) for b in range(g) for c in range(g)], float) * spacing
+    base0 = grid[rng.choice(len(grid), n_atoms, replace=False)]
+    bases = np.array([base0] + [base0 + rng.normal(0, 0.25, base0.shape) for _ in range(n_conformers - 1)])
+    R = bases[rng.randint(0, len(bases), n_frames)] + rng.normal(0, jitter, (n_frames, n_atoms, 3))
+    i, j = np.tril_indices(n_atoms, -1)
+    diff = R[:, i, :] - R[:, j, :]
+    dist = np.sqrt((diff**2).sum(-1))
+    E = (1.0 / dist).sum(-1)
+    gp = diff / (dist**3)[..., None]
+    F = np.zeros_like(R)
+    for m in range(n_frames):
+        np.add.at(F[m], i, gp[m])
+        np.subtract.at(F[m], j, gp[m])
+    return R, E, F
+
+
+def cpu_baseline(n_atoms, sample_M, sig, lam, full_M):
+    """Times the oracle (NumPy port of the reference's algorithm) on a bounded sample on the host
+    and extrapolates assembly ~ M^2 and Cholesky ~ M^3 to the benchmark size."""
+    from oracle import gdml_oracle as orc
+
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    R, E, F = synth_geometries(n_atoms, sample_M + 64, seed=0)
+    Rf = R.reshape(len(R), -1)
+    tp = orc.tril_perms_from_atom_perms(np.arange(n_atoms)[None])
+    lin = orc.tril_perms_lin_from_tril_perms(tp)
+
+    def run():
+        xo, go = orc.desc_from_R(Rf[:sample_M])
+        t0 = time.perf_counter()
+        K = orc.assemble_K(xo, go, lin, sig)
+        t1 = time.perf_counter()
+        y = F[:sample_M].ravel() / np.std(F[:sample_M])
+        alphas, used_lu = orc.analytic_solve(K, y, lam)
+        t2 = time.perf_counter()
+        JA = orc.d_desc_dot_vec(go, alphas.reshape(sample_M, -1))
+        xq, gq = orc.desc_from_R(Rf[sample_M:])
+        orc.predict_from_desc(xq, gq, xo, JA, tp, sig)
+        t3 = time.perf_counter()
+        return t1 - t0, t2 - t1, (t3 - t2), used_lu
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            ta, tc, tpred, used_lu = run()
+    else:
+        ta, tc, tpred, used_lu = run()
+    s = full_M / float(sample_M)
+    est = ta * s**2 + tc * s**3
+    geoms_per_s = 64.0 / tpred / s  # predict cost ~ M per query
+    return {
+        'value': est,
+        'unit': 's',
+        'cores': 1,
+        'kind': 'port',
+        'sample': 'oracle (NumPy port of train.py:97-302 + scipy cho_factor/cho_solve) at M={} on 1 thread: '
+        'assemble {:.2f} s, Cholesky+solve {:.2f} s{}; extrapolated to M={} by M^2 / M^3; '
+        'predict {:.0f} geoms/s extrapolated (~1/M)'.format(
+            sample_M, ta, tc, ' (LU fallback)' if used_lu else '', full_M, geoms_per_s
+        ),
+        'predict_geoms_per_s': geoms_per_s,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--n-atoms', type=int, default=21)
+    ap.add_argument('--n-train', type=int, default=1000)
+    ap.add_argument('--n-query', type=int, default=1000)
+    ap.add_argument('--sig', type=float, default=20.0)
+    ap.add_argument('--lam', type=float, default=1e-10)
+    ap.add_argument('--cpu-sample', type=int, default=100, help='training points of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch  # plumbing only: rendezvous, barrier, max-reduce of the timings
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from sgdml_amd import _lib
+
+    N, M, B = args.n_atoms, args.n_train, args.n_query
+    N3 = 3 * N
+    n = M * N3
+    # every rank = one task of the sigma grid (cli.py:806) on its own seeded data
+    sig = args.sig + 10.0 * rank
+    R, E, F = synth_geometries(N, M + B, seed=rank)
+    Rf = R.reshape(M + B, -1)
+    y = F[:M].ravel().copy()
+    y_std = np.std(y)
+    y /= y_std
+
+    ctx = _lib.Context(local_rank)
+    tp = np.zeros((1, N * (N - 1) // 2), dtype=np.int64)
+    tp[0] = np.arange(tp.shape[1])
+    xd, gd = ctx.desc_from_R(Rf[:M], N)
+    ctx.train_upload(xd, gd, tp)  # resident before timing
+    # query geometries resident in HBM
+    dR, dE, dF = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    lib = ctx._lib
+    ctx._check(lib.gdml_dev_alloc(ctx._h, B * N3 * 8, C.byref(dR)))
+    ctx._check(lib.gdml_dev_alloc(ctx._h, B * 8, C.byref(dE)))
+    ctx._check(lib.gdml_dev_alloc(ctx._h, B * N3 * 8, C.byref(dF)))
+    Rq = np.ascontiguousarray(Rf[M:])
+    ctx._check(lib.gdml_memcpy_h2d(ctx._h, dR, Rq.ctypes.data_as(C.c_void_p), Rq.nbytes))
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    phases = {'assemble': [], 'factor': [], 'solve': [], 'predict': []}
+    info_last = [0]
+
+    def step(record):
+        ctx.assemble_K(sig, False)
+        info_last[0] = ctx.chol_factor(args.lam)
+        alphas = ctx.chol_solve(y)
+        # model for prediction: J alpha on the device (training-set Jacobians are resident)
+        if step.first:
+            ctx.predict_upload_model(xd, np.zeros_like(xd), tp, sig, None)
+            step.first = False
+        ctx.set_alphas(alphas)
+        ctx._check(lib.gdml_predict_dev(ctx._h, dR, B, None, None, dE, dF))
+        if record:
+            for k in phases:
+                phases[k].append(ctx.phase_ms(k)[0])
+        return alphas
+
+    step.first = True
+    for _ in range(args.warmup):
+        step(False)
+    if not args.no_profile:
+        ctx.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        alphas = step(True)
+    barrier()
+    t1 = time.perf_counter()
+    wall_ms = (t1 - t0) * 1e3 / max(1, args.steps)
+
+    build_solve_ms = float(np.mean(phases['assemble']) + np.mean(phases['factor']) + np.mean(phases['solve']))
+    pred_ms = float(np.mean(phases['predict']))
+    vals = np.array([wall_ms, build_solve_ms, pred_ms])
+    if dist is not None:
+        import torch
+
+        t = torch.tensor(vals, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        vals = t.cpu().numpy()
+    wall_ms, build_solve_ms, pred_ms = [float(v) for v in vals]
+
+    out = None
+    if rank == 0:
+        # sanity of the result that was timed: residual of the solve through the matrix-free operator
+        Kv = ctx.kernel_matvec(args.lam, False, -alphas)
+        resid = float(np.linalg.norm(-Kv - y) / np.linalg.norm(y))  # (-K + lam I) x = -(Kx - lam x)
+        roof = None
+        extra = {}
+        if not args.no_profile:
+            g_ms, g_n, g_fl = ctx.kernel_stat('gemm_nt_sub')
+            a_ms, a_n, a_by = ctx.kernel_stat('assemble')
+            p_ms, p_n, p_fl = ctx.kernel_stat('predict')
+            if g_ms > 0:
+                ach = g_fl / (g_ms * 1e-3) / 1e12
+                roof = {'kernel': 'gemm_nt_sub_kernel (fp64 MFMA SYRK/GEMM of the blocked Cholesky)',
+                        'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                        'frac': ach / FP64_MFMA_PEAK_TF, 'traffic': None,
+                        'launches': g_n, 'avg_launch_ms': g_ms / max(1, g_n),
+                        'algorithmic_flops_per_launch': g_fl / max(1, g_n)}
+            if a_ms > 0:
+                ach = a_by / (a_ms * 1e-3) / 1e9
+                extra['roofline_assemble'] = {'kernel': 'assemble_kernel', 'bound': 'hbm', 'achieved': ach,
+                                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                                              'traffic': None, 'avg_launch_ms': a_ms / max(1, a_n)}
+            if p_ms > 0:
+                extra['predict_kernel'] = {'kernel': 'predict_kernel', 'avg_launch_ms': p_ms / max(1, p_n),
+                                           'algorithmic_TFLOPs': p_fl / (p_ms * 1e-3) / 1e12}
+        chol_tf = (n**3 / 3.0) / (np.mean(phases['factor']) * 1e-3) / 1e12
+        out = {
+            'metric': 'kernel-matrix build+solve wall-clock, N_train={} {}-atom (aspirin-sized)'.format(M, N),
+            'value': build_solve_ms / 1e3,
+            'unit': 's',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': wall_ms,
+            'higher_is_better': False,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': 'aspirin-sized N=21 N_train={} analytic Cholesky, 1xMI355X per model '
+                                   '(BASELINE.json configs[1])'.format(M),
+                       'n_atoms': N, 'n_train': M, 'n_perms': 1, 'sig': sig, 'lam': args.lam,
+                       'matrix_n': n, 'query_batch': B, 'parallelism': 'replicas (one sigma-grid task per GPU)'},
+            'phases_ms': {k: float(np.mean(v)) for k, v in phases.items()},
+            'cholesky_info': info_last[0],
+            'solve_rel_residual': resid,
+            'cholesky_TFLOPs_whole_factorization': chol_tf,
+            'predict': {'geoms_per_s': world * B / (pred_ms * 1e-3), 'forces_per_s': world * B * N3 / (pred_ms * 1e-3),
+                        'batch': B, 'ms': pred_ms},
+            'roofline': roof,
+        }
+        out.update(extra)
+        if args.cpu_sample > 0:
+            out['cpu_baseline'] = cpu_baseline(N, args.cpu_sample, args.sig, args.lam, M)
+        else:
+            out['cpu_baseline'] = None
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -69,6 +69,14 @@ int gdml_mem_info(gdml_ctx* ctx, int64_t* held, int64_t* free_b, int64_t* total_
  * Also returns how many kernel launches the phase issued. */
 int gdml_phase_ms(gdml_ctx* ctx, const char* phase, double* ms_out, int64_t* launches_out);
 
+/* Per-kernel timing for roofline reports: after gdml_profile(ctx, 1) every launch of the hot
+ * kernels is bracketed by HIP events on the compute stream; gdml_kernel_stat returns the summed
+ * launch duration, the launch count and the summed ALGORITHMIC work (flops for "gemm_nt_sub",
+ * bytes for "assemble" and "predict") since profiling was enabled.  Off by default. */
+int gdml_profile(gdml_ctx* ctx, int enable);
+int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t* launches_out,
+                     double* work_out);
+
 /* ---- descriptors  (replaces Desc.from_R, sgdml/utils/desc.py:288-365, :208-239) --------
  * R (M,3N) -> R_desc (M,D) = 1/|r_i - r_j|, R_d_desc (M,D,3) = (r_i - r_j)/d^3.
  * lat / lat_inv: 3x3 row-major lattice (columns = vectors) and its inverse, or both NULL;

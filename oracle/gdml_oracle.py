@@ -160,6 +160,7 @@ def _full_K(R_desc, R_d_desc, tril_perms, sig, use_E_cstr):
     sig = float(sig)
 
     J = d_desc_from_comp(R_d_desc)  # (M,D,3N)
+    Jt = np.ascontiguousarray(J.transpose(0, 2, 1))  # (M,3N,D)
     n_rows = M * dim_i + (M if use_E_cstr else 0)
     K = np.zeros((n_rows, n_rows))
     E_off = M * dim_i
@@ -171,10 +172,11 @@ def _full_K(R_desc, R_d_desc, tril_perms, sig, use_E_cstr):
         nrm = SQRT5 * np.sqrt(np.sum(d * d, axis=-1))  # (M,P)
         e = np.exp(-nrm / sig)
         b = 5.0 * e / (3.0 * sig**4)
-        u = np.einsum('mpd,pdc->mpc', d, Jj_p)  # (M,P,3N)
-        A = np.einsum('mpd,mpc->mdc', 5.0 * b[..., None] * d, u)
-        A -= np.einsum('mp,pdc->mdc', (sig**2 + sig * nrm) * b, Jj_p)
-        blk = np.einsum('mdr,mdc->mrc', J, A)  # (M,3N,3N)
+        # (all contractions as batched matmul so that BLAS does the work, like the reference's np.dot)
+        u = np.matmul(d.transpose(1, 0, 2), Jj_p).transpose(1, 0, 2)  # (M,P,3N): d_p^T J_j^p
+        A = np.matmul((5.0 * b[..., None] * d).transpose(0, 2, 1), u)  # (M,D,3N)
+        A -= np.tensordot((sig**2 + sig * nrm) * b, Jj_p, axes=([1], [0]))
+        blk = np.matmul(Jt, A)  # (M,3N,3N) = J_i^T A
         K[:E_off, j * dim_i : (j + 1) * dim_i] = blk.reshape(M * dim_i, dim_i)
 
         if use_E_cstr:

@@ -26,6 +26,8 @@ SIGNATURES = {
     'gdml_sync': (C.c_int, [_vp]),
     'gdml_mem_info': (C.c_int, [_vp, _ip, _ip, _ip]),
     'gdml_phase_ms': (C.c_int, [_vp, C.c_char_p, _dp, _ip]),
+    'gdml_profile': (C.c_int, [_vp, C.c_int]),
+    'gdml_kernel_stat': (C.c_int, [_vp, C.c_char_p, _dp, _ip, _dp]),
     'gdml_desc_from_R': (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
     'gdml_train_upload': (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_int]),
     'gdml_assemble_K': (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64,
@@ -156,6 +158,15 @@ class Context(object):
         ms, n = C.c_double(), C.c_int64()
         self._check(self._lib.gdml_phase_ms(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile(self, enable=True):
+        self._check(self._lib.gdml_profile(self._h, int(bool(enable))))
+
+    def kernel_stat(self, name):
+        """(summed ms, launches, summed algorithmic work) of a hot kernel since profile(True)."""
+        ms, n, w = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self._lib.gdml_kernel_stat(self._h, name.encode(), C.byref(ms), C.byref(n), C.byref(w)))
+        return ms.value, n.value, w.value
 
     def desc_from_R(self, R, n_atoms, lat_and_inv=None):
         R = f64(R).reshape(-1, 3 * n_atoms)

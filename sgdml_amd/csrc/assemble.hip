@@ -316,6 +316,7 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   while (i_chunk > 1 && n_j * ((A.M + i_chunk - 1) / i_chunk) < 4096) i_chunk >>= 1;
   A.i_chunk = i_chunk;
   dim3 grid((unsigned)n_j, (unsigned)((A.M + i_chunk - 1) / i_chunk));
+  const int slot = ktime_begin(ctx);
   switch (AC) {
 #define CASE(v) \
   case v:       \
@@ -324,6 +325,8 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24)
 #undef CASE
   }
+  // algorithmic bytes: every requested element of K written once
+  ktime_end(ctx, slot, "assemble", 8.0 * (double)A.M * 3.0 * N * (double)n_j * 3.0 * N);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;

@@ -172,7 +172,10 @@ static int launch_gemm_nt_sub(gdml_ctx* ctx, const double* A, int64_t lda, const
   g.n_super = lower ? sm * (sm + 1) / 2 : sm * sn;
   int64_t groups = (g.n_super + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
   int64_t blocks = groups * 512;
+  const int slot = ktime_begin(ctx);
   hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g);
+  ktime_end(ctx, slot, "gemm_nt_sub",
+            lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;

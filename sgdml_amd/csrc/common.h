@@ -18,6 +18,19 @@ struct PhaseStat {
   int64_t launches = 0;
 };
 
+// Per-kernel accumulators filled when profiling is enabled (gdml_profile): HIP events are
+// recorded around every launch of the named kernel on the compute stream.
+struct KernelStat {
+  double ms = 0.0;       // sum of launch durations
+  int64_t launches = 0;
+  double work = 0.0;     // algorithmic work (flops or bytes) summed over launches
+};
+struct PendingTiming {
+  std::string name;
+  hipEvent_t e0, e1;
+  double work;
+};
+
 // Device-resident training set (gdml_train_upload).
 struct TrainSet {
   int64_t M = 0;
@@ -53,6 +66,10 @@ struct gdml_ctx {
   std::map<void*, int64_t> allocs;
   std::map<std::string, PhaseStat> phases;
   int64_t launch_counter = 0;
+  bool profiling = false;
+  std::map<std::string, KernelStat> kstats;
+  std::vector<PendingTiming> pending;
+  std::vector<hipEvent_t> event_pool;
 
   TrainSet ts;
   Model model;
@@ -102,6 +119,10 @@ int ctx_alloc(gdml_ctx* ctx, void** p, int64_t bytes);
 int ctx_free(gdml_ctx* ctx, void* p);
 int ctx_scratch(gdml_ctx* ctx, int64_t bytes, double** out);
 void phase_begin(gdml_ctx* ctx);
+// kernel timing (no-ops unless ctx->profiling)
+int ktime_begin(gdml_ctx* ctx);  // returns slot or -1
+void ktime_end(gdml_ctx* ctx, int slot, const char* name, double work);
+int ktime_collect(gdml_ctx* ctx);
 int phase_end(gdml_ctx* ctx, const char* name);
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

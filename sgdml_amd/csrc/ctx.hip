@@ -62,6 +62,11 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   if (!ctx) return GDML_OK;
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
+  for (auto& t : ctx->pending) {
+    hipEventDestroy(t.e0);
+    hipEventDestroy(t.e1);
+  }
+  for (auto e : ctx->event_pool) hipEventDestroy(e);
   for (auto& kv : ctx->allocs) hipFree(kv.first);
   ctx->allocs.clear();
   if (ctx->d_info) hipFree(ctx->d_info);
@@ -163,6 +168,75 @@ int phase_end(gdml_ctx* ctx, const char* name) {
   PhaseStat& s = ctx->phases[name];
   s.ms = ms;
   s.launches = ctx->launch_counter;
+  return GDML_OK;
+}
+
+static hipEvent_t pool_get(gdml_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+int ktime_begin(gdml_ctx* ctx) {
+  if (!ctx->profiling) return -1;
+  PendingTiming t;
+  t.e0 = pool_get(ctx);
+  t.e1 = pool_get(ctx);
+  t.work = 0;
+  (void)hipEventRecord(t.e0, ctx->stream);
+  ctx->pending.push_back(t);
+  return (int)ctx->pending.size() - 1;
+}
+
+void ktime_end(gdml_ctx* ctx, int slot, const char* name, double work) {
+  if (slot < 0) return;
+  PendingTiming& t = ctx->pending[slot];
+  t.name = name;
+  t.work = work;
+  (void)hipEventRecord(t.e1, ctx->stream);
+}
+
+int ktime_collect(gdml_ctx* ctx) {
+  if (ctx->pending.empty()) return GDML_OK;
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& t : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
+      KernelStat& k = ctx->kstats[t.name];
+      k.ms += ms;
+      k.launches += 1;
+      k.work += t.work;
+    }
+    ctx->event_pool.push_back(t.e0);
+    ctx->event_pool.push_back(t.e1);
+  }
+  ctx->pending.clear();
+  return GDML_OK;
+}
+
+extern "C" int gdml_profile(gdml_ctx* ctx, int enable) {
+  if (!ctx) return GDML_ERR_INVALID;
+  GDML_TRY(ktime_collect(ctx));
+  ctx->profiling = enable != 0;
+  ctx->kstats.clear();
+  return GDML_OK;
+}
+
+extern "C" int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out,
+                                int64_t* launches_out, double* work_out) {
+  if (!ctx || !kernel) return GDML_ERR_INVALID;
+  GDML_TRY(ktime_collect(ctx));
+  auto it = ctx->kstats.find(kernel);
+  KernelStat k;
+  if (it != ctx->kstats.end()) k = it->second;
+  if (ms_out) *ms_out = k.ms;
+  if (launches_out) *launches_out = k.launches;
+  if (work_out) *work_out = k.work;
   return GDML_OK;
 }
 

@@ -237,6 +237,7 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   A.xq = d_xq; A.xp = md.xp; A.jap = md.jap; A.aE = md.has_aE ? md.aE : nullptr;
   A.B = B; A.MP = MP; A.D = D; A.sig = md.sig; A.JS = (int)JS; A.rows_per_split = rps;
   A.part_F = part; A.part_E = part + JS * B * (int64_t)D;
+  const int slot = ktime_begin(ctx);
   switch (KPL) {
     case 1: dispatch_qb<1>(ctx, A, QB); break;
     case 2: dispatch_qb<2>(ctx, A, QB); break;
@@ -245,6 +246,8 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
     case 16: dispatch_qb<16>(ctx, A, QB); break;
     default: dispatch_qb<32>(ctx, A, QB); break;
   }
+  // algorithmic work: ~10 D flops per (query, table row)
+  ktime_end(ctx, slot, "predict", 10.0 * (double)D * (double)B * (double)MP);
   ctx->launch_counter++;
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) {
