@@ -50,19 +50,22 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid, int 
   return s;
 }
 
-template <int AC>
-__global__ void __launch_bounds__(768) assemble_kernel(AsmArgs A) {
+// IB row points are processed per iteration so that the barriers and the latency of the
+// cooperative phase are amortised over IB blocks; the next batch's x_i / g_i are prefetched into
+// registers while the current batch is accumulated.
+template <int AC, int IB>
+__global__ void __launch_bounds__(512) assemble_kernel(AsmArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = A.N, D = A.D, P = A.P, N3 = 3 * N;
-  double* xj = smem;           // D
-  double* gj = xj + D;         // 3D  [k][3]
-  double* xi = gj + 3 * D;     // D
-  double* gi = xi + D;         // 3D
-  double* dv = gi + 3 * D;     // D
-  double* u = dv + D;          // 3N
-  double* vv = u + N3;         // 3N
-  double* dg = vv + N3;        // 9N
-  double* red = dg + 9 * N;    // 32
+  double* xj = smem;               // D
+  double* gj = xj + D;             // 3D  [k][3]
+  double* xi = gj + 3 * D;         // IB x D
+  double* gi = xi + IB * D;        // IB x 3D
+  double* dv = gi + IB * 3 * D;    // IB x D
+  double* u = dv + IB * D;         // IB x 3N
+  double* vv = u + IB * N3;        // IB x 3N
+  double* dg = vv + IB * N3;       // IB x 9N
+  double* red = dg + IB * 9 * N;   // IB x 16
 
   const int tid = threadIdx.x, T = blockDim.x, nwaves = T >> 6;
   const int64_t jb = blockIdx.x;
@@ -88,31 +91,84 @@ __global__ void __launch_bounds__(768) assemble_kernel(AsmArgs A) {
   const double base_div = 5.0 / (3.0 * sig * sig * sig * sig);
   const double e_fact = 5.0 / (3.0 * sig * sig * sig);
 
-  for (int64_t i = i_beg; i < i_end; ++i) {
-    __syncthreads();  // previous iteration's readers of xi/gi are done
-    for (int k = tid; k < D; k += T) xi[k] = A.x[i * D + k];
-    for (int k = tid; k < 3 * D; k += T) gi[k] = A.g[i * 3 * D + k];
-
-    double acc[AC][3];
+  // staging of the IB row points: 4 IB D doubles, PF per thread
+  const int stage_n = IB * 4 * D;
+  constexpr int PF = 8;  // register prefetch slots per thread (stage_n <= PF * T is checked on the host)
+  double pf[PF];
+  auto stage_fetch = [&](int64_t i0) {
 #pragma unroll
-    for (int aa = 0; aa < AC; ++aa) acc[aa][0] = acc[aa][1] = acc[aa][2] = 0.0;
-    double erow = 0.0;
+    for (int s = 0; s < PF; ++s) {
+      const int e = tid + s * T;
+      double v = 0.0;
+      if (e < stage_n) {
+        const int ib = e / (4 * D), r = e - ib * 4 * D;
+        int64_t i = i0 + ib;
+        if (i >= i_end) i = i_end - 1;
+        v = (r < D) ? A.x[i * D + r] : A.g[i * 3 * D + (r - D)];
+      }
+      pf[s] = v;
+    }
+  };
+  auto stage_commit = [&]() {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int e = tid + s * T;
+      if (e < stage_n) {
+        const int ib = e / (4 * D), r = e - ib * 4 * D;
+        if (r < D)
+          xi[ib * D + r] = pf[s];
+        else
+          gi[ib * 3 * D + (r - D)] = pf[s];
+      }
+    }
+  };
+
+  stage_fetch(i_beg);
+  for (int64_t i0 = i_beg; i0 < i_end; i0 += IB) {
+    const int nb = (i_end - i0 < IB) ? (int)(i_end - i0) : IB;
+    __syncthreads();  // previous batch's readers of xi/gi are done
+    stage_commit();
+    if (i0 + IB < i_end) stage_fetch(i0 + IB);
+
+    double acc[IB][AC][3];
+    double erow[IB];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+      erow[ib] = 0.0;
+#pragma unroll
+      for (int aa = 0; aa < AC; ++aa) acc[ib][aa][0] = acc[ib][aa][1] = acc[ib][aa][2] = 0.0;
+    }
 
     for (int p = 0; p < P; ++p) {
       const int32_t* tp = A.tp + (size_t)p * D;
       const int32_t* perm = A.perm + (size_t)p * N;
       const int32_t* pinv = A.pinv + (size_t)p * N;
       __syncthreads();  // xi/gi staged; previous perm's phase B done
-      // ---- A1: d_p and its squared norm
-      double part = 0.0;
+      // ---- A1: d_p and squared norms for the IB points
+      double part[IB];
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) part[ib] = 0.0;
       for (int k = tid; k < D; k += T) {
-        double dk = xi[k] - xj[tp[k]];
-        dv[k] = dk;
-        part += dk * dk;
+        const double xjk = xj[tp[k]];
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) {
+          const double dk = xi[ib * D + k] - xjk;
+          dv[ib * D + k] = dk;
+          part[ib] += dk * dk;
+        }
       }
-      const double nrm2 = block_sum(part, red, tid, nwaves);  // contains the barrier after dv[]
-      // ---- A2: u_p (3N), v_p (3N), diagonal blocks (9N)
-      for (int t = tid; t < 15 * N; t += T) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) part[ib] = wave_sum(part[ib]);
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) red[ib * 16 + (tid >> 6)] = part[ib];
+      }
+      __syncthreads();  // dv[] and red[] visible
+      // ---- A2: u_p (3N), v_p (3N), diagonal blocks (9N) for each of the IB points
+      for (int t2 = tid; t2 < IB * 15 * N; t2 += T) {
+        const int ib = t2 / (15 * N), t = t2 - ib * 15 * N;
+        const double* dvb = dv + ib * D;
+        const double* gib = gi + ib * 3 * D;
         if (t < N3) {
           int bb = t / 3, be = t - 3 * bb;
           int ap = pinv[bb];
@@ -121,9 +177,9 @@ __global__ void __launch_bounds__(768) assemble_kernel(AsmArgs A) {
             if (m == ap) continue;
             int q = perm[m];
             double gv = gj[pair_idx(bb, q) * 3 + be];
-            s += dv[pair_idx(ap, m)] * (bb < q ? gv : -gv);
+            s += dvb[pair_idx(ap, m)] * (bb < q ? gv : -gv);
           }
-          u[t] = s;
+          u[ib * N3 + t] = s;
         } else if (t < 2 * N3) {
           int tt = t - N3;
           int a = tt / 3, al = tt - 3 * a;
@@ -131,10 +187,10 @@ __global__ void __launch_bounds__(768) assemble_kernel(AsmArgs A) {
           for (int m = 0; m < N; ++m) {
             if (m == a) continue;
             int k = pair_idx(a, m);
-            double gv = gi[k * 3 + al];
-            s += dv[k] * (a < m ? gv : -gv);
+            double gv = gib[k * 3 + al];
+            s += dvb[k] * (a < m ? gv : -gv);
           }
-          vv[tt] = s;
+          vv[ib * N3 + tt] = s;
         } else {
           int tt = t - 2 * N3;
           int a = tt / 9, r = tt - 9 * a;
@@ -144,63 +200,79 @@ __global__ void __launch_bounds__(768) assemble_kernel(AsmArgs A) {
           for (int m = 0; m < N; ++m) {
             if (m == a) continue;
             int q = perm[m];
-            double g1 = gi[pair_idx(a, m) * 3 + al];
+            double g1 = gib[pair_idx(a, m) * 3 + al];
             double g2 = gj[pair_idx(pa, q) * 3 + be];
             double pr = g1 * g2;
             s += ((a < m) == (pa < q)) ? pr : -pr;
           }
-          dg[tt] = s;
+          dg[ib * 9 * N + tt] = s;
         }
       }
       __syncthreads();
       // ---- B: accumulate this thread's outputs
-      const double nrm = sqrt5 * sqrt(nrm2);
-      const double ex = exp(-nrm * inv_sig);
-      const double bp = ex * base_div;
-      const double cp = (sig * sig + sig * nrm) * bp;
       if (active) {
-        const double uc_raw = u[c];
-        const double uc = 5.0 * bp * uc_raw;
         const int ap = pinv[b];
+        const double gjb = 0.0;
+        (void)gjb;
 #pragma unroll
-        for (int aa = 0; aa < AC; ++aa) {
-          const int a = chunk * AC + aa;
-          if (a < N) {
-            double t0, t1, t2;
-            if (a != ap) {
-              const int k = pair_idx(a, ap);
-              const int q = perm[a];
-              double w = cp * gj[pair_idx(b, q) * 3 + beta];
-              w = ((a < ap) == (b < q)) ? -w : w;
-              t0 = gi[k * 3 + 0] * w;
-              t1 = gi[k * 3 + 1] * w;
-              t2 = gi[k * 3 + 2] * w;
-            } else {
-              t0 = -cp * dg[a * 9 + 0 + beta];
-              t1 = -cp * dg[a * 9 + 3 + beta];
-              t2 = -cp * dg[a * 9 + 6 + beta];
+        for (int ib = 0; ib < IB; ++ib) {
+          double nrm2 = 0.0;
+          for (int w = 0; w < nwaves; ++w) nrm2 += red[ib * 16 + w];
+          const double nrm = sqrt5 * sqrt(nrm2);
+          const double ex = exp(-nrm * inv_sig);
+          const double bp = ex * base_div;
+          const double cp = (sig * sig + sig * nrm) * bp;
+          const double uc_raw = u[ib * N3 + c];
+          const double uc = 5.0 * bp * uc_raw;
+          const double* gib = gi + ib * 3 * D;
+          const double* vb = vv + ib * N3;
+          const double* dgb = dg + ib * 9 * N;
+#pragma unroll
+          for (int aa = 0; aa < AC; ++aa) {
+            const int a = chunk * AC + aa;
+            if (a < N) {
+              double t0, t1, t2;
+              if (a != ap) {
+                const int k = pair_idx(a, ap);
+                const int q = perm[a];
+                double w = cp * gj[pair_idx(b, q) * 3 + beta];
+                w = ((a < ap) == (b < q)) ? -w : w;
+                t0 = gib[k * 3 + 0] * w;
+                t1 = gib[k * 3 + 1] * w;
+                t2 = gib[k * 3 + 2] * w;
+              } else {
+                t0 = -cp * dgb[a * 9 + 0 + beta];
+                t1 = -cp * dgb[a * 9 + 3 + beta];
+                t2 = -cp * dgb[a * 9 + 6 + beta];
+              }
+              acc[ib][aa][0] += vb[3 * a + 0] * uc + t0;
+              acc[ib][aa][1] += vb[3 * a + 1] * uc + t1;
+              acc[ib][aa][2] += vb[3 * a + 2] * uc + t2;
             }
-            acc[aa][0] += vv[3 * a + 0] * uc + t0;
-            acc[aa][1] += vv[3 * a + 1] * uc + t1;
-            acc[aa][2] += vv[3 * a + 2] * uc + t2;
           }
+          if (A.use_E && chunk == 0) erow[ib] -= e_fact * (nrm + sig) * ex * uc_raw;  // train.py:235-248
         }
-        if (A.use_E && chunk == 0) erow -= e_fact * (nrm + sig) * ex * uc_raw;  // train.py:235-248
       }
     }
-    // ---- write the block: row (3N i + 3a + alpha), column outcol
+    // ---- write the blocks: row (3N i + 3a + alpha), column outcol
     if (active && outcol >= 0) {
 #pragma unroll
-      for (int aa = 0; aa < AC; ++aa) {
-        const int a = chunk * AC + aa;
-        if (a < N) {
-          double* dst = A.K + ((int64_t)i * N3 + 3 * a) * A.ld + outcol;
-          dst[0] = acc[aa][0];
-          dst[A.ld] = acc[aa][1];
-          dst[2 * A.ld] = acc[aa][2];
+      for (int ib = 0; ib < IB; ++ib) {
+        if (ib < nb) {
+          const int64_t i = i0 + ib;
+#pragma unroll
+          for (int aa = 0; aa < AC; ++aa) {
+            const int a = chunk * AC + aa;
+            if (a < N) {
+              double* dst = A.K + ((int64_t)i * N3 + 3 * a) * A.ld + outcol;
+              dst[0] = acc[ib][aa][0];
+              dst[A.ld] = acc[ib][aa][1];
+              dst[2 * A.ld] = acc[ib][aa][2];
+            }
+          }
+          if (A.use_E && chunk == 0) A.K[(A.M * N3 + i) * A.ld + outcol] = erow[ib];
         }
       }
-      if (A.use_E && chunk == 0) A.K[(A.M * N3 + i) * A.ld + outcol] = erow;
     }
   }
 }
@@ -285,46 +357,74 @@ __global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
   if (tid == 0) A.K[(A.M * N3 + i) * A.ld + col] = ee;
 }
 
-template <int AC>
+template <int AC, int IB>
 static void launch_asm(gdml_ctx* ctx, const AsmArgs& A, dim3 grid, int T, size_t lds) {
-  hipFuncSetAttribute((const void*)assemble_kernel<AC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipFuncSetAttribute((const void*)assemble_kernel<AC, IB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)lds);
-  hipLaunchKernelGGL(assemble_kernel<AC>, grid, dim3(T), lds, ctx->stream, A);
+  hipLaunchKernelGGL((assemble_kernel<AC, IB>), grid, dim3(T), lds, ctx->stream, A);
+}
+
+static size_t asm_lds_bytes(int N, int D, int IB) {
+  return (size_t)(4 * D + IB * (5 * D + 15 * N) + IB * 16) * 8;
 }
 
 static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   const int N = A.N, D = A.D;
-  static const int acs[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
-  int AC = 24;
+  static const int acs[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+  int AC = 32;
   for (int v : acs) {
     int items = ((N + v - 1) / v) * 3 * N;
-    if (items <= 768) {
+    if (items <= 512) {
       AC = v;
       break;
     }
   }
   int items = ((N + AC - 1) / AC) * 3 * N;
-  if (items > 768)
+  if (items > 512)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assembly kernel supports up to %d atoms", 64);
   int T = ((items + 63) / 64) * 64;
-  size_t lds = (size_t)(9 * D + 15 * N + 32) * 8;
+  // batch of row points per iteration: as large as LDS (<= 64 KiB per workgroup, so that two
+  // workgroups fit a CU), the register prefetch (8 slots/thread) and the accumulators allow
+  int IB = 1;
+  if (AC <= 4) {
+    for (int cand : {4, 2}) {
+      if (asm_lds_bytes(N, D, cand) <= 72 * 1024 && cand * 4 * D <= 8 * T) {
+        IB = cand;
+        break;
+      }
+    }
+  }
+  if (IB * 4 * D > 8 * T) {
+    // prefetch slots exhausted even for IB = 1 (large D, few threads): widen the workgroup
+    T = ((4 * D + 7) / 8 + 63) / 64 * 64;
+    if (T > 512) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assembly kernel supports up to 64 atoms");
+  }
+  size_t lds = asm_lds_bytes(N, D, IB);
   if (lds > 160 * 1024)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED,
                      "assembly kernel needs %zu bytes of LDS for N=%d (limit 160 KiB)", lds, N);
   // choose the i-chunk so that the grid has >= ~8 workgroups per CU
-  int i_chunk = 16;
-  while (i_chunk > 1 && n_j * ((A.M + i_chunk - 1) / i_chunk) < 4096) i_chunk >>= 1;
+  int i_chunk = 32;
+  while (i_chunk > IB && n_j * ((A.M + i_chunk - 1) / i_chunk) < 4096) i_chunk >>= 1;
+  if (i_chunk < IB) i_chunk = IB;
   A.i_chunk = i_chunk;
   dim3 grid((unsigned)n_j, (unsigned)((A.M + i_chunk - 1) / i_chunk));
   const int slot = ktime_begin(ctx);
-  switch (AC) {
-#define CASE(v) \
-  case v:       \
-    launch_asm<v>(ctx, A, grid, T, lds); \
+#define CASE(v)                                             \
+  case v:                                                   \
+    if (IB == 4) launch_asm<v, 4>(ctx, A, grid, T, lds);    \
+    else if (IB == 2) launch_asm<v, 2>(ctx, A, grid, T, lds); \
+    else launch_asm<v, 1>(ctx, A, grid, T, lds);            \
     break;
-    CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24)
-#undef CASE
+#define CASE1(v)                             \
+  case v:                                    \
+    launch_asm<v, 1>(ctx, A, grid, T, lds);  \
+    break;
+  switch (AC) {
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE1(6) CASE1(8) CASE1(12) CASE1(16) CASE1(24) CASE1(32)
   }
+#undef CASE
+#undef CASE1
   // algorithmic bytes: every requested element of K written once
   ktime_end(ctx, slot, "assemble", 8.0 * (double)A.M * 3.0 * N * (double)n_j * 3.0 * N);
   ctx->launch_counter++;
@@ -411,7 +511,7 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
 
   // ---- (re)allocate the device matrix
   const int64_t tot_rows = n_rows + alloc_extra_rows;
-  const int64_t ld = n_cols;
+  const int64_t ld = (n_cols + 15) / 16 * 16;  // rows start on 128-byte boundaries
   if (ctx->K) {
     GDML_TRY(ctx_free(ctx, ctx->K));
     ctx->K = nullptr;

@@ -38,8 +38,10 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int64_t n_super;  // number of 8x8 super tiles enumerated
   int super_n;      // super-tile columns
+  int aligned;      // A, B 16-byte aligned with even leading dimensions (vector loads legal)
 };
 
+template <bool FULL>
 __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int64_t ld,
                                                int64_t row0, int64_t nrows, int64_t k0, int64_t K,
                                                int tid, d2 (&r)[4]) {
@@ -49,15 +51,18 @@ __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int
     int cidx = tid + 256 * s;
     int row = cidx >> 3, kc = (cidx & 7) * 2;
     int64_t gr = row0 + row, gk = k0 + kc;
-    d2 v = {0.0, 0.0};
-    if (gr < nrows) {
-      const double* p = G + gr * ld + gk;
-      if (gk + 1 < K)
-        v = *reinterpret_cast<const d2*>(p);
-      else if (gk < K)
-        v.x = p[0];
+    if (FULL) {
+      r[s] = *reinterpret_cast<const d2*>(G + gr * ld + gk);
+    } else {
+      // branch-free guarded load: clamp the address, then zero what is out of range
+      int64_t cr = gr < nrows ? gr : nrows - 1;
+      int64_t ck0 = gk < K ? gk : K - 1, ck1 = gk + 1 < K ? gk + 1 : K - 1;
+      double v0 = G[cr * ld + ck0], v1 = G[cr * ld + ck1];
+      d2 v;
+      v.x = (gr < nrows && gk < K) ? v0 : 0.0;
+      v.y = (gr < nrows && gk + 1 < K) ? v1 : 0.0;
+      r[s] = v;
     }
-    r[s] = v;
   }
 }
 
@@ -67,6 +72,94 @@ __device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid,
     int cidx = tid + 256 * s;
     int row = cidx >> 3, kc = (cidx & 7) * 2;
     *reinterpret_cast<d2*>(S + row * GPITCH + kc) = r[s];
+  }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[2][GT * GPITCH],
+                                               int64_t row0, int64_t col0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lk = lane >> 4;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t nk = (g.K + GBK - 1) / GBK;
+  d2 ra[4], rb[4];
+  gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, 0, g.K, tid, ra);
+  gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, 0, g.K, tid, rb);
+  gemm_store_tile(lds[0][0], tid, ra);
+  gemm_store_tile(lds[0][1], tid, rb);
+  __syncthreads();
+
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    if (kt + 1 < nk) {
+      gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
+      gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
+    }
+    const double* As = lds[cur][0] + (wm * 64 + li) * GPITCH + lk;
+    const double* Bs = lds[cur][1] + (wn * 64 + li) * GPITCH + lk;
+#pragma unroll
+    for (int ks = 0; ks < GBK; ks += 4) {
+      double a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[i * 16 * GPITCH + ks];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Bs[j * 16 * GPITCH + ks];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      gemm_store_tile(lds[cur ^ 1][0], tid, ra);
+      gemm_store_tile(lds[cur ^ 1][1], tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C -= acc.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r.
+  // All loads of a 64x16 column strip are issued before the first use (no serialised round trips).
+  double* Cw = g.C + (row0 + wm * 64 + lk) * g.ldc + col0 + wn * 64 + li;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double cv[4][4];
+    if (FULL) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[i][r] = Cw[(i * 16 + 4 * r) * g.ldc + j * 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[i][r] - acc[i][j][r];
+    } else {
+      const int64_t gc = col0 + wn * 64 + j * 16 + li;
+      const bool cok = gc < g.N;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
+          const bool ok = cok && gr < g.M;
+          const int64_t cr = gr < g.M ? gr : g.M - 1, cc = cok ? gc : g.N - 1;
+          cv[i][r] = g.C[cr * g.ldc + cc];
+          (void)ok;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
+          if (cok && gr < g.M) g.C[gr * g.ldc + gc] = cv[i][r] - acc[i][j][r];
+        }
+    }
   }
 }
 
@@ -92,70 +185,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   const int64_t ti = SI * 8 + (within >> 3), tj = SJ * 8 + (within & 7);
   if (ti >= g.tiles_m || tj >= g.tiles_n) return;
   if (g.lower && tj > ti) return;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
   const int64_t row0 = ti * GT, col0 = tj * GT;
-  const int li = lane & 15, lk = lane >> 4;
-
-  d4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  const int64_t nk = (g.K + GBK - 1) / GBK;
-  d2 ra[4], rb[4];
-  gemm_load_tile(g.A, g.lda, row0, g.M, 0, g.K, tid, ra);
-  gemm_load_tile(g.B, g.ldb, col0, g.N, 0, g.K, tid, rb);
-  gemm_store_tile(lds[0][0], tid, ra);
-  gemm_store_tile(lds[0][1], tid, rb);
-  __syncthreads();
-
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    if (kt + 1 < nk) {
-      gemm_load_tile(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
-      gemm_load_tile(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
-    }
-    const double* As = lds[cur][0] + (wm * 64 + li) * GPITCH + lk;
-    const double* Bs = lds[cur][1] + (wn * 64 + li) * GPITCH + lk;
-#pragma unroll
-    for (int ks = 0; ks < GBK; ks += 4) {
-      double a[4], bb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[i * 16 * GPITCH + ks];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bb[j] = Bs[j * 16 * GPITCH + ks];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      gemm_store_tile(lds[cur ^ 1][0], tid, ra);
-      gemm_store_tile(lds[cur ^ 1][1], tid, rb);
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue: C -= acc.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t gc = col0 + wn * 64 + j * 16 + li;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
-        if (gr < g.M && gc < g.N) {
-          double* p = g.C + gr * g.ldc + gc;
-          *p -= acc[i][j][r];
-        }
-      }
-    }
-  }
+  const bool full = (row0 + GT <= g.M) && (col0 + GT <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
+  if (full)
+    gemm_tile_body<true>(g, lds, row0, col0);
+  else
+    gemm_tile_body<false>(g, lds, row0, col0);
 }
 
 static int launch_gemm_nt_sub(gdml_ctx* ctx, const double* A, int64_t lda, const double* B,
@@ -165,6 +200,8 @@ static int launch_gemm_nt_sub(gdml_ctx* ctx, const double* A, int64_t lda, const
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.lower = lower;
+  g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
+              (lda % 2 == 0) && (ldb % 2 == 0);
   g.tiles_m = (int)((M + GT - 1) / GT);
   g.tiles_n = (int)((N + GT - 1) / GT);
   int64_t sm = (g.tiles_m + 7) / 8, sn = (g.tiles_n + 7) / 8;
@@ -182,48 +219,45 @@ static int launch_gemm_nt_sub(gdml_ctx* ctx, const double* A, int64_t lda, const
 }
 
 // ------------------------------------------------------------------------------------------
-// potrf on a w x w (w <= 64) diagonal block, in place (lower).  One workgroup of 256 threads.
-// info (device int): set to (global 1-based index of the failing pivot) if a pivot is <= 0 or NaN
-// and info was 0 (LAPACK dpotrf convention).
+// potrf on a w x w (w <= 64) diagonal block, in place (lower).  ONE wavefront: lane r keeps row r of
+// the block in registers (fully unrolled right-looking elimination, no barriers); per step the
+// scaled column is exchanged through a 64-entry LDS vector (broadcast reads).  Entries above the
+// diagonal are scratch.  info (device int): first failing pivot, global 1-based (LAPACK dpotrf).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
-                                                      int64_t global_off, int* __restrict__ info) {
-  __shared__ double L[64 * 65];
-  __shared__ int fail;
-  const int tid = threadIdx.x;
-  if (tid == 0) fail = 0;
-  for (int e = tid; e < w * w; e += 256) {
-    int r = e / w, c = e - r * w;
-    L[r * 65 + c] = (c <= r) ? A[r * ld + c] : 0.0;
+__global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
+                                                     int64_t global_off, int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double T[64 * 65];
+  __shared__ __attribute__((aligned(16))) double col[64];
+  const int lane = threadIdx.x;
+  // coalesced load into LDS, identity padding outside the w x w block
+  for (int r = 0; r < 64; ++r) {
+    double v = (r == lane) ? 1.0 : 0.0;
+    if (r < w && lane < w) v = A[(int64_t)r * ld + lane];
+    T[r * 65 + lane] = v;
   }
-  __syncthreads();
-  for (int j = 0; j < w; ++j) {
-    const double d = L[j * 65 + j];
-    if (!(d > 0.0)) {  // also catches NaN
-      if (tid == 0) {
-        fail = 1;
-        atomicCAS(info, 0, (int)(global_off + j + 1));
-      }
-      break;  // d is uniform across the workgroup
-    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  double row[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) row[c] = T[lane * 65 + c];
+  int fail = 0;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const double d = __shfl(row[j], j, 64);
+    if (!(d > 0.0) && fail == 0) fail = j + 1;
     const double dj = sqrt(d);
-    const double inv = 1.0 / dj;
-    __syncthreads();
-    if (tid == 0) L[j * 65 + j] = dj;
-    for (int r = j + 1 + tid; r < w; r += 256) L[r * 65 + j] *= inv;
-    __syncthreads();
-    const int rem = w - j - 1;
-    for (int e = tid; e < rem * rem; e += 256) {
-      int r = j + 1 + e / rem, c = j + 1 + e % rem;
-      if (c <= r) L[r * 65 + c] -= L[r * 65 + j] * L[c * 65 + j];
-    }
-    __syncthreads();
+    const double lr = row[j] / dj;
+    row[j] = (lane == j) ? dj : lr;
+    col[lane] = lr;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int c = j + 1; c < 64; ++c) row[c] -= lr * col[c];
   }
-  __syncthreads();
-  for (int e = tid; e < w * w; e += 256) {
-    int r = e / w, c = e - r * w;
-    if (c <= r) A[r * ld + c] = L[r * 65 + c];
-  }
+  if (fail != 0 && fail <= w && lane == 0) atomicCAS(info, 0, (int)(global_off + fail));
+#pragma unroll
+  for (int c = 0; c < 64; ++c) T[lane * 65 + c] = row[c];
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  for (int r = 0; r < w; ++r)
+    if (lane <= r && lane < w) A[(int64_t)r * ld + lane] = T[r * 65 + lane];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -300,7 +334,7 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
       const int64_t c0 = k0 + jj;
       const int w = (int)((nb - jj < 64) ? nb - jj : 64);
       double* Ad = A + c0 * ld + c0;
-      hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(256), 0, ctx->stream, Ad, ld, w, c0,
+      hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(64), 0, ctx->stream, Ad, ld, w, c0,
                          ctx->d_info);
       ctx->launch_counter++;
       const int64_t m = n - c0 - w;
@@ -338,29 +372,62 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
 // Backward L^T x = z : per block I (from the bottom) solve L_II^T x_I = z_I, then
 // z[c] -= sum_{r in I} L[r,c] x[r] for the columns c left of the block (one thread per column).
 // ------------------------------------------------------------------------------------------
+// 64x64 triangular solve by ONE wavefront, operands in registers.
+//   TRANS = false: L z = b, lane r holds row r of L;    TRANS = true: L^T x = b, lane c holds column c.
+// Ls: LDS copy of the block ([64][65], identity-padded), b: this lane's right-hand side entry.
+template <bool TRANS>
+__device__ __forceinline__ double tri_solve64_wave(const double* Ls, double b, int lane) {
+  double v[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) v[k] = TRANS ? Ls[k * 65 + lane] : Ls[lane * 65 + k];
+  double sol = 0.0;
+  if (!TRANS) {
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+      const double t = b / v[c];            // meaningful on lane c
+      const double zc = __shfl(t, c, 64);
+      if (lane == c) sol = zc;
+      b -= v[c] * zc;                       // lanes r > c use it; others ignore their b afterwards
+    }
+  } else {
+#pragma unroll
+    for (int r = 63; r >= 0; --r) {
+      const double t = b / v[r];            // lane r: v[r] = L[r][r]
+      const double xr = __shfl(t, r, 64);
+      if (lane == r) sol = xr;
+      b -= v[r] * xr;                       // lane c < r: L[r][c] x_r
+    }
+  }
+  return sol;
+}
+
+__device__ __forceinline__ void load_block64(const double* __restrict__ L, int64_t ld, int64_t c0,
+                                             int w, double* Ls, int tid, int T) {
+  for (int e = tid; e < 64 * 64; e += T) {
+    int r = e >> 6, c = e & 63;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < w && c < w && c <= r) v = L[(c0 + r) * ld + c0 + c];
+    Ls[r * 65 + c] = v;
+  }
+}
+
 __global__ void __launch_bounds__(256) trsv_fwd_kernel(const double* __restrict__ L, int64_t ld,
                                                        int64_t n, int64_t c0, int w,
                                                        double* __restrict__ b,
                                                        double* __restrict__ z_out) {
-  __shared__ double Ls[64 * 65];
+  __shared__ __attribute__((aligned(16))) double Ls[64 * 65];
   __shared__ double z[64];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < w * w; e += 256) {
-    int r = e / w, c = e - r * w;
-    Ls[r * 65 + c] = L[(c0 + r) * ld + c0 + c];
-  }
-  if (tid < w) z[tid] = b[c0 + tid];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  load_block64(L, ld, c0, w, Ls, tid, 256);
   __syncthreads();
-  // column-oriented substitution, 64 lanes of wave 0 (others wait)
-  for (int c = 0; c < w; ++c) {
-    if (tid == c) z[c] = z[c] / Ls[c * 65 + c];
-    __syncthreads();
-    if (tid > c && tid < w) z[tid] -= Ls[tid * 65 + c] * z[c];
-    __syncthreads();
+  if (wave == 0) {
+    const double bi = lane < w ? b[c0 + lane] : 0.0;
+    const double zi = tri_solve64_wave<false>(Ls, bi, lane);
+    z[lane] = zi;
+    if (blockIdx.x == 0 && lane < w) z_out[c0 + lane] = zi;
   }
-  if (blockIdx.x == 0 && tid < w) z_out[c0 + tid] = z[tid];
+  __syncthreads();
   // rows below: one wave per row, lanes over the w columns
-  const int lane = tid & 63, wave = tid >> 6;
   const int64_t first = c0 + w;
   const double zl = lane < w ? z[lane] : 0.0;
   for (int64_t r = first + (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
@@ -373,24 +440,19 @@ __global__ void __launch_bounds__(256) trsv_fwd_kernel(const double* __restrict_
 __global__ void __launch_bounds__(256) trsv_bwd_kernel(const double* __restrict__ L, int64_t ld,
                                                        int64_t c0, int w, double* __restrict__ b,
                                                        double* __restrict__ x_out) {
-  __shared__ double Ls[64 * 65];
+  __shared__ __attribute__((aligned(16))) double Ls[64 * 65];
   __shared__ double x[64];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < w * w; e += 256) {
-    int r = e / w, c = e - r * w;
-    Ls[r * 65 + c] = L[(c0 + r) * ld + c0 + c];
-  }
-  if (tid < w) x[tid] = b[c0 + tid];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  load_block64(L, ld, c0, w, Ls, tid, 256);
   __syncthreads();
-  // L^T x = z : x_c = (z_c - sum_{r>c} L[r][c] x_r) / L[c][c], c descending
-  for (int c = w - 1; c >= 0; --c) {
-    if (tid == c) x[c] = x[c] / Ls[c * 65 + c];
-    __syncthreads();
-    if (tid < c) x[tid] -= Ls[c * 65 + tid] * x[c];
-    __syncthreads();
+  if (wave == 0) {
+    const double bi = lane < w ? b[c0 + lane] : 0.0;
+    const double xi = tri_solve64_wave<true>(Ls, bi, lane);
+    x[lane] = xi;
+    if (blockIdx.x == 0 && lane < w) x_out[c0 + lane] = xi;
   }
-  if (blockIdx.x == 0 && tid < w) x_out[c0 + tid] = x[tid];
-  // columns left of the block
+  __syncthreads();
+  // columns left of the block: z[c] -= sum_{r in block} L[r,c] x[r]   (one thread per column)
   for (int64_t c = (int64_t)blockIdx.x * 256 + tid; c < c0; c += (int64_t)gridDim.x * 256) {
     double s = 0.0;
     for (int r = 0; r < w; ++r) s += L[(c0 + r) * ld + c] * x[r];
