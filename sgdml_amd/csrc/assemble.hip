@@ -35,7 +35,9 @@ struct AsmArgs {
   const int32_t* colmap;  // (n_j, 3N) output column per block column, -1 = skip (null: dense)
   int64_t j0;
   int64_t col0;  // dense mode: output column of point j0
-  int i_chunk;
+  int64_t n_j;   // number of column points
+  int i_chunk;   // column points walked by one workgroup
+  int dbg;  // GDML_ASM_DEBUG ablation bits: 1 skip stores, 2 skip phase A2, 4 skip phase B
   double* K;
   int64_t ld;
 };
@@ -50,28 +52,46 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid, int 
   return s;
 }
 
-// IB row points are processed per iteration so that the barriers and the latency of the
-// cooperative phase are amortised over IB blocks; the next batch's x_i / g_i are prefetched into
-// registers while the current batch is accumulated.
-template <int AC, int IB>
-__global__ void __launch_bounds__(512) assemble_kernel(AsmArgs A) {
+// Layout of the cooperative phase (all in LDS, dense and index-free so that every inner loop is a
+// plain length-N dot product):
+//   GJp[b][m][.] = G_j(b, pi m)          (N x N x 3, zero where m = pi^-1 b)   per (j, p)
+//   Gi [a][m][.] = G_i(a, m)             (N x N x 3, zero diagonal)            per row point
+//   DvF[a][m]    = d_p[pair(a,m)]        (N x N symmetric, zero diagonal)      per (row point, p)
+// with G_x(a,m) = (r_m - r_a)/d^3 = +-g_x[pair(a,m)].  Then
+//   v[a,.]  = sum_m DvF[a][m] Gi[a][m][.]        u[b,.] = sum_m DvF[pi^-1 b][m] GJp[b][m][.]
+//   dg[a]   = sum_m Gi[a][m] (x) GJp[pi a][m]    |d_p|^2 = 1/2 sum DvF^2
+// and an output element is  5 b_p v[a,al] u[b,be] - c_p Gi[a][pi^-1 b][al] GJp[b][a][be]
+// (dg[a] instead of the product when pi a = b).
+//
+// Loop nest: a workgroup keeps IB row points i resident and walks over CONSECUTIVE column points j.
+// Adjacent 3N-wide row segments of K are therefore written by the same CU a few microseconds
+// apart, so the partially covered cache lines at the segment borders merge in that XCD's L2
+// (measured: 2.4 TB/s for isolated 504-byte segments vs 4.2 TB/s back-to-back, 6 TB/s full rows).
+// The (j,p) tables of the next iteration are prefetched into registers during the current one.
+template <int AC, int IB, int MINW>
+__global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int N = A.N, D = A.D, P = A.P, N3 = 3 * N;
-  double* xj = smem;               // D
-  double* gj = xj + D;             // 3D  [k][3]
-  double* xi = gj + 3 * D;         // IB x D
-  double* gi = xi + IB * D;        // IB x 3D
-  double* dv = gi + IB * 3 * D;    // IB x D
-  double* u = dv + IB * D;         // IB x 3N
-  double* vv = u + IB * N3;        // IB x 3N
-  double* dg = vv + IB * N3;       // IB x 9N
-  double* red = dg + IB * 9 * N;   // IB x 16
+  const int N = A.N, D = A.D, P = A.P, N3 = 3 * N, NN = N * N;
+  double* xjp = smem;               // D
+  double* GJp = xjp + D;            // 3 NN
+  double* xi = GJp + 3 * NN;        // IB x D
+  double* Gi = xi + IB * D;         // IB x 3 NN
+  double* DvF = Gi + IB * 3 * NN;   // IB x NN
+  double* u = DvF + IB * NN;        // IB x 3N
+  double* vv = u + IB * N3;         // IB x 3N
+  double* dg = vv + IB * N3;        // IB x 9N
+  double* red = dg + IB * 9 * N;    // IB x 16
+  int* pidx = reinterpret_cast<int*>(red + IB * 16);  // NN  pair index of (a,m)
+  int* perm_s = pidx + NN;                            // N
+  int* pinv_s = perm_s + N;                           // N
+  int* stab = pinv_s + N;                             // 3 NN: offset k*3+al in g (bit 31: negate), -1: zero
+  int* mtab = stab + 3 * NN;                          // NN: m of the flattened (a,m)
 
   const int tid = threadIdx.x, T = blockDim.x, nwaves = T >> 6;
-  const int64_t jb = blockIdx.x;
-  const int64_t j = A.jlist ? A.jlist[jb] : A.j0 + jb;
-  const int64_t i_beg = (int64_t)blockIdx.y * A.i_chunk;
-  const int64_t i_end = (i_beg + A.i_chunk < A.M) ? i_beg + A.i_chunk : A.M;
+  const int64_t i0 = (int64_t)blockIdx.x * IB;
+  const int nb = (A.M - i0 < IB) ? (int)(A.M - i0) : IB;
+  const int64_t jb_beg = (int64_t)blockIdx.y * A.i_chunk;
+  const int64_t jb_end = (jb_beg + A.i_chunk < A.n_j) ? jb_beg + A.i_chunk : A.n_j;
 
   const int n_chunks = (N + AC - 1) / AC;
   const int item = tid;
@@ -79,11 +99,34 @@ __global__ void __launch_bounds__(512) assemble_kernel(AsmArgs A) {
   const int chunk = active ? item / N3 : 0;
   const int c = active ? item - chunk * N3 : 0;
   const int b = c / 3, beta = c - 3 * b;
-  int64_t outcol = -1;
-  if (active) outcol = A.colmap ? (int64_t)A.colmap[jb * N3 + c] : A.col0 + jb * N3 + c;
 
-  for (int k = tid; k < D; k += T) xj[k] = A.x[j * D + k];
-  for (int k = tid; k < 3 * D; k += T) gj[k] = A.g[j * 3 * D + k];
+  for (int e = tid; e < NN; e += T) {
+    const int a = e / N, m = e - a * N;
+    pidx[e] = (a == m) ? 0 : pair_idx(a, m);
+    mtab[e] = m;
+  }
+  for (int q = tid; q < 3 * NN; q += T) {
+    const int am = q / 3, al = q - 3 * am;
+    const int a = am / N, m = am - a * N;
+    int v = -1;
+    if (a != m) v = (pair_idx(a, m) * 3 + al) | ((a < m) ? 0 : (int)0x80000000u);
+    stab[q] = v;
+  }
+  __syncthreads();
+  // resident row points: x_i and the dense G_i
+  for (int ib = 0; ib < IB; ++ib) {
+    const int64_t i = (ib < nb) ? i0 + ib : i0 + nb - 1;
+    for (int k = tid; k < D; k += T) xi[ib * D + k] = A.x[i * D + k];
+    for (int q = tid; q < 3 * NN; q += T) {
+      const int t = stab[q];
+      double v = 0.0;
+      if (t != -1) {
+        v = A.g[i * 3 * D + (t & 0x7fffffff)];
+        if (t < 0) v = -v;
+      }
+      Gi[ib * 3 * NN + q] = v;
+    }
+  }
 
   const double sig = A.sig;
   const double inv_sig = 1.0 / sig;
@@ -91,186 +134,198 @@ __global__ void __launch_bounds__(512) assemble_kernel(AsmArgs A) {
   const double base_div = 5.0 / (3.0 * sig * sig * sig * sig);
   const double e_fact = 5.0 / (3.0 * sig * sig * sig);
 
-  // staging of the IB row points: 4 IB D doubles, PF per thread
-  const int stage_n = IB * 4 * D;
-  constexpr int PF = 8;  // register prefetch slots per thread (stage_n <= PF * T is checked on the host)
-  double pf[PF];
-  auto stage_fetch = [&](int64_t i0) {
-#pragma unroll
-    for (int s = 0; s < PF; ++s) {
-      const int e = tid + s * T;
-      double v = 0.0;
-      if (e < stage_n) {
-        const int ib = e / (4 * D), r = e - ib * 4 * D;
-        int64_t i = i0 + ib;
-        if (i >= i_end) i = i_end - 1;
-        v = (r < D) ? A.x[i * D + r] : A.g[i * 3 * D + (r - D)];
-      }
-      pf[s] = v;
-    }
+  // (j,p) tables, flattened step t = (jb - jb_beg) * P + p: permuted x_j (D) + dense permuted G_j (3 NN)
+  const int per_pt = D + 3 * NN;
+  constexpr int PFI = 4;  // register prefetch slots per thread
+  const bool use_pf = per_pt <= PFI * T;
+  double pf[PFI];
+  int pf_perm = 0;
+  auto jp_value = [&](int r, int64_t j, int p) -> double {
+    if (r < D) return A.x[j * D + A.tp[(size_t)p * D + r]];
+    const int q = r - D;
+    const int bm = q / 3, be = q - 3 * bm;
+    const int m = mtab[bm];
+    const int t = stab[(bm - m + A.perm[(size_t)p * N + m]) * 3 + be];
+    if (t == -1) return 0.0;
+    const double gv = A.g[j * 3 * D + (t & 0x7fffffff)];
+    return (t < 0) ? -gv : gv;
   };
-  auto stage_commit = [&]() {
+  auto jp_store = [&](int r, double v) {
+    if (r < D)
+      xjp[r] = v;
+    else
+      GJp[r - D] = v;
+  };
+  auto jp_fetch = [&](int64_t step) {
+    const int64_t jb = jb_beg + step / P;
+    const int p = (int)(step - (step / P) * P);
+    const int64_t j = A.jlist ? A.jlist[jb] : A.j0 + jb;
 #pragma unroll
-    for (int s = 0; s < PF; ++s) {
-      const int e = tid + s * T;
-      if (e < stage_n) {
-        const int ib = e / (4 * D), r = e - ib * 4 * D;
-        if (r < D)
-          xi[ib * D + r] = pf[s];
-        else
-          gi[ib * 3 * D + (r - D)] = pf[s];
-      }
+    for (int s = 0; s < PFI; ++s) {
+      const int r = tid + s * T;
+      pf[s] = (r < per_pt) ? jp_value(r, j, p) : 0.0;
     }
+    if (tid < N)
+      pf_perm = A.perm[(size_t)p * N + tid];
+    else if (tid < 2 * N)
+      pf_perm = A.pinv[(size_t)p * N + tid - N];
   };
 
-  stage_fetch(i_beg);
-  for (int64_t i0 = i_beg; i0 < i_end; i0 += IB) {
-    const int nb = (i_end - i0 < IB) ? (int)(i_end - i0) : IB;
-    __syncthreads();  // previous batch's readers of xi/gi are done
-    stage_commit();
-    if (i0 + IB < i_end) stage_fetch(i0 + IB);
+  const int64_t n_steps = (jb_end - jb_beg) * P;
+  if (use_pf && n_steps > 0) jp_fetch(0);
 
-    double acc[IB][AC][3];
-    double erow[IB];
+  double acc[IB][AC][3];
+  double erow[IB];
+  for (int64_t step = 0; step < n_steps; ++step) {
+    const int64_t jb = jb_beg + step / P;
+    const int p = (int)(step - (step / P) * P);
+    __syncthreads();  // previous step's readers of the (j,p) tables and DvF/u/v/dg are done
+    if (use_pf) {
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib) {
-      erow[ib] = 0.0;
-#pragma unroll
-      for (int aa = 0; aa < AC; ++aa) acc[ib][aa][0] = acc[ib][aa][1] = acc[ib][aa][2] = 0.0;
-    }
-
-    for (int p = 0; p < P; ++p) {
-      const int32_t* tp = A.tp + (size_t)p * D;
-      const int32_t* perm = A.perm + (size_t)p * N;
-      const int32_t* pinv = A.pinv + (size_t)p * N;
-      __syncthreads();  // xi/gi staged; previous perm's phase B done
-      // ---- A1: d_p and squared norms for the IB points
-      double part[IB];
-#pragma unroll
-      for (int ib = 0; ib < IB; ++ib) part[ib] = 0.0;
-      for (int k = tid; k < D; k += T) {
-        const double xjk = xj[tp[k]];
-#pragma unroll
-        for (int ib = 0; ib < IB; ++ib) {
-          const double dk = xi[ib * D + k] - xjk;
-          dv[ib * D + k] = dk;
-          part[ib] += dk * dk;
-        }
+      for (int s = 0; s < PFI; ++s) {
+        const int r = tid + s * T;
+        if (r < per_pt) jp_store(r, pf[s]);
       }
-#pragma unroll
-      for (int ib = 0; ib < IB; ++ib) part[ib] = wave_sum(part[ib]);
-      if ((tid & 63) == 0) {
-#pragma unroll
-        for (int ib = 0; ib < IB; ++ib) red[ib * 16 + (tid >> 6)] = part[ib];
-      }
-      __syncthreads();  // dv[] and red[] visible
-      // ---- A2: u_p (3N), v_p (3N), diagonal blocks (9N) for each of the IB points
-      for (int t2 = tid; t2 < IB * 15 * N; t2 += T) {
-        const int ib = t2 / (15 * N), t = t2 - ib * 15 * N;
-        const double* dvb = dv + ib * D;
-        const double* gib = gi + ib * 3 * D;
-        if (t < N3) {
-          int bb = t / 3, be = t - 3 * bb;
-          int ap = pinv[bb];
-          double s = 0.0;
-          for (int m = 0; m < N; ++m) {
-            if (m == ap) continue;
-            int q = perm[m];
-            double gv = gj[pair_idx(bb, q) * 3 + be];
-            s += dvb[pair_idx(ap, m)] * (bb < q ? gv : -gv);
-          }
-          u[ib * N3 + t] = s;
-        } else if (t < 2 * N3) {
-          int tt = t - N3;
-          int a = tt / 3, al = tt - 3 * a;
-          double s = 0.0;
-          for (int m = 0; m < N; ++m) {
-            if (m == a) continue;
-            int k = pair_idx(a, m);
-            double gv = gib[k * 3 + al];
-            s += dvb[k] * (a < m ? gv : -gv);
-          }
-          vv[ib * N3 + tt] = s;
-        } else {
-          int tt = t - 2 * N3;
-          int a = tt / 9, r = tt - 9 * a;
-          int al = r / 3, be = r - 3 * al;
-          int pa = perm[a];
-          double s = 0.0;
-          for (int m = 0; m < N; ++m) {
-            if (m == a) continue;
-            int q = perm[m];
-            double g1 = gib[pair_idx(a, m) * 3 + al];
-            double g2 = gj[pair_idx(pa, q) * 3 + be];
-            double pr = g1 * g2;
-            s += ((a < m) == (pa < q)) ? pr : -pr;
-          }
-          dg[ib * 9 * N + tt] = s;
-        }
-      }
-      __syncthreads();
-      // ---- B: accumulate this thread's outputs
-      if (active) {
-        const int ap = pinv[b];
-        const double gjb = 0.0;
-        (void)gjb;
-#pragma unroll
-        for (int ib = 0; ib < IB; ++ib) {
-          double nrm2 = 0.0;
-          for (int w = 0; w < nwaves; ++w) nrm2 += red[ib * 16 + w];
-          const double nrm = sqrt5 * sqrt(nrm2);
-          const double ex = exp(-nrm * inv_sig);
-          const double bp = ex * base_div;
-          const double cp = (sig * sig + sig * nrm) * bp;
-          const double uc_raw = u[ib * N3 + c];
-          const double uc = 5.0 * bp * uc_raw;
-          const double* gib = gi + ib * 3 * D;
-          const double* vb = vv + ib * N3;
-          const double* dgb = dg + ib * 9 * N;
-#pragma unroll
-          for (int aa = 0; aa < AC; ++aa) {
-            const int a = chunk * AC + aa;
-            if (a < N) {
-              double t0, t1, t2;
-              if (a != ap) {
-                const int k = pair_idx(a, ap);
-                const int q = perm[a];
-                double w = cp * gj[pair_idx(b, q) * 3 + beta];
-                w = ((a < ap) == (b < q)) ? -w : w;
-                t0 = gib[k * 3 + 0] * w;
-                t1 = gib[k * 3 + 1] * w;
-                t2 = gib[k * 3 + 2] * w;
-              } else {
-                t0 = -cp * dgb[a * 9 + 0 + beta];
-                t1 = -cp * dgb[a * 9 + 3 + beta];
-                t2 = -cp * dgb[a * 9 + 6 + beta];
-              }
-              acc[ib][aa][0] += vb[3 * a + 0] * uc + t0;
-              acc[ib][aa][1] += vb[3 * a + 1] * uc + t1;
-              acc[ib][aa][2] += vb[3 * a + 2] * uc + t2;
-            }
-          }
-          if (A.use_E && chunk == 0) erow[ib] -= e_fact * (nrm + sig) * ex * uc_raw;  // train.py:235-248
-        }
+      if (tid < N)
+        perm_s[tid] = pf_perm;
+      else if (tid < 2 * N)
+        pinv_s[tid - N] = pf_perm;
+      if (step + 1 < n_steps) jp_fetch(step + 1);
+    } else {
+      const int64_t j = A.jlist ? A.jlist[jb] : A.j0 + jb;
+      for (int r = tid; r < per_pt; r += T) jp_store(r, jp_value(r, j, p));
+      for (int e = tid; e < N; e += T) {
+        perm_s[e] = A.perm[(size_t)p * N + e];
+        pinv_s[e] = A.pinv[(size_t)p * N + e];
       }
     }
-    // ---- write the blocks: row (3N i + 3a + alpha), column outcol
-    if (active && outcol >= 0) {
+    if (p == 0) {
 #pragma unroll
       for (int ib = 0; ib < IB; ++ib) {
-        if (ib < nb) {
-          const int64_t i = i0 + ib;
+        erow[ib] = 0.0;
 #pragma unroll
-          for (int aa = 0; aa < AC; ++aa) {
-            const int a = chunk * AC + aa;
-            if (a < N) {
-              double* dst = A.K + ((int64_t)i * N3 + 3 * a) * A.ld + outcol;
-              dst[0] = acc[ib][aa][0];
-              dst[A.ld] = acc[ib][aa][1];
-              dst[2 * A.ld] = acc[ib][aa][2];
+        for (int aa = 0; aa < AC; ++aa) acc[ib][aa][0] = acc[ib][aa][1] = acc[ib][aa][2] = 0.0;
+      }
+    }
+    __syncthreads();  // tables visible
+    // ---- A1: dense difference matrices and squared norms for the IB points
+    double part[IB];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) part[ib] = 0.0;
+    for (int e = tid; e < NN; e += T) {
+      const int k = pidx[e];
+      const bool diag = mtab[e] * (N + 1) == e;
+      const double xjk = xjp[k];
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        const double dk = diag ? 0.0 : xi[ib * D + k] - xjk;
+        DvF[ib * NN + e] = dk;
+        part[ib] += dk * dk;
+      }
+    }
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) part[ib] = wave_sum(part[ib]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) red[ib * 16 + (tid >> 6)] = part[ib];
+    }
+    __syncthreads();  // DvF[] and red[] visible
+    // ---- A2: u_p (3N), v_p (3N), diagonal blocks (9N) for each of the IB points
+    for (int t2 = tid; t2 < ((A.dbg & 2) ? 0 : IB * 15 * N); t2 += T) {
+      const int ib = t2 / (15 * N), t = t2 - ib * 15 * N;
+      const double* Dv = DvF + ib * NN;
+      const double* Gib = Gi + ib * 3 * NN;
+      if (t < N3) {  // u[b,be] = sum_m DvF[pinv b][m] GJp[b][m][be]
+        const int bb = t / 3, be = t - 3 * bb;
+        const double* dr = Dv + pinv_s[bb] * N;
+        const double* gr = GJp + bb * N3 + be;
+        double s = 0.0;
+#pragma unroll 7
+        for (int m = 0; m < N; ++m) s += dr[m] * gr[3 * m];
+        u[ib * N3 + t] = s;
+      } else if (t < 2 * N3) {  // v[a,al] = sum_m DvF[a][m] Gi[a][m][al]
+        const int tt = t - N3;
+        const int a = tt / 3, al = tt - 3 * a;
+        const double* dr = Dv + a * N;
+        const double* gr = Gib + a * N3 + al;
+        double s = 0.0;
+#pragma unroll 7
+        for (int m = 0; m < N; ++m) s += dr[m] * gr[3 * m];
+        vv[ib * N3 + tt] = s;
+      } else {  // dg[a][al][be] = sum_m Gi[a][m][al] GJp[perm a][m][be]
+        const int tt = t - 2 * N3;
+        const int a = tt / 9, r = tt - 9 * a;
+        const int al = r / 3, be = r - 3 * al;
+        const double* g1 = Gib + a * N3 + al;
+        const double* g2 = GJp + perm_s[a] * N3 + be;
+        double s = 0.0;
+#pragma unroll 7
+        for (int m = 0; m < N; ++m) s += g1[3 * m] * g2[3 * m];
+        dg[ib * 9 * N + tt] = s;
+      }
+    }
+    __syncthreads();
+    // ---- B: accumulate this thread's outputs
+    if (active && !(A.dbg & 4)) {
+      const int ap = pinv_s[b];
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        double nrm2 = 0.0;
+        for (int w = 0; w < nwaves; ++w) nrm2 += red[ib * 16 + w];
+        const double nrm = sqrt5 * sqrt(0.5 * nrm2);
+        const double ex = exp(-nrm * inv_sig);
+        const double bp = ex * base_div;
+        const double cp = (sig * sig + sig * nrm) * bp;
+        const double uc_raw = u[ib * N3 + c];
+        const double uc = 5.0 * bp * uc_raw;
+        const double* Gib = Gi + ib * 3 * NN;
+        const double* vb = vv + ib * N3;
+        const double* dgb = dg + ib * 9 * N;
+#pragma unroll
+        for (int aa = 0; aa < AC; ++aa) {
+          const int a = chunk * AC + aa;
+          if (a < N) {
+            double t0, t1, t2;
+            if (a != ap) {
+              const double w = -cp * GJp[(b * N + a) * 3 + beta];
+              const double* gia = Gib + (a * N + ap) * 3;
+              t0 = gia[0] * w;
+              t1 = gia[1] * w;
+              t2 = gia[2] * w;
+            } else {
+              t0 = -cp * dgb[a * 9 + 0 + beta];
+              t1 = -cp * dgb[a * 9 + 3 + beta];
+              t2 = -cp * dgb[a * 9 + 6 + beta];
             }
+            acc[ib][aa][0] += vb[3 * a + 0] * uc + t0;
+            acc[ib][aa][1] += vb[3 * a + 1] * uc + t1;
+            acc[ib][aa][2] += vb[3 * a + 2] * uc + t2;
           }
-          if (A.use_E && chunk == 0) A.K[(A.M * N3 + i) * A.ld + outcol] = erow[ib];
+        }
+        if (A.use_E && chunk == 0) erow[ib] -= e_fact * (nrm + sig) * ex * uc_raw;  // train.py:235-248
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- after the last permutation: write the IB blocks (rows 3N i + 3a + alpha, column outcol)
+    if (p == P - 1 && active) {
+      const int64_t outcol = A.colmap ? (int64_t)A.colmap[jb * N3 + c] : A.col0 + jb * N3 + c;
+      if (outcol >= 0 && (!(A.dbg & 1) || acc[0][0][0] == 1.2345e-300)) {
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) {
+          if (ib < nb) {
+            const int64_t i = i0 + ib;
+#pragma unroll
+            for (int aa = 0; aa < AC; ++aa) {
+              const int a = chunk * AC + aa;
+              if (a < N) {
+                double* dst = A.K + ((int64_t)i * N3 + 3 * a) * A.ld + outcol;
+                dst[0] = acc[ib][aa][0];
+                dst[A.ld] = acc[ib][aa][1];
+                dst[2 * A.ld] = acc[ib][aa][2];
+              }
+            }
+            if (A.use_E && chunk == 0) A.K[(A.M * N3 + i) * A.ld + outcol] = erow[ib];
+          }
         }
       }
     }
@@ -357,24 +412,33 @@ __global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
   if (tid == 0) A.K[(A.M * N3 + i) * A.ld + col] = ee;
 }
 
-template <int AC, int IB>
+template <int AC, int IB, int MINW>
 static void launch_asm(gdml_ctx* ctx, const AsmArgs& A, dim3 grid, int T, size_t lds) {
-  hipFuncSetAttribute((const void*)assemble_kernel<AC, IB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)lds);
-  hipLaunchKernelGGL((assemble_kernel<AC, IB>), grid, dim3(T), lds, ctx->stream, A);
+  hipFuncSetAttribute((const void*)assemble_kernel<AC, IB, MINW>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((assemble_kernel<AC, IB, MINW>), grid, dim3(T), lds, ctx->stream, A);
 }
 
 static size_t asm_lds_bytes(int N, int D, int IB) {
-  return (size_t)(4 * D + IB * (5 * D + 15 * N) + IB * 16) * 8;
+  const size_t NN = (size_t)N * N;
+  size_t dbl = D + 3 * NN + (size_t)IB * (D + 3 * NN + NN + 15 * N + 16);
+  size_t ints = NN + 2 * N + 3 * NN + NN;
+  return dbl * 8 + ints * 4 + 16;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
 static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   const int N = A.N, D = A.D;
   static const int acs[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+  const int t_target = env_int("GDML_ASM_T", 256);
   int AC = 32;
   for (int v : acs) {
     int items = ((N + v - 1) / v) * 3 * N;
-    if (items <= 512) {
+    if (items <= t_target) {
       AC = v;
       break;
     }
@@ -383,48 +447,52 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   if (items > 512)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assembly kernel supports up to %d atoms", 64);
   int T = ((items + 63) / 64) * 64;
-  // batch of row points per iteration: as large as LDS (<= 64 KiB per workgroup, so that two
-  // workgroups fit a CU), the register prefetch (8 slots/thread) and the accumulators allow
+  // batch of row points per iteration (GDML_ASM_IB overrides): 4 if it fits in LDS, else 2, else 1
   int IB = 1;
-  if (AC <= 4) {
+  if (AC <= 6) {
+    const int want = env_int("GDML_ASM_IB", 2);
     for (int cand : {4, 2}) {
-      if (asm_lds_bytes(N, D, cand) <= 72 * 1024 && cand * 4 * D <= 8 * T) {
+      if (cand <= want && asm_lds_bytes(N, D, cand) <= 150 * 1024) {
         IB = cand;
         break;
       }
     }
   }
-  if (IB * 4 * D > 8 * T) {
-    // prefetch slots exhausted even for IB = 1 (large D, few threads): widen the workgroup
-    T = ((4 * D + 7) / 8 + 63) / 64 * 64;
-    if (T > 512) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assembly kernel supports up to 64 atoms");
-  }
+  const int minw = env_int("GDML_ASM_MINW", 2);
   size_t lds = asm_lds_bytes(N, D, IB);
   if (lds > 160 * 1024)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED,
                      "assembly kernel needs %zu bytes of LDS for N=%d (limit 160 KiB)", lds, N);
-  // choose the i-chunk so that the grid has >= ~8 workgroups per CU
-  int i_chunk = 32;
-  while (i_chunk > IB && n_j * ((A.M + i_chunk - 1) / i_chunk) < 4096) i_chunk >>= 1;
-  if (i_chunk < IB) i_chunk = IB;
-  A.i_chunk = i_chunk;
-  dim3 grid((unsigned)n_j, (unsigned)((A.M + i_chunk - 1) / i_chunk));
+  // column points per workgroup: long enough to amortise the resident row points, short enough
+  // that the grid has >= ~8 workgroups per CU
+  const int64_t n_ib = (A.M + IB - 1) / IB;
+  int j_chunk = env_int("GDML_ASM_ICHUNK", 64);
+  while (j_chunk > 4 && n_ib * ((n_j + j_chunk - 1) / j_chunk) < 4096) j_chunk >>= 1;
+  A.i_chunk = j_chunk;
+  A.n_j = n_j;
+  dim3 grid((unsigned)n_ib, (unsigned)((n_j + j_chunk - 1) / j_chunk));
   const int slot = ktime_begin(ctx);
-#define CASE(v)                                             \
-  case v:                                                   \
-    if (IB == 4) launch_asm<v, 4>(ctx, A, grid, T, lds);    \
-    else if (IB == 2) launch_asm<v, 2>(ctx, A, grid, T, lds); \
-    else launch_asm<v, 1>(ctx, A, grid, T, lds);            \
+#define LAUNCH(ac, ib)                                                  \
+  do {                                                                  \
+    if (minw >= 4) launch_asm<ac, ib, 4>(ctx, A, grid, T, lds);         \
+    else launch_asm<ac, ib, 2>(ctx, A, grid, T, lds);                   \
+  } while (0)
+#define CASE(v)                          \
+  case v:                                \
+    if (IB == 4) LAUNCH(v, 4);           \
+    else if (IB == 2) LAUNCH(v, 2);      \
+    else LAUNCH(v, 1);                   \
     break;
-#define CASE1(v)                             \
-  case v:                                    \
-    launch_asm<v, 1>(ctx, A, grid, T, lds);  \
+#define CASE1(v)                                 \
+  case v:                                        \
+    launch_asm<v, 1, 2>(ctx, A, grid, T, lds);   \
     break;
   switch (AC) {
-    CASE(1) CASE(2) CASE(3) CASE(4) CASE1(6) CASE1(8) CASE1(12) CASE1(16) CASE1(24) CASE1(32)
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE1(8) CASE1(12) CASE1(16) CASE1(24) CASE1(32)
   }
 #undef CASE
 #undef CASE1
+#undef LAUNCH
   // algorithmic bytes: every requested element of K written once
   ktime_end(ctx, slot, "assemble", 8.0 * (double)A.M * 3.0 * N * (double)n_j * 3.0 * N);
   ctx->launch_counter++;
@@ -549,6 +617,10 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
     A.x = ts.x; A.g = ts.g; A.tp = ts.tp; A.perm = ts.perm; A.pinv = ts.pinv;
     A.M = M; A.N = N; A.D = ts.D; A.P = ts.P; A.sig = sig; A.use_E = use_E_cstr;
     A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.col0 = 0; A.i_chunk = 8;
+    {
+      const char* dbg = getenv("GDML_ASM_DEBUG");
+      A.dbg = dbg ? atoi(dbg) : 0;
+    }
     A.K = ctx->K; A.ld = ld;
     rc = assemble_dispatch(ctx, A, n_j);
   }

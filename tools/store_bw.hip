@@ -1,0 +1,49 @@
+// Write-bandwidth probe for the kernel-matrix store pattern on MI355X (63000^2 fp64).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef double d2 __attribute__((ext_vector_type(2)));
+// mode 0: block (j, iy) plain; mode 1: XCD remap (consecutive j on one XCD); mode 2: WG loops over 8 consecutive j
+__global__ void seg_kernel(double* K, int64_t ld, int N3, int M, int ichunk, int mode, int nj) {
+  int64_t b = blockIdx.x;
+  int64_t j, iy; int jrep = 1;
+  if (mode == 0) { j = b % nj; iy = b / nj; }
+  else if (mode == 1) { int64_t x = b & 7, l = b >> 3; int64_t per = nj / 8; j = x * per + (l % per); iy = l / per; }
+  else { int64_t x = b & 7, l = b >> 3; int64_t groups = nj / 8; int64_t per = groups / 8; j = (x * per + (l % per)) * 8; iy = l / per; jrep = 8; }
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int64_t i0 = iy * ichunk;
+  for (int64_t i = i0; i < i0 + ichunk && i < M; ++i)
+    for (int jj = 0; jj < jrep; ++jj)
+      for (int r = wave; r < N3; r += nw)
+        if (lane < N3) K[(i * N3 + r) * ld + (j + jj) * N3 + lane] = (double)lane;
+}
+// pairs of block columns, 16-byte stores, XCD remap
+__global__ void seg2_kernel(double* K, int64_t ld, int N3, int M, int ichunk, int nj2) {
+  int64_t b = blockIdx.x; int64_t x = b & 7, l = b >> 3; int64_t per = nj2 / 8;
+  int64_t j2 = x * per + (l % per), iy = l / per;
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int64_t i0 = iy * ichunk; d2 v = {1.0, 2.0};
+  for (int64_t i = i0; i < i0 + ichunk && i < M; ++i)
+    for (int r = wave; r < N3; r += nw)
+      if (lane < N3) *reinterpret_cast<d2*>(&K[(i * N3 + r) * ld + j2 * 2 * N3 + 2 * lane]) = v;
+}
+__global__ void row8_kernel(double* K, int64_t ld, int64_t n) {
+  int64_t r = blockIdx.x; double* row = K + r * ld;
+  for (int64_t c = threadIdx.x; c < n; c += blockDim.x) row[c] = 1.0;
+}
+#define T(name, call) do { hipEventRecord(a); call; hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b); printf("%-28s: %.2f ms  %.0f GB/s\n", name, ms, gb / ms * 1e3); } while (0)
+int main() {
+  int N3 = 63, M = 1000; int64_t n = (int64_t)N3 * M, ld = (n + 15) / 16 * 16;
+  double* K; hipMalloc(&K, n * ld * 8);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); float ms;
+  double gb = 8.0 * n * n / 1e9;
+  int ic = 32; int ny = (M + ic - 1) / ic;
+  for (int rep = 0; rep < 2; ++rep) {
+    T("seg plain", (seg_kernel<<<dim3(M * ny), 448>>>(K, ld, N3, M, ic, 0, M)));
+    T("seg xcd-remap", (seg_kernel<<<dim3(M * ny), 448>>>(K, ld, N3, M, ic, 1, M)));
+    T("seg xcd-remap 8j/WG", (seg_kernel<<<dim3(M / 8 * ny), 448>>>(K, ld, N3, M, ic, 2, M)));
+    T("seg pairs 16B xcd-remap", (seg2_kernel<<<dim3(M / 2 * ny), 448>>>(K, ld, N3, M, ic, M / 2)));
+    T("rows 8B", (row8_kernel<<<(unsigned)n, 256>>>(K, ld, n)));
+  }
+  return 0;
+}
