@@ -22,12 +22,13 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // C[M x N] -= A[M x K] * B[N x K]^T     (row-major, leading dimensions lda/ldb/ldc)
 // lower != 0: C is square-symmetric-updated, only tiles with tile_row >= tile_col are computed.
 // Workgroup: 256 threads = 4 waves (2 x 2), tile 128 x 128, each wave 64 x 64 = 4 x 4 MFMA tiles.
-// LDS: [row][BK+2] doubles per operand and stage (pitch 18 => conflict-free ds_read_b64 of the
-// MFMA operand pattern lane -> (row = l&15, k = l>>4), and conflict-free 16-byte row writes).
+// LDS: [row][BK+1] doubles per operand and stage: pitch 17 doubles = 34 dwords makes the MFMA operand
+// pattern lane -> (row = l&15, k = l>>4) conflict-free for ds_read_b64 AND for the ds_read2_b64 the
+// compiler merges them into (16-lane groups, 32 banks: 34 i mod 32 = 2 i), and the 8-byte row writes too.
 // ------------------------------------------------------------------------------------------
 #define GT 128
 #define GBK 16
-#define GPITCH 18
+#define GPITCH 17
 
 struct GemmArgs {
   const double* A;
@@ -39,6 +40,7 @@ struct GemmArgs {
   int64_t n_super;  // number of 8x8 super tiles enumerated
   int super_n;      // super-tile columns
   int aligned;      // A, B 16-byte aligned with even leading dimensions (vector loads legal)
+  int dbg;          // GDML_GEMM_DEBUG ablation bits: 1 no epilogue, 2 no tile loads, 4 no LDS reads, 8 no barrier
 };
 
 template <bool FULL>
@@ -71,7 +73,8 @@ __device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid,
   for (int s = 0; s < 4; ++s) {
     int cidx = tid + 256 * s;
     int row = cidx >> 3, kc = (cidx & 7) * 2;
-    *reinterpret_cast<d2*>(S + row * GPITCH + kc) = r[s];
+    S[row * GPITCH + kc] = r[s].x;
+    S[row * GPITCH + kc + 1] = r[s].y;
   }
 }
 
@@ -98,7 +101,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
-    if (kt + 1 < nk) {
+    if (kt + 1 < nk && !(g.dbg & 2)) {
       gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
       gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
     }
@@ -107,21 +110,32 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
     for (int ks = 0; ks < GBK; ks += 4) {
       double a[4], bb[4];
+      if (g.dbg & 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[i * 16 * GPITCH + ks];
+        for (int i = 0; i < 4; ++i) a[i] = bb[i] = (double)(lane + i + ks);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bb[j] = Bs[j * 16 * GPITCH + ks];
+        for (int i = 0; i < 4; ++i) a[i] = As[i * 16 * GPITCH + ks];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bb[j] = Bs[j * 16 * GPITCH + ks];
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+      if (ks == GBK / 2 - 4 && kt + 1 < nk && !(g.dbg & 2)) {
+        // the next tile's global loads were issued ~32 MFMAs ago: write them to the other LDS
+        // buffer now so that the stores drain under the remaining MFMAs of this tile
+        gemm_store_tile(lds[cur ^ 1][0], tid, ra);
+        gemm_store_tile(lds[cur ^ 1][1], tid, rb);
+      }
     }
-    if (kt + 1 < nk) {
-      gemm_store_tile(lds[cur ^ 1][0], tid, ra);
-      gemm_store_tile(lds[cur ^ 1][1], tid, rb);
-    }
-    __syncthreads();
+    if (!(g.dbg & 8)) __syncthreads();
+  }
+  if (g.dbg & 1) {
+    if (acc[0][0][0] == 1.2345e-300) g.C[0] = 0.0;  // keep the accumulators alive
+    return;
   }
 
   // ---- epilogue: C -= acc.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r.
@@ -193,13 +207,21 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
     gemm_tile_body<false>(g, lds, row0, col0);
 }
 
-static int launch_gemm_nt_sub(gdml_ctx* ctx, const double* A, int64_t lda, const double* B,
-                              int64_t ldb, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                              int lower) {
+static int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
+                              const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
+                              int64_t N, int64_t K, int lower) {
   if (M <= 0 || N <= 0 || K <= 0) return GDML_OK;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.lower = lower;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("GDML_GEMM_DEBUG");
+      dbg = e ? atoi(e) : 0;
+    }
+    g.dbg = dbg;
+  }
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
               (lda % 2 == 0) && (ldb % 2 == 0);
   g.tiles_m = (int)((M + GT - 1) / GT);
@@ -209,8 +231,8 @@ static int launch_gemm_nt_sub(gdml_ctx* ctx, const double* A, int64_t lda, const
   g.n_super = lower ? sm * (sm + 1) / 2 : sm * sn;
   int64_t groups = (g.n_super + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
   int64_t blocks = groups * 512;
-  const int slot = ktime_begin(ctx);
-  hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g);
+  const int slot = (st == ctx->stream) ? ktime_begin(ctx) : -1;
+  hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
   ktime_end(ctx, slot, "gemm_nt_sub",
             lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K);
   ctx->launch_counter++;
@@ -325,37 +347,72 @@ __global__ void __launch_bounds__(256) negate_shift_kernel(double* __restrict__ 
   }
 }
 
-int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out) {
-  HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
-  const int64_t NB = 512;
-  for (int64_t k0 = 0; k0 < n; k0 += NB) {
-    const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
-    for (int64_t jj = 0; jj < nb; jj += 64) {
-      const int64_t c0 = k0 + jj;
-      const int w = (int)((nb - jj < 64) ? nb - jj : 64);
-      double* Ad = A + c0 * ld + c0;
-      hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(64), 0, ctx->stream, Ad, ld, w, c0,
-                         ctx->d_info);
+// Factor one panel: columns [k0, k0+nb), rows [k0, n), 64-wide sub-steps (potrf64 / trsm64 / K=64 gemm).
+static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0,
+                        int64_t nb) {
+  for (int64_t jj = 0; jj < nb; jj += 64) {
+    const int64_t c0 = k0 + jj;
+    const int w = (int)((nb - jj < 64) ? nb - jj : 64);
+    double* Ad = A + c0 * ld + c0;
+    hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(64), 0, st, Ad, ld, w, c0, ctx->d_info);
+    ctx->launch_counter++;
+    const int64_t m = n - c0 - w;
+    if (m > 0) {
+      double* X = A + (c0 + w) * ld + c0;
+      hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ad, X, ld,
+                         w, m);
       ctx->launch_counter++;
-      const int64_t m = n - c0 - w;
-      if (m > 0) {
-        double* X = A + (c0 + w) * ld + c0;
-        hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0,
-                           ctx->stream, Ad, X, ld, w, m);
-        ctx->launch_counter++;
-        const int64_t ncols = k0 + nb - (c0 + w);
-        if (ncols > 0) {
-          // rest of the panel:  C[c0+w:n, c0+w:k0+nb] -= X[c0+w:n, :] X[c0+w:k0+nb, :]^T
-          GDML_TRY(launch_gemm_nt_sub(ctx, X, ld, X, ld, A + (c0 + w) * ld + (c0 + w), ld, m, ncols,
-                                      w, 0));
-        }
+      const int64_t ncols = k0 + nb - (c0 + w);
+      if (ncols > 0) {
+        // rest of the panel:  C[c0+w:n, c0+w:k0+nb] -= X[c0+w:n, :] X[c0+w:k0+nb, :]^T
+        GDML_TRY(launch_gemm_nt_sub(ctx, st, X, ld, X, ld, A + (c0 + w) * ld + (c0 + w), ld, m, ncols,
+                                    w, 0));
       }
     }
+  }
+  return GDML_OK;
+}
+
+// Right-looking blocked Cholesky with one panel of look-ahead: after panel k is factored, the
+// compute stream first updates only the columns of panel k+1, then (a) the panel stream factors
+// panel k+1 (latency-bound 64-wide steps) while (b) the compute stream applies the big SYRK to
+// the rest of the trailing matrix.  The two touch disjoint columns.
+int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out) {
+  HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  static int64_t NB = 0;  // outer panel width (GDML_CHOL_NB overrides; multiple of 64)
+  if (NB == 0) {
+    const char* e = getenv("GDML_CHOL_NB");
+    NB = e ? atoll(e) : 512;
+    if (NB < 64 || NB % 64) NB = 512;
+  }
+  hipStream_t sm = ctx->stream, sp = ctx->stream2;
+  hipEvent_t evA = ctx->ev_la[0], evB = ctx->ev_la[1];
+  const bool lookahead = getenv("GDML_NO_LOOKAHEAD") == nullptr;
+  GDML_TRY(panel_factor(ctx, sm, A, n, ld, 0, n < NB ? n : NB));
+  for (int64_t k0 = 0; k0 < n; k0 += NB) {
+    const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
     const int64_t t0 = k0 + nb;
-    if (t0 < n) {
-      const double* P = A + t0 * ld + k0;
-      GDML_TRY(launch_gemm_nt_sub(ctx, P, ld, P, ld, A + t0 * ld + t0, ld, n - t0, n - t0, nb, 1));
+    if (t0 >= n) break;
+    const int64_t nb2 = (n - t0 < NB) ? n - t0 : NB;
+    const int64_t t1 = t0 + nb2;
+    const double* P = A + t0 * ld + k0;  // rows t0.. of panel k
+    // (1) next panel's columns: C[t0:n, t0:t1] -= P[t0:n] P[t0:t1]^T
+    GDML_TRY(launch_gemm_nt_sub(ctx, sm, P, ld, P, ld, A + t0 * ld + t0, ld, n - t0, nb2, nb, 0));
+    if (lookahead) {
+      HIP_CHECK(ctx, hipEventRecord(evA, sm));
+      HIP_CHECK(ctx, hipStreamWaitEvent(sp, evA, 0));
+      GDML_TRY(panel_factor(ctx, sp, A, n, ld, t0, nb2));
+      HIP_CHECK(ctx, hipEventRecord(evB, sp));
     }
+    // (2) rest of the trailing matrix: C[t1:n, t1:n] -= P[t1:n] P[t1:n]^T  (lower)
+    if (t1 < n) {
+      const double* P1 = A + t1 * ld + k0;
+      GDML_TRY(launch_gemm_nt_sub(ctx, sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, n - t1, n - t1, nb, 1));
+    }
+    if (lookahead)
+      HIP_CHECK(ctx, hipStreamWaitEvent(sm, evB, 0));
+    else
+      GDML_TRY(panel_factor(ctx, sm, A, n, ld, t0, nb2));
   }
   HIP_CHECK(ctx, hipGetLastError());
   int info = 0;

@@ -62,6 +62,7 @@ struct gdml_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_la[2] = {nullptr, nullptr};  // look-ahead hand-off between the two streams
   std::string err;
   int64_t held = 0;
   std::map<void*, int64_t> allocs;
