@@ -1,22 +1,511 @@
-// Nystroem-preconditioned CG on the device (replaces sgdml/solvers/iterative.py) -- see below.
+// Nystroem-preconditioned conjugate gradients on the device.
+//
+// Replaces sgdml/solvers/iterative.py: _nystroem_cholesky_factor (:208-351), _cho_factor_stable
+// (:414-471), the preconditioner operator (:83-142), the kernel operator (:144-206, predict.hip)
+// and scipy.sparse.linalg.cg as called at :740-752.
+//
+// Device layout: the (n+m) x m matrix of gdml_assemble_K(GDML_COLS_INDEX, alloc_extra_rows = m):
+// rows [0,n) = K_nm (un-negated), rows [n,n+m) = work area for the m x m blocks (K_mm, then
+// K_nm^T K_nm + lam I), exactly like the reference's K_nmm (iterative.py:237-253).  After the
+// factorisation rows [0,n) hold X = (L^-1 K_mn)^T, the preconditioner is P v = (X X^T v - v)/lam.
+#include <math.h>
+
 #include "common.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// dst rows n..n+m <- -K[idx[q], :]           (iterative.py:250)
+__global__ void __launch_bounds__(256) gather_neg_rows_kernel(double* __restrict__ K, int64_t ld,
+                                                              const int64_t* __restrict__ idx,
+                                                              int64_t m, int64_t n) {
+  const int64_t q = blockIdx.x;
+  const double* src = K + idx[q] * ld;
+  double* dst = K + (n + q) * ld;
+  for (int64_t c = threadIdx.x; c < m; c += 256) dst[c] = -src[c];
+}
+
+__global__ void __launch_bounds__(256) add_diag_kernel(double* __restrict__ A, int64_t ld, int64_t m,
+                                                       double v) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < m) A[t * ld + t] += v;
+}
+
+// ------------------------------------------------------------------------------------------
+// C[m x m] (lower tiles) = X^T X, X is n x m row-major (K dimension = rows of X).  fp64 MFMA,
+// 128 x 128 tiles, BK = 16, LDS layout [k][128+16] (the operand read lane -> (i = l&15, k = l>>4)
+// touches 16 consecutive doubles per k: conflict-free), global loads are full 1 KiB rows.
+// ------------------------------------------------------------------------------------------
+#define TT 128
+#define TBK 16
+#define TP 144
+
+__device__ __forceinline__ void tn_load(const double* __restrict__ X, int64_t ld, int64_t n, int64_t m,
+                                        int64_t k0, int64_t c0, int tid, d2 (&r)[4]) {
+  // 16 rows x 128 cols = 1024 chunks of 2 doubles: chunk c -> row c/64, col pair c%64
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int cidx = tid + 256 * s;
+    const int kr = cidx >> 6, cc = (cidx & 63) * 2;
+    const int64_t gk = k0 + kr, gc = c0 + cc;
+    d2 v = {0.0, 0.0};
+    if (gk < n) {
+      if (gc < m) v.x = X[gk * ld + gc];
+      if (gc + 1 < m) v.y = X[gk * ld + gc + 1];
+    }
+    r[s] = v;
+  }
+}
+__device__ __forceinline__ void tn_store(double* __restrict__ S, int tid, const d2 (&r)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int cidx = tid + 256 * s;
+    const int kr = cidx >> 6, cc = (cidx & 63) * 2;
+    S[kr * TP + cc] = r[s].x;
+    S[kr * TP + cc + 1] = r[s].y;
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) syrk_tn_kernel(const double* __restrict__ X, int64_t ldx,
+                                                         int64_t n, int64_t m, double* __restrict__ C,
+                                                         int64_t ldc, int tiles) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][TBK * TP];
+  // linear block id -> lower-triangular tile (ti >= tj)
+  const int64_t b = blockIdx.x;
+  int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > b) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+  const int64_t tj = b - ti * (ti + 1) / 2;
+  if (ti >= tiles) return;
+  const int64_t row0 = ti * TT, col0 = tj * TT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lk = lane >> 4;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t nk = (n + TBK - 1) / TBK;
+  d2 ra[4], rb[4];
+  tn_load(X, ldx, n, m, 0, row0, tid, ra);
+  tn_load(X, ldx, n, m, 0, col0, tid, rb);
+  tn_store(lds[0][0], tid, ra);
+  tn_store(lds[0][1], tid, rb);
+  __syncthreads();
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    if (kt + 1 < nk) {
+      tn_load(X, ldx, n, m, (kt + 1) * TBK, row0, tid, ra);
+      tn_load(X, ldx, n, m, (kt + 1) * TBK, col0, tid, rb);
+    }
+    const double* As = lds[cur][0] + lk * TP + wm * 64 + li;
+    const double* Bs = lds[cur][1] + lk * TP + wn * 64 + li;
+#pragma unroll
+    for (int ks = 0; ks < TBK; ks += 4) {
+      double a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[ks * TP + i * 16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Bs[ks * TP + j * 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      tn_store(lds[cur ^ 1][0], tid, ra);
+      tn_store(lds[cur ^ 1][1], tid, rb);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t gc = col0 + wn * 64 + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
+        if (gr < m && gc < m) C[gr * ldc + gc] = acc[i][j][r];
+      }
+    }
+}
+
+// out[r] = sum_c X[r][c]^2   (leverage scores, iterative.py:107-109)
+__global__ void __launch_bounds__(256) row_sqnorm_kernel(const double* __restrict__ X, int64_t ld,
+                                                         int64_t n, int64_t m, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  double s = 0.0;
+  for (int64_t c = lane; c < m; c += 64) {
+    const double v = X[r * ld + c];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[r] = s;
+}
+
+// t_part[rc][c] = sum_{r in chunk rc} X[r][c] v[r]
+__global__ void __launch_bounds__(256) gemv_t_part_kernel(const double* __restrict__ X, int64_t ld,
+                                                          int64_t n, int64_t m,
+                                                          const double* __restrict__ v, int rows_per,
+                                                          double* __restrict__ part) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = (r0 + rows_per < n) ? r0 + rows_per : n;
+  if (c >= m) return;
+  double s = 0.0;
+  for (int64_t r = r0; r < r1; ++r) s += X[r * ld + c] * v[r];
+  part[(int64_t)blockIdx.y * m + c] = s;
+}
+__global__ void __launch_bounds__(256) reduce_parts_kernel(const double* __restrict__ part, int64_t m,
+                                                           int nparts, double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= m) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * m + c];
+  out[c] = s;
+}
+// out[r] = (sum_c X[r][c] t[c] - v[r]) * inv_lam
+__global__ void __launch_bounds__(256) gemv_n_precon_kernel(const double* __restrict__ X, int64_t ld,
+                                                            int64_t n, int64_t m,
+                                                            const double* __restrict__ t,
+                                                            const double* __restrict__ v, double inv_lam,
+                                                            double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  double s = 0.0;
+  for (int64_t c = lane; c < m; c += 64) s += X[r * ld + c] * t[c];
+  s = wave_sum(s);
+  if (lane == 0) out[r] = (s - v[r]) * inv_lam;
+}
+
+// ---- small vector kernels for the PCG loop
+__global__ void __launch_bounds__(256) dot_part_kernel(const double* __restrict__ a,
+                                                       const double* __restrict__ b, int64_t n,
+                                                       double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    s += a[i] * b[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(256) vec_axpy_kernel(double* __restrict__ y, const double* __restrict__ x,
+                                                       double a, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+__global__ void __launch_bounds__(256) vec_xpby_kernel(double* __restrict__ p, const double* __restrict__ z,
+                                                       double beta, int64_t n) {  // p = z + beta p
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = z[i] + beta * p[i];
+}
+__global__ void __launch_bounds__(256) vec_neg_kernel(double* __restrict__ y, const double* __restrict__ x,
+                                                      int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = -x[i];
+}
+
+static int dev_dot(gdml_ctx* ctx, const double* a, const double* b, int64_t n, double* d_part,
+                   double* out) {
+  const int nb = 256;
+  hipLaunchKernelGGL(dot_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, b, n, d_part);
+  double h[256];
+  HIP_CHECK(ctx, hipMemcpyAsync(h, d_part, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  double s = 0.0;
+  for (int i = 0; i < nb; ++i) s += h[i];
+  *out = s;
+  return GDML_OK;
+}
+
+// X[:, 0:m] <- X L^-T  for the n rows of X (L: m x m lower), blocked 512 / 64 like the Cholesky.
+static int tall_trsm(gdml_ctx* ctx, const double* L, double* X, int64_t n, int64_t m, int64_t ld) {
+  const int64_t NB = 512;
+  hipStream_t st = ctx->stream;
+  for (int64_t k0 = 0; k0 < m; k0 += NB) {
+    const int64_t nb = (m - k0 < NB) ? m - k0 : NB;
+    for (int64_t jj = 0; jj < nb; jj += 64) {
+      const int64_t c0 = k0 + jj;
+      const int w = (int)((nb - jj < 64) ? nb - jj : 64);
+      GDML_TRY(launch_trsm64(ctx, st, L + c0 * ld + c0, X + c0, ld, w, n));
+      const int64_t ncols = k0 + nb - (c0 + w);
+      if (ncols > 0)
+        GDML_TRY(launch_gemm_nt_sub(ctx, st, X + c0, ld, L + (c0 + w) * ld + c0, ld, X + c0 + w, ld, n,
+                                    ncols, w, 0));
+    }
+    const int64_t t0 = k0 + nb;
+    if (t0 < m)
+      GDML_TRY(launch_gemm_nt_sub(ctx, st, X + k0, ld, L + t0 * ld + k0, ld, X + t0, ld, n, m - t0, nb, 0));
+  }
+  return GDML_OK;
+}
+
+// Cholesky with escalating diagonal jitter (iterative.py:414-471).  A: m x m (lower referenced).
+// Returns GDML_OK with *ok = 1 on success, *ok = 0 if every attempt failed.
+static int cho_factor_stable_dev(gdml_ctx* ctx, double* A, int64_t m, int64_t ld, double* backup,
+                                 bool pre_reg, int eps_mag_max, int* ok) {
+  const double eps = 2.220446049250313e-16;
+  int eps_mag = (int)floor(log10(eps));  // -16
+  if (pre_reg) {
+    hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, A, ld, m, eps);
+    eps_mag += 1;
+  }
+  *ok = 0;
+  for (int mag = eps_mag; mag <= eps_mag_max; ++mag) {
+    HIP_CHECK(ctx, hipMemcpy2DAsync(backup, m * 8, A, ld * 8, m * 8, m, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+    int info = 0;
+    GDML_TRY(chol_factor_device(ctx, A, m, ld, &info));
+    if (info == 0) {
+      *ok = 1;
+      return GDML_OK;
+    }
+    HIP_CHECK(ctx, hipMemcpy2DAsync(A, ld * 8, backup, m * 8, m * 8, m, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+    hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, A, ld, m,
+                       pow(10.0, (double)mag));
+  }
+  return GDML_OK;
+}
 
 extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* idx, int64_t m,
                                     double* lev_scores_out, double* LinvKmn_host_out, int* info) {
-  if (!ctx) return GDML_ERR_INVALID;
-  return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "gdml_nystroem_factor: not built yet");
+  if (!ctx || !idx || m < 1) return GDML_ERR_INVALID;
+  if (!ctx->K || ctx->K_cols != m || ctx->K_extra < m)
+    return gdml_fail(ctx, GDML_ERR_STATE,
+                     "gdml_nystroem_factor: needs the (n+m) x m matrix of gdml_assemble_K(INDEX, extra=m)");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int64_t n = ctx->K_rows, ld = ctx->K_ld;
+  if (info) *info = 0;
+  double* X = ctx->K;
+  double* S = ctx->K + n * ld;  // m x m work block
+  void* tmp = nullptr;
+  GDML_TRY(ctx_alloc(ctx, &tmp, m * m * 8 + m * 8));
+  double* backup = (double*)tmp;
+  int64_t* d_idx = (int64_t*)(backup + m * m);
+  int rc = GDML_OK;
+  auto body = [&]() -> int {
+    HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    phase_begin(ctx);
+    // K_mm = -K[idx, :]  (psd copy, iterative.py:250)
+    hipLaunchKernelGGL(gather_neg_rows_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, ctx->K, ld,
+                       d_idx, m, n);
+    int ok = 0;
+    GDML_TRY(cho_factor_stable_dev(ctx, S, m, ld, backup, true, 1, &ok));  // iterative.py:263
+    if (!ok)
+      return gdml_fail(ctx, GDML_ERR_NOT_PD,
+                       "Failed to factorize despite strong regularization (max: 10)! You could try a larger sigma.");
+    GDML_TRY(tall_trsm(ctx, S, X, n, m, ld));  // K_nm <- K_nm L_mm^-T  (iterative.py:276-286)
+    // inner = K_nm^T K_nm + lam I  (iterative.py:293-294)
+    const int tiles = (int)((m + TT - 1) / TT);
+    hipLaunchKernelGGL(syrk_tn_kernel, dim3((unsigned)(tiles * (tiles + 1) / 2)), dim3(256), 0,
+                       ctx->stream, X, ld, n, m, S, ld, tiles);
+    hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, S, ld, m, lam);
+    GDML_TRY(cho_factor_stable_dev(ctx, S, m, ld, backup, false, -14, &ok));  // iterative.py:304-306
+    if (!ok) {
+      if (info) *info = 1;
+      return gdml_fail(ctx, GDML_ERR_NOT_PD,
+                       "second Nystroem Cholesky failed (the reference falls back to QR here, "
+                       "iterative.py:313-324: not implemented)");
+    }
+    GDML_TRY(tall_trsm(ctx, S, X, n, m, ld));  // iterative.py:335-345
+    GDML_TRY(phase_end(ctx, "precon"));
+    return GDML_OK;
+  };
+  rc = body();
+  if (rc == GDML_OK) {
+    ctx->precon = X;
+    ctx->precon_m = m;
+    ctx->precon_n = n;
+    if (lev_scores_out) {
+      double* d_lev;
+      rc = ctx_slot(ctx, 2, n * 8, &d_lev);
+      if (rc == GDML_OK) {
+        hipLaunchKernelGGL(row_sqnorm_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, ctx->stream, X, ld, n,
+                           m, d_lev);
+        hipError_t e = hipMemcpyAsync(lev_scores_out, d_lev, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "lev scores: %s", hipGetErrorString(e));
+      }
+    }
+    if (rc == GDML_OK && LinvKmn_host_out) {
+      // host gets L^-1 K_mn (m x n): transpose of X, done on the host side of the copy
+      std::vector<double> h((size_t)n * m);
+      hipError_t e = hipMemcpy2DAsync(h.data(), m * 8, X, ld * 8, m * 8, n, hipMemcpyDeviceToHost,
+                                      ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess)
+        rc = gdml_fail(ctx, GDML_ERR_HIP, "factor copy: %s", hipGetErrorString(e));
+      else
+        for (int64_t r = 0; r < n; ++r)
+          for (int64_t c = 0; c < m; ++c) LinvKmn_host_out[c * n + r] = h[(size_t)r * m + c];
+    }
+  }
+  int rc2 = ctx_free(ctx, tmp);
+  return rc != GDML_OK ? rc : rc2;
 }
+
+// d_out = (X X^T d_v - d_v)/lam  on device vectors
+static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, double* d_out) {
+  if (!ctx->precon) return gdml_fail(ctx, GDML_ERR_STATE, "no preconditioner resident");
+  const int64_t n = ctx->precon_n, m = ctx->precon_m, ld = ctx->K_ld;
+  int rows_per = 2048;
+  int nparts = (int)((n + rows_per - 1) / rows_per);
+  double* buf;
+  GDML_TRY(ctx_slot(ctx, 3, ((int64_t)nparts * m + m) * 8, &buf));
+  double* part = buf;
+  double* t = buf + (int64_t)nparts * m;
+  hipLaunchKernelGGL(gemv_t_part_kernel, dim3(ceil_div(m, 256), nparts), dim3(256), 0, ctx->stream,
+                     ctx->precon, ld, n, m, d_v, rows_per, part);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m,
+                     nparts, t);
+  hipLaunchKernelGGL(gemv_n_precon_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, ctx->stream, ctx->precon,
+                     ld, n, m, t, d_v, 1.0 / lam, d_out);
+  ctx->launch_counter += 3;
+  HIP_CHECK(ctx, hipGetLastError());
+  return GDML_OK;
+}
+
 extern "C" int gdml_precon_apply(gdml_ctx* ctx, double lam, const double* v, int64_t n, double* out) {
-  if (!ctx) return GDML_ERR_INVALID;
-  return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "gdml_precon_apply: not built yet");
+  if (!ctx || !v || !out) return GDML_ERR_INVALID;
+  if (!ctx->precon || n != ctx->precon_n)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_precon_apply: no matching preconditioner resident");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  void* buf = nullptr;
+  GDML_TRY(ctx_alloc(ctx, &buf, 2 * n * 8));
+  double* dv = (double*)buf;
+  double* dout = dv + n;
+  int rc = GDML_OK;
+  hipError_t e = hipMemcpyAsync(dv, v, n * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+  if (rc == GDML_OK) rc = precon_apply_device(ctx, lam, dv, dout);
+  if (rc == GDML_OK) {
+    e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+  }
+  int rc2 = ctx_free(ctx, buf);
+  return rc != GDML_OK ? rc : rc2;
 }
+
+// Preconditioned CG for A x = y, A v = -(K v - lam v)  (iterative.py:740-752; scipy cg:
+// stop when ||r|| < rtol*||y||, atol = 0).  All vectors stay on the device; two scalars per
+// iteration come back to the host.
 extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const double* x0,
                         int64_t n, double rtol, int64_t maxiter, int use_precon, gdml_pcg_cb cb,
                         int64_t cb_every, void* user, double* x_out, int64_t* iters_out,
                         double* resid_out, int* info_out) {
-  if (!ctx) return GDML_ERR_INVALID;
-  return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "gdml_pcg: not built yet");
+  if (!ctx || !y || !x_out) return GDML_ERR_INVALID;
+  if (use_precon && (!ctx->precon || ctx->precon_n != n))
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_pcg: no matching preconditioner resident");
+  if (!ctx->model.xp || !ctx->ts.x)
+    return gdml_fail(ctx, GDML_ERR_STATE,
+                     "gdml_pcg: training set and operator model must be resident "
+                     "(gdml_train_upload + gdml_predict_upload_model)");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  void* buf = nullptr;
+  GDML_TRY(ctx_alloc(ctx, &buf, (6 * n + 256) * 8));
+  double* x = (double*)buf;
+  double* r = x + n;
+  double* z = r + n;
+  double* p = z + n;
+  double* q = p + n;
+  double* b = q + n;
+  double* d_part = b + n;
+  const int grid = ceil_div(n, 256);
+  std::vector<double> hx;
+  int rc = GDML_OK, info = 1;
+  int64_t it = 0;
+  double rn = 0.0;
+  auto body = [&]() -> int {
+    HIP_CHECK(ctx, hipMemcpyAsync(b, y, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    double bb = 0.0;
+    GDML_TRY(dev_dot(ctx, b, b, n, d_part, &bb));
+    const double bnrm = sqrt(bb);
+    if (bnrm == 0.0) {
+      HIP_CHECK(ctx, hipMemsetAsync(x, 0, n * 8, ctx->stream));
+      info = 0;
+      return GDML_OK;
+    }
+    const double atol = rtol * bnrm;
+    if (x0) {
+      HIP_CHECK(ctx, hipMemcpyAsync(x, x0, n * 8, hipMemcpyHostToDevice, ctx->stream));
+      GDML_TRY(matvec_device(ctx, lam, use_E_cstr, x, n, q));  // q = K x - lam x = -A x
+      HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      hipLaunchKernelGGL(vec_axpy_kernel, dim3(grid), dim3(256), 0, ctx->stream, r, q, 1.0, n);  // r = b - A x
+    } else {
+      HIP_CHECK(ctx, hipMemsetAsync(x, 0, n * 8, ctx->stream));
+      HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    double rho_prev = 0.0;
+    for (it = 0; it < maxiter; ++it) {
+      double rr = 0.0;
+      GDML_TRY(dev_dot(ctx, r, r, n, d_part, &rr));
+      rn = sqrt(rr);
+      if (rn < atol) {
+        info = 0;
+        return GDML_OK;
+      }
+      const double* zz = r;
+      if (use_precon) {
+        GDML_TRY(precon_apply_device(ctx, lam, r, z));
+        zz = z;
+      }
+      double rho = 0.0;
+      GDML_TRY(dev_dot(ctx, r, zz, n, d_part, &rho));
+      if (it == 0)
+        HIP_CHECK(ctx, hipMemcpyAsync(p, zz, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      else
+        hipLaunchKernelGGL(vec_xpby_kernel, dim3(grid), dim3(256), 0, ctx->stream, p, zz, rho / rho_prev, n);
+      GDML_TRY(matvec_device(ctx, lam, use_E_cstr, p, n, q));  // q = -(A p)
+      double pq = 0.0;
+      GDML_TRY(dev_dot(ctx, p, q, n, d_part, &pq));
+      const double alpha = rho / (-pq);
+      hipLaunchKernelGGL(vec_axpy_kernel, dim3(grid), dim3(256), 0, ctx->stream, x, p, alpha, n);
+      hipLaunchKernelGGL(vec_axpy_kernel, dim3(grid), dim3(256), 0, ctx->stream, r, q, alpha, n);  // r -= alpha A p
+      rho_prev = rho;
+      if (cb && cb_every > 0 && ((it + 1) % cb_every) == 0) {
+        hx.resize((size_t)n);
+        HIP_CHECK(ctx, hipMemcpyAsync(hx.data(), x, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (cb(it + 1, rn, hx.data(), user) != 0) {
+          info = 2;
+          ++it;
+          return GDML_OK;
+        }
+      }
+    }
+    double rr = 0.0;
+    GDML_TRY(dev_dot(ctx, r, r, n, d_part, &rr));
+    rn = sqrt(rr);
+    info = rn < atol ? 0 : 1;
+    return GDML_OK;
+  };
+  phase_begin(ctx);
+  rc = body();
+  if (rc == GDML_OK) rc = phase_end(ctx, "pcg");
+  if (rc == GDML_OK) {
+    hipError_t e = hipMemcpyAsync(x_out, x, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+  }
+  if (iters_out) *iters_out = it;
+  if (resid_out) *resid_out = rn;
+  if (info_out) *info_out = info;
+  int rc2 = ctx_free(ctx, buf);
+  return rc != GDML_OK ? rc : rc2;
 }
+
 extern "C" int gdml_comm_unique_id(void* id128_out) { return GDML_ERR_UNSUPPORTED; }
 extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world) {
   if (!ctx) return GDML_ERR_INVALID;

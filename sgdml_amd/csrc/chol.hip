@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
     gemm_tile_body<false>(g, lds, row0, col0);
 }
 
-static int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
+int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
                               const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
                               int64_t N, int64_t K, int lower) {
   if (M <= 0 || N <= 0 || K <= 0) return GDML_OK;
@@ -345,6 +345,15 @@ __global__ void __launch_bounds__(256) negate_shift_kernel(double* __restrict__ 
     if (c == r) v += lam;
     row[c] = v;
   }
+}
+
+int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, int64_t ld, int w,
+                  int64_t m) {
+  if (m <= 0) return GDML_OK;
+  hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ld, X, ld, w, m);
+  ctx->launch_counter++;
+  HIP_CHECK(ctx, hipGetLastError());
+  return GDML_OK;
 }
 
 // Factor one panel: columns [k0, k0+nb), rows [k0, n), 64-wide sub-steps (potrf64 / trsm64 / K=64 gemm).

@@ -157,4 +157,8 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
 int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_b,
                       double* d_z, double* d_x);
 int operator_model_from_trainset(gdml_ctx* ctx, double sig);
+int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B,
+                       int64_t ldb, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int lower);
+int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, int64_t ld, int w,
+                  int64_t m);
 int ctx_slot(gdml_ctx* ctx, int slot, int64_t bytes, double** out);

@@ -1,0 +1,282 @@
+"""
+Iterative solver with the reference's ``Iterative`` interface (sgdml/solvers/iterative.py:60-866):
+Nystroem-preconditioned CG on the matrix-free kernel operator.
+
+Everything numerical runs on the GPU through the C ABI: partial-column kernel assembly, the two
+jitter-stabilised Cholesky factorisations + triangular solves + K_nm^T K_nm of the Nystroem factor
+(gdml_nystroem_factor), the preconditioner mat-vecs, the prediction-based K v and the CG
+recurrence (gdml_pcg).  What stays in Python is the reference's control policy: leverage-score
+sampling of inducing columns, the "effectiveness" bookkeeping and restart with 1.2x more inducing
+points (iterative.py:614-801), and checkpoint callbacks.
+"""
+import collections
+import logging
+import timeit
+from functools import partial
+
+import numpy as np
+
+from .. import DONE, NOT_DONE
+from .. import _lib
+
+CG_STEPS_HIST_LEN = 100  # iterative.py:48-50
+EFF_RESTART_THRESH = 0  # iterative.py:51
+MAX_NUM_RESTARTS = 6  # iterative.py:53
+
+
+class CGRestartException(Exception):
+    pass
+
+
+class Iterative(object):
+    def __init__(self, gdml_train, desc, max_memory, max_processes, use_torch, callback=None):
+        self.log = logging.getLogger(__name__)
+        self.gdml_train = gdml_train
+        self.gdml_predict = None  # the reference keeps a GDMLPredict here; the operator lives in the context
+        self.desc = desc
+        self.callback = callback
+        self._max_memory = max_memory
+        self._max_processes = max_processes
+        self._use_torch = use_torch
+
+    # ------------------------------------------------------------------ building blocks
+
+    def _ctx(self):
+        return self.gdml_train._context()
+
+    def _upload(self, R_desc, R_d_desc, tril_perms_lin):
+        dim_d = R_desc.shape[1]
+        self._tril_perms = _lib.tril_perms_from_lin(tril_perms_lin, dim_d)
+        self._ctx().train_upload(R_desc, R_d_desc, self._tril_perms)
+
+    def _nystroem_cholesky_factor(
+        self, R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr, col_idxs, callback_task_name='',
+        callback=None, want_factor=True,
+    ):
+        """L^-1 K_mn (m x n) for the inducing columns col_idxs (iterative.py:208-351).  The factor stays
+        resident on the GPU as the preconditioner; the host copy is optional."""
+        ctx = self._ctx()
+        self._upload(R_desc, R_d_desc, tril_perms_lin)
+        if isinstance(col_idxs, slice):
+            n = R_desc.shape[0] * self.desc.dim_i + (R_desc.shape[0] if use_E_cstr else 0)
+            col_idxs = np.arange(n)[col_idxs]
+        col_idxs = np.asarray(col_idxs, dtype=np.int64)
+        m = len(col_idxs)
+        if callback is not None:
+            name = ' ({})'.format(callback_task_name) if callback_task_name else ''
+            callback = partial(callback, disp_str='Assembling kernel [m x k]{}'.format(name))
+            callback(0, 100)
+        ctx.assemble_K(sig, use_E_cstr, idx=col_idxs, alloc_extra_rows=m)
+        if callback is not None:
+            callback(DONE)
+        lev, fac, _ = ctx.nystroem_factor(lam, col_idxs, want_factor=want_factor)
+        self._last_lev_scores = lev
+        return fac
+
+    def _init_precon_operator(self, task, R_desc, R_d_desc, tril_perms_lin, inducing_pts_idxs, callback=None):
+        """Builds the device-resident preconditioner; returns (apply, lev_scores) (iterative.py:83-142)."""
+        lam = task['lam']
+        self._nystroem_cholesky_factor(
+            R_desc, R_d_desc, tril_perms_lin, task['sig'], lam, use_E_cstr=task['use_E_cstr'],
+            col_idxs=inducing_pts_idxs, callback=callback, want_factor=False,
+        )
+        ctx = self._ctx()
+        return (lambda v: ctx.precon_apply(lam, v)), self._last_lev_scores
+
+    def _init_kernel_operator(self, task, R_desc, R_d_desc, tril_perms_lin, lam, n, callback=None):
+        """Matrix-free K v - lam v on the training set (iterative.py:144-206)."""
+        ctx = self._ctx()
+        n_train = R_desc.shape[0]
+        use_E_cstr = task['use_E_cstr']
+        self._upload(R_desc, R_d_desc, tril_perms_lin)
+        ctx.predict_upload_model(
+            R_desc, np.zeros_like(R_desc), self._tril_perms, task['sig'], np.zeros(n_train) if use_E_cstr else None
+        )
+        return lambda v: ctx.kernel_matvec(lam, use_E_cstr, v)
+
+    def _lev_scores(self, R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr, n_inducing_pts, callback=None):
+        """Approximate leverage scores from min(k,10)*3N random columns (iterative.py:353-399)."""
+        n_train, dim_d = R_d_desc.shape[:2]
+        dim_i = 3 * int((1 + np.sqrt(8 * dim_d + 1)) / 2)
+        dim_m = dim_i * min(n_inducing_pts, 10)
+        lev_approx_idxs = np.sort(
+            np.random.choice(n_train * dim_i + (n_train if use_E_cstr else 0), dim_m, replace=False)
+        )
+        self._nystroem_cholesky_factor(
+            R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr=use_E_cstr, col_idxs=lev_approx_idxs,
+            callback_task_name='lev. scores', callback=callback, want_factor=False,
+        )
+        return self._last_lev_scores
+
+    def inducing_pts_from_lev_scores(self, lev_scores, N):
+        """Sample N columns with probability proportional to the leverage scores (iterative.py:401-411)."""
+        idxs = np.random.choice(np.arange(lev_scores.size), N, replace=False, p=lev_scores / lev_scores.sum())
+        return np.sort(idxs)
+
+    # ------------------------------------------------------------------ solve
+
+    def solve(self, task, R_desc, R_d_desc, tril_perms_lin, y, y_std, tol=1e-4, save_progr_callback=None):
+        n_train, n_atoms = task['R_train'].shape[:2]
+        dim_i = 3 * n_atoms
+        sig, lam = task['sig'], task['lam']
+        use_E_cstr = task['use_E_cstr']
+        ctx = self._ctx()
+
+        alphas0_F = task['alphas0_F'] if 'alphas0_F' in task else None
+        alphas0_E = task['alphas0_E'] if 'alphas0_E' in task else None
+        num_iters0 = task['solver_iters'] if 'solver_iters' in task else 0
+
+        n = n_train * dim_i + (n_train if use_E_cstr else 0)
+        _, free_b, _ = ctx.mem_info()
+        budget = free_b if self._max_memory is None else min(free_b, int(self._max_memory) * 1024**3)
+        n_inducing_pts = min(n_train, Iterative.max_n_inducing_pts_device(n_train, n_atoms, 0.8 * budget))
+        n_inducing_pts = max(1, n_inducing_pts)
+        n_inducing_pts_init = (
+            len(task['inducing_pts_idxs']) // dim_i if 'inducing_pts_idxs' in task else None
+        )
+
+        if self.callback is not None:
+            self.callback = partial(
+                self.callback,
+                disp_str='Building preconditioner (k={} ind. point{})'.format(
+                    n_inducing_pts, 's' if n_inducing_pts > 1 else ''
+                ),
+            )
+            self.callback(NOT_DONE)
+
+        start = timeit.default_timer()
+        lev_scores = None
+        if n_inducing_pts_init is not None and n_inducing_pts_init == n_inducing_pts:
+            inducing_pts_idxs = task['inducing_pts_idxs']
+        else:
+            lev_scores = self._lev_scores(R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr, n_inducing_pts)
+            inducing_pts_idxs = self.inducing_pts_from_lev_scores(lev_scores, n_inducing_pts * dim_i)
+        _, lev_scores = self._init_precon_operator(task, R_desc, R_d_desc, tril_perms_lin, inducing_pts_idxs)
+        if self.callback is not None:
+            dur_s = timeit.default_timer() - start
+            self.callback(DONE, sec_disp_str='took {:.1f} s'.format(dur_s) if dur_s >= 0.1 else '')
+
+        self._init_kernel_operator(task, R_desc, R_d_desc, tril_perms_lin, lam, n)
+
+        alpha_t = None
+        if alphas0_F is not None:
+            alpha_t = -np.asarray(alphas0_F)
+            if alphas0_E is not None:
+                alpha_t = np.hstack((alpha_t, -np.asarray(alphas0_E)))
+
+        state = {'num_iters': int(num_iters0), 'resid': 0.0, 'start': 0.0, 'avg_tt': 0.0, 'alpha_t': alpha_t}
+        steps_hist = collections.deque(maxlen=CG_STEPS_HIST_LEN)
+        maxiter = 3 * n_atoms * n_train * 10  # iterative.py:747-750
+
+        def _cg_status(it, resid, xk):
+            """Reference policy per iteration (iterative.py:614-735); returns True to stop for a restart."""
+            stop = timeit.default_timer()
+            tt = 0.0 if state['start'] == 0 else (stop - state['start'])
+            state['avg_tt'] += tt
+            state['start'] = timeit.default_timer()
+            old_resid = state['resid']
+            state['resid'] = resid
+            step = 0 if state['num_iters'] == num_iters0 else resid - old_resid
+            steps_hist.append(step)
+            arr = np.array(steps_hist)
+            tot = np.abs(arr).sum()
+            ratio = (-arr.clip(max=0).sum() / tot) if tot > 0 else 1
+            eff = 0 if state['num_iters'] == num_iters0 else (int(100 * ratio) - 50) * 2
+
+            if self.callback is not None and tt > 0.0 and state['num_iters'] % int(np.ceil(1.0 / tt)) == 0:
+                self.callback(
+                    NOT_DONE,
+                    disp_str='Training error (RMSE): forces {:.4f}'.format(resid / np.sqrt(len(y))),
+                    sec_disp_str='{:d} iter @ {:.2f} iter/s [eff: {:d}%], k={:d}'.format(
+                        state['num_iters'], 1.0 / tt, eff, n_inducing_pts
+                    ),
+                )
+            if (
+                save_progr_callback is not None
+                and tt > 0.0
+                and state['num_iters'] % int(np.ceil(2 * 60.0 / tt)) == 0
+                and state['num_iters'] % 10 == 0
+            ):
+                alphas_F, alphas_E = -xk, None
+                if use_E_cstr:
+                    alphas_F, alphas_E = -xk[:-n_train], -xk[-n_train:]
+                unconv_model = self.gdml_train.create_model(
+                    task, 'cg', R_desc, R_d_desc, tril_perms_lin, y_std, alphas_F.copy(), alphas_E=alphas_E
+                )
+                unconv_model.update({
+                    'solver_tol': tol, 'solver_iters': state['num_iters'] + 1, 'solver_resid': resid,
+                    'norm_y_train': np.linalg.norm(y), 'inducing_pts_idxs': inducing_pts_idxs, 'c': 0,
+                })
+                save_progr_callback(unconv_model)
+
+            state['num_iters'] += 1
+            if len(steps_hist) == CG_STEPS_HIST_LEN and eff <= EFF_RESTART_THRESH and n_inducing_pts < n_train:
+                state['alpha_t'] = xk.copy()
+                return True
+            return False
+
+        num_restarts = 0
+        info = 1
+        while True:
+            x, info, _iters, resid = ctx.pcg(
+                lam, use_E_cstr, y, x0=state['alpha_t'], rtol=tol, maxiter=maxiter, use_precon=True,
+                callback=_cg_status, cb_every=1,
+            )
+            if info != 2:  # converged or maxiter
+                state['resid'] = resid
+                alphas = -x
+                break
+            # CGRestartException path (iterative.py:755-801)
+            num_restarts += 1
+            steps_hist.clear()
+            if num_restarts == MAX_NUM_RESTARTS:
+                info = 1
+                alphas = state['alpha_t']
+                break
+            n_inducing_pts = min(int(np.ceil(1.2 * n_inducing_pts)), n_train)
+            inducing_pts_idxs = self.inducing_pts_from_lev_scores(lev_scores, n_inducing_pts * dim_i)
+            _, lev_scores = self._init_precon_operator(task, R_desc, R_d_desc, tril_perms_lin, inducing_pts_idxs)
+            self._init_kernel_operator(task, R_desc, R_d_desc, tril_perms_lin, lam, n)
+
+        is_conv = info == 0
+        num_iters = state['num_iters']
+        if self.callback is not None:
+            self.callback(
+                DONE,
+                disp_str='Training on {:,} points{}'.format(n_train, '' if is_conv else ' (NOT CONVERGED)'),
+                sec_disp_str='{:d} iter @ {} iter/s'.format(
+                    num_iters, '{:.2f}'.format(num_iters / state['avg_tt']) if state['avg_tt'] > 0 else '--'
+                ),
+                done_with_warning=not is_conv,
+            )
+        train_rmse = state['resid'] / np.sqrt(len(y))
+        return alphas, tol, num_iters, state['resid'], train_rmse, inducing_pts_idxs, is_conv
+
+    # ------------------------------------------------------------------ memory models
+
+    @staticmethod
+    def max_n_inducing_pts(n_train, n_atoms, max_memory_bytes):
+        """Host-RAM model of the reference (iterative.py:827-844), kept for API parity."""
+        SQUARE_FACT, LINEAR_FACT = 5, 4
+        to_dof = (3 * n_atoms) ** 2 * 8
+        sq_factor = LINEAR_FACT * n_train * to_dof
+        ny_factor = SQUARE_FACT * to_dof
+        k = (np.sqrt(sq_factor**2 + 4.0 * ny_factor * max_memory_bytes) - sq_factor) / (2 * ny_factor)
+        return min(int(k), n_train)
+
+    @staticmethod
+    def est_memory_requirement(n_train, n_inducing_pts, n_atoms):
+        """Host-RAM model of the reference (iterative.py:846-866)."""
+        SQUARE_FACT, LINEAR_FACT = 5, 4
+        est_bytes = LINEAR_FACT * n_train * n_inducing_pts * (3 * n_atoms) ** 2 * 8
+        est_bytes += SQUARE_FACT * n_inducing_pts * n_inducing_pts * (3 * n_atoms) ** 2 * 8
+        return est_bytes
+
+    @staticmethod
+    def max_n_inducing_pts_device(n_train, n_atoms, budget_bytes):
+        """HBM model of this backend: the (n+m) x m matrix plus one m x m backup, n = 3N M, m = 3N k."""
+        to_dof = (3 * n_atoms) ** 2 * 8
+        lin = n_train * to_dof  # n m 8 = M k (3N)^2 8
+        sq = 2 * to_dof  # 2 m^2 8
+        k = (np.sqrt(lin**2 + 4.0 * sq * budget_bytes) - lin) / (2 * sq)
+        return min(int(k), n_train)

@@ -32,6 +32,7 @@ class GDMLTrain(object):
         self._max_processes = max_processes
         self._use_torch = use_torch  # accepted for API compatibility; the HIP backend always runs
         self._ctx = None
+        self._force_solver = None  # testing hook: 'analytic' or 'cg' overrides the memory-based choice
 
     def __del__(self):
         global _instance_alive
@@ -295,6 +296,8 @@ class GDMLTrain(object):
         budget = self._device_budget_bytes()
         est_analytic = Analytic.est_device_memory(n_train, n_atoms, task['use_E_cstr'])
         use_analytic_solver = est_analytic < 0.95 * budget
+        if self._force_solver is not None:
+            use_analytic_solver = self._force_solver == 'analytic'
         solver_keys = {}
 
         if use_analytic_solver:
