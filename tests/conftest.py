@@ -22,3 +22,14 @@ def golden(request):
     g = dict(np.load(os.path.join(GOLDEN_DIR, request.param + '.npz')))
     g['name'] = request.param
     return g
+
+
+def pytest_runtest_logstart(nodeid, location):
+    """Breadcrumb for post-mortems of hard crashes (GPU memory faults abort the interpreter)."""
+    d = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(d):
+        try:
+            with open(os.path.join(d, 'last_test.txt'), 'w') as f:
+                f.write(nodeid + '\n')
+        except OSError:
+            pass
