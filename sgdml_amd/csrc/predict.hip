@@ -58,6 +58,8 @@ __global__ void __launch_bounds__(256) jdotv_kernel(const double* __restrict__ g
   out[t] = gg[0] * (vj[0] - vi[0]) + gg[1] * (vj[1] - vi[1]) + gg[2] * (vj[2] - vi[2]);
 }
 
+typedef double d2x __attribute__((ext_vector_type(2)));
+
 struct PredArgs {
   const double* xq;   // (B,D) query descriptors
   const double* xp;   // (MP,D)
@@ -153,6 +155,168 @@ __global__ void __launch_bounds__(256) predict_kernel(PredArgs A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Bulk variant (B >= 32, D <= 256): no cross-lane reductions at all.
+// A workgroup owns 32 queries and a split of the table rows, processed in tiles of 32 rows.
+//   phase 1: every thread owns 2 x 2 (query,row) pairs and runs over k with the query / table
+//            tiles staged in LDS as [k][q] / [k][r] (16-byte reads, broadcast across lanes);
+//            |d|^2 and a stay in registers, the Matern scalars are evaluated once per pair and
+//            written to LDS as w1[r][q], b2[r][q];
+//   phase 2: every thread owns one query and every 8th k (x and F_x in registers) and accumulates
+//            F_x[q][k] += w1 (x - X_r[k]) - b2 JA_r[k] over the 32 rows.
+// Per (query,row,k): 6 VALU instructions and < 2 LDS reads.
+// ------------------------------------------------------------------------------------------
+#define PQ 32
+#define PR 32
+#define PKC 32
+#define PPITCH 34
+
+template <int NCH>  // number of 32-wide k chunks, D <= 32 NCH
+__global__ void __launch_bounds__(256, 2) predict_bulk_kernel(PredArgs A) {
+  __shared__ __attribute__((aligned(16))) double xs[PKC * PPITCH];
+  __shared__ __attribute__((aligned(16))) double Xs[PKC * PPITCH];
+  __shared__ __attribute__((aligned(16))) double Js[PKC * PPITCH];
+  __shared__ __attribute__((aligned(16))) double w1s[PR * PPITCH];
+  __shared__ __attribute__((aligned(16))) double b2s[PR * PPITCH];
+  const int tid = threadIdx.x;
+  const int D = A.D;
+  const int64_t q0 = (int64_t)blockIdx.x * PQ;
+  const int split = blockIdx.y;
+  const int64_t r_beg = (int64_t)split * A.rows_per_split;
+  const int64_t r_end = (r_beg + A.rows_per_split < A.MP) ? r_beg + A.rows_per_split : A.MP;
+  const double sig = A.sig, inv_sig = 1.0 / sig;
+  const double sqrt5 = 2.23606797749978969641;
+  const double fact = 5.0 / (3.0 * sig * sig * sig);
+  const double dscale = 5.0 / sig;
+  const double inv_3sig = 1.0 / (3.0 * sig);
+  const bool has_aE = A.aE != nullptr;
+
+  // phase-1 ownership: queries qa, qa+1 ; rows ra, ra+1 of the tile
+  const int qa = (tid & 15) * 2, ra = (tid >> 4) * 2;
+  // phase-2 ownership: query q2, k = 32 c + kg + 8 i
+  const int q2 = tid & 31, kg = tid >> 5;
+  double xr[NCH * 4], Fx[NCH * 4];
+#pragma unroll
+  for (int a = 0; a < NCH * 4; ++a) {
+    const int k = 32 * (a >> 2) + kg + 8 * (a & 3);
+    const int64_t qi = q0 + q2;
+    xr[a] = (qi < A.B && k < D) ? A.xq[qi * D + k] : 0.0;
+    Fx[a] = 0.0;
+  }
+  double E0 = 0.0, E1 = 0.0;  // partial energies of queries qa, qa+1
+
+  // staging helpers: element e in [0,1024): row/query = e >> 5, kk = e & 31
+  auto stage_rows = [&](int64_t r0, int c) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int e = tid + 256 * s;
+      const int rr = e >> 5, kk = e & 31;
+      const int64_t r = r0 + rr;
+      const int k = 32 * c + kk;
+      const bool ok = r < r_end && k < D;
+      Xs[kk * PPITCH + rr] = ok ? A.xp[r * D + k] : 0.0;
+      Js[kk * PPITCH + rr] = ok ? A.jap[r * D + k] : 0.0;
+    }
+  };
+
+  for (int64_t r0 = r_beg; r0 < r_end; r0 += PR) {
+    // ---------------- phase 1
+    double s2[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, sa[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    for (int c = 0; c < NCH; ++c) {
+      __syncthreads();  // previous readers of xs/Xs/Js done
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int e = tid + 256 * s;
+        const int qq = e >> 5, kk = e & 31;
+        const int64_t qi = q0 + qq;
+        const int k = 32 * c + kk;
+        xs[kk * PPITCH + qq] = (qi < A.B && k < D) ? A.xq[qi * D + k] : 0.0;
+      }
+      stage_rows(r0, c);
+      __syncthreads();
+#pragma unroll 8
+      for (int kk = 0; kk < PKC; ++kk) {
+        const d2x xv = *reinterpret_cast<const d2x*>(&xs[kk * PPITCH + qa]);
+        const d2x Xv = *reinterpret_cast<const d2x*>(&Xs[kk * PPITCH + ra]);
+        const d2x Jv = *reinterpret_cast<const d2x*>(&Js[kk * PPITCH + ra]);
+        const double d00 = xv.x - Xv.x, d01 = xv.x - Xv.y, d10 = xv.y - Xv.x, d11 = xv.y - Xv.y;
+        s2[0][0] += d00 * d00; sa[0][0] += d00 * Jv.x;
+        s2[0][1] += d01 * d01; sa[0][1] += d01 * Jv.y;
+        s2[1][0] += d10 * d10; sa[1][0] += d10 * Jv.x;
+        s2[1][1] += d11 * d11; sa[1][1] += d11 * Jv.y;
+      }
+    }
+    // Matern scalars once per pair
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t r = r0 + ra + j;
+        double w1 = 0.0, b2 = 0.0, e = 0.0;
+        if (r < r_end) {
+          const double nrm = sqrt5 * sqrt(s2[i][j]);
+          const double ex = exp(-nrm * inv_sig);
+          const double b = fact * ex;
+          b2 = b * (nrm + sig);
+          w1 = dscale * sa[i][j] * b;
+          e = sa[i][j] * b2;
+          if (has_aE) {
+            const double ae = A.aE[r];
+            w1 += ae * b2;
+            e += ae * (1.0 + (nrm * inv_sig) * (1.0 + nrm * inv_3sig)) * ex;
+          }
+        }
+        w1s[(ra + j) * PPITCH + qa + i] = w1;
+        b2s[(ra + j) * PPITCH + qa + i] = b2;
+        if (i == 0) E0 += e; else E1 += e;
+      }
+    // ---------------- phase 2
+    for (int c = 0; c < NCH; ++c) {
+      __syncthreads();  // w1s/b2s visible (first chunk); previous readers of Xs/Js done
+      if (NCH > 1 || true) stage_rows(r0, c);
+      __syncthreads();
+#pragma unroll 4
+      for (int rr = 0; rr < PR; rr += 2) {
+        const double w1a = w1s[rr * PPITCH + q2], w1b = w1s[(rr + 1) * PPITCH + q2];
+        const double b2a = b2s[rr * PPITCH + q2], b2b = b2s[(rr + 1) * PPITCH + q2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = kg + 8 * i;
+          const d2x Xv = *reinterpret_cast<const d2x*>(&Xs[kk * PPITCH + rr]);
+          const d2x Jv = *reinterpret_cast<const d2x*>(&Js[kk * PPITCH + rr]);
+          const double x = xr[c * 4 + i];
+          double f = Fx[c * 4 + i];
+          f += w1a * (x - Xv.x);
+          f -= b2a * Jv.x;
+          f += w1b * (x - Xv.y);
+          f -= b2b * Jv.y;
+          Fx[c * 4 + i] = f;
+        }
+      }
+    }
+  }
+  // ---- outputs: partial F_x (q2, k) and partial E (reduced over the 16 threads sharing qa)
+  {
+    const int64_t qi = q0 + q2;
+    if (qi < A.B) {
+#pragma unroll
+      for (int a = 0; a < NCH * 4; ++a) {
+        const int k = 32 * (a >> 2) + kg + 8 * (a & 3);
+        if (k < D) A.part_F[((int64_t)split * A.B + qi) * D + k] = Fx[a];
+      }
+    }
+  }
+  __syncthreads();
+  w1s[(tid >> 4) * PPITCH + qa] = E0;
+  w1s[(tid >> 4) * PPITCH + qa + 1] = E1;
+  __syncthreads();
+  if (tid < PQ && q0 + tid < A.B) {
+    double e = 0.0;
+    for (int g = 0; g < 16; ++g) e += w1s[g * PPITCH + tid];
+    A.part_E[(int64_t)split * A.B + q0 + tid] = e;
+  }
+}
+
 // One workgroup per query: sum the split partials in order, then F = J_x^T F_x.
 __global__ void __launch_bounds__(256) predict_epilogue_kernel(const double* __restrict__ part_F,
                                                                const double* __restrict__ part_E,
@@ -218,15 +382,17 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   int KPL = 1;
   while (KPL * 64 < D) KPL <<= 1;
   if (KPL > 32) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "predict kernel supports D <= 2048");
+  const bool bulk = (B >= 256) && (D <= 256) && getenv("GDML_PREDICT_V1") == nullptr;
   int QB = max_qb_for(KPL);
   while (QB > 1 && (B + QB - 1) / QB < 512 && QB > B) QB >>= 1;  // do not waste query slots
   while (QB > 1 && B < QB) QB >>= 1;
-  int64_t n_qt = (B + QB - 1) / QB;
-  int64_t JS = (4096 + n_qt - 1) / n_qt;
-  int64_t max_js = MP / 16 > 1 ? MP / 16 : 1;
+  int64_t n_qt = bulk ? (B + PQ - 1) / PQ : (B + QB - 1) / QB;
+  int64_t JS = ((bulk ? 2048 : 4096) + n_qt - 1) / n_qt;
+  int64_t max_js = bulk ? (MP / 64 > 1 ? MP / 64 : 1) : (MP / 16 > 1 ? MP / 16 : 1);
   if (JS > max_js) JS = max_js;
   if (JS < 1) JS = 1;
   int64_t rps = (MP + JS - 1) / JS;
+  if (bulk) rps = (rps + PR - 1) / PR * PR;
   JS = (MP + rps - 1) / rps;
 
   int64_t need = (JS * B * (int64_t)D + JS * B) * 8;
@@ -238,13 +404,23 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   A.B = B; A.MP = MP; A.D = D; A.sig = md.sig; A.JS = (int)JS; A.rows_per_split = rps;
   A.part_F = part; A.part_E = part + JS * B * (int64_t)D;
   const int slot = ktime_begin(ctx);
-  switch (KPL) {
-    case 1: dispatch_qb<1>(ctx, A, QB); break;
-    case 2: dispatch_qb<2>(ctx, A, QB); break;
-    case 4: dispatch_qb<4>(ctx, A, QB); break;
-    case 8: dispatch_qb<8>(ctx, A, QB); break;
-    case 16: dispatch_qb<16>(ctx, A, QB); break;
-    default: dispatch_qb<32>(ctx, A, QB); break;
+  if (bulk) {
+    dim3 grid((unsigned)n_qt, (unsigned)JS);
+    const int nch = (D + 31) / 32;
+    switch (nch) {
+#define BC(v) case v: hipLaunchKernelGGL(predict_bulk_kernel<v>, grid, dim3(256), 0, ctx->stream, A); break;
+      BC(1) BC(2) BC(3) BC(4) BC(5) BC(6) BC(7) default: hipLaunchKernelGGL(predict_bulk_kernel<8>, grid, dim3(256), 0, ctx->stream, A); break;
+#undef BC
+    }
+  } else {
+    switch (KPL) {
+      case 1: dispatch_qb<1>(ctx, A, QB); break;
+      case 2: dispatch_qb<2>(ctx, A, QB); break;
+      case 4: dispatch_qb<4>(ctx, A, QB); break;
+      case 8: dispatch_qb<8>(ctx, A, QB); break;
+      case 16: dispatch_qb<16>(ctx, A, QB); break;
+      default: dispatch_qb<32>(ctx, A, QB); break;
+    }
   }
   // algorithmic work: ~10 D flops per (query, table row)
   ktime_end(ctx, slot, "predict", 10.0 * (double)D * (double)B * (double)MP);
