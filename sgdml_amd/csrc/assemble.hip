@@ -622,7 +622,10 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
       A.dbg = dbg ? atoi(dbg) : 0;
     }
     A.K = ctx->K; A.ld = ld;
-    rc = assemble_dispatch(ctx, A, n_j);
+    if (assemble_wave_applicable(ctx))
+      rc = assemble_wave_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, ctx->K, ld);
+    else
+      rc = assemble_dispatch(ctx, A, n_j);
   }
   if (rc == GDML_OK && !e_pts.empty()) {
     if (N3 > 512) rc = gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "E-constraint columns need 3N <= 512");

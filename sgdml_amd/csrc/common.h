@@ -41,6 +41,8 @@ struct TrainSet {
   int32_t* tp = nullptr;     // (P,D)    descriptor permutations
   int32_t* perm = nullptr;   // (P,N)    atom permutations  pi_p
   int32_t* pinv = nullptr;   // (P,N)    inverse atom permutations
+  double* XF = nullptr;      // (M,N,N)   dense x[pair(b,m)] table, m-major (assemble_wave.hip)
+  double* GD = nullptr;      // (M,N,N,3) dense G(b,m) table, m-major
   std::vector<int32_t> h_tp, h_perm, h_pinv;
 };
 
@@ -162,3 +164,6 @@ int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t l
 int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, int64_t ld, int w,
                   int64_t m);
 int ctx_slot(gdml_ctx* ctx, int slot, int64_t bytes, double** out);
+bool assemble_wave_applicable(const gdml_ctx* ctx);
+int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist,
+                         const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld);
