@@ -44,9 +44,34 @@ extern "C" int gdml_ctx_create(int device, gdml_ctx** ctx_out) {
     return gdml_fail(nullptr, GDML_ERR_INVALID, "device %d out of range [0,%d)", device, n);
   gdml_ctx* ctx = new gdml_ctx();
   ctx->device = device;
-  if ((e = hipSetDevice(device)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess ||
+  // Two streams: `stream` carries the bulk kernels, `stream2` the latency-bound panel steps of the
+  // look-ahead Cholesky.  stream2 gets the highest priority; optionally (GDML_RESERVE_CUS=n) the
+  // bulk stream is masked off n compute units so that single-wave panel kernels never queue behind
+  // a full grid of GEMM workgroups.
+  auto make_streams = [&]() -> hipError_t {
+    hipError_t err;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char* pr = getenv("GDML_PANEL_PRIO");
+    const bool use_prio = pr == nullptr || atoi(pr) != 0;
+    const char* rs = getenv("GDML_RESERVE_CUS");
+    const int reserve = rs ? atoi(rs) : 0;
+    if (reserve > 0) {
+      hipDeviceProp_t prop;
+      if ((err = hipGetDeviceProperties(&prop, device)) != hipSuccess) return err;
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int c = reserve; c < ncu; ++c) mask[c / 32] |= 1u << (c % 32);
+      if ((err = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mask.size(), mask.data())) != hipSuccess)
+        return err;
+    } else {
+      if ((err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return err;
+    }
+    if (use_prio)
+      return hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi);
+    return hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = make_streams()) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev0)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&ctx->ev_la[0], hipEventDisableTiming)) != hipSuccess ||
