@@ -71,7 +71,7 @@ def load():
             'libgdml_hip.so not found at {} -- build it with `python -c "import __graft_entry__ as g; '
             'g.build()"` or `make -C sgdml_amd/csrc`. There is no CPU fallback.'.format(LIB_PATH)
         )
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # raises AttributeError if the symbol is missing
         fn.restype = res
@@ -148,6 +148,26 @@ class Context(object):
 
     def sync(self):
         self._check(self._lib.gdml_sync(self._h))
+
+    # -- multi-GPU (one process per GPU, RCCL bound inside the library)
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL unique id (call on one rank, ship to the others by any host channel)."""
+        lib = load()
+        buf = C.create_string_buffer(128)
+        rc = lib.gdml_comm_unique_id(buf)
+        if rc != GDML_OK:
+            raise GDMLHipError('gdml_comm_unique_id failed: ' + lib.gdml_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """unique_id=None creates a 'virtual rank' (shard arithmetic, no collectives; tests only)."""
+        self._check(self._lib.gdml_comm_init(self._h, unique_id, int(rank), int(world)))
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        self._check(self._lib.gdml_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     def mem_info(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
@@ -280,8 +300,10 @@ class Context(object):
 
     def nystroem_factor(self, lam, idx, want_factor=False):
         idx = i64(idx)
-        n_rows, _, _ = self.K_shape()
-        lev = np.empty(n_rows)
+        n_rows, _, _ = self.K_shape()  # rows held by this rank
+        n_glob = self.n_train * 3 * self.n_atoms + (0 if n_rows % (3 * self.n_atoms) == 0 else self.n_train)
+        _, world = self.comm_info()
+        lev = np.empty(n_glob if world > 1 else n_rows)
         fac = np.empty((idx.size, n_rows)) if want_factor else None
         info = C.c_int(0)
         self._check(self._lib.gdml_nystroem_factor(self._h, float(lam), _ptr(idx), idx.size, _ptr(lev),

@@ -35,6 +35,7 @@ struct AsmArgs {
   const int32_t* colmap;  // (n_j, 3N) output column per block column, -1 = skip (null: dense)
   int64_t j0;
   int64_t col0;  // dense mode: output column of point j0
+  int64_t i_beg, i_end;  // row points handled by this launch (rows written relative to i_beg)
   int64_t n_j;   // number of column points
   int i_chunk;   // column points walked by one workgroup
   int dbg;  // GDML_ASM_DEBUG ablation bits: 1 skip stores, 2 skip phase A2, 4 skip phase B
@@ -88,8 +89,8 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
   int* mtab = stab + 3 * NN;                          // NN: m of the flattened (a,m)
 
   const int tid = threadIdx.x, T = blockDim.x, nwaves = T >> 6;
-  const int64_t i0 = (int64_t)blockIdx.x * IB;
-  const int nb = (A.M - i0 < IB) ? (int)(A.M - i0) : IB;
+  const int64_t i0 = A.i_beg + (int64_t)blockIdx.x * IB;
+  const int nb = (A.i_end - i0 < IB) ? (int)(A.i_end - i0) : IB;
   const int64_t jb_beg = (int64_t)blockIdx.y * A.i_chunk;
   const int64_t jb_end = (jb_beg + A.i_chunk < A.n_j) ? jb_beg + A.i_chunk : A.n_j;
 
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
             for (int aa = 0; aa < AC; ++aa) {
               const int a = chunk * AC + aa;
               if (a < N) {
-                double* dst = A.K + ((int64_t)i * N3 + 3 * a) * A.ld + outcol;
+                double* dst = A.K + ((int64_t)(i - A.i_beg) * N3 + 3 * a) * A.ld + outcol;
                 dst[0] = acc[ib][aa][0];
                 dst[A.ld] = acc[ib][aa][1];
                 dst[2 * A.ld] = acc[ib][aa][2];
@@ -465,7 +466,7 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
                      "assembly kernel needs %zu bytes of LDS for N=%d (limit 160 KiB)", lds, N);
   // column points per workgroup: long enough to amortise the resident row points, short enough
   // that the grid has >= ~8 workgroups per CU
-  const int64_t n_ib = (A.M + IB - 1) / IB;
+  const int64_t n_ib = (A.i_end - A.i_beg + IB - 1) / IB;
   int j_chunk = env_int("GDML_ASM_ICHUNK", 64);
   while (j_chunk > 4 && n_ib * ((n_j + j_chunk - 1) / j_chunk) < 4096) j_chunk >>= 1;
   A.i_chunk = j_chunk;
@@ -494,7 +495,7 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
 #undef CASE1
 #undef LAUNCH
   // algorithmic bytes: every requested element of K written once
-  ktime_end(ctx, slot, "assemble", 8.0 * (double)A.M * 3.0 * N * (double)n_j * 3.0 * N);
+  ktime_end(ctx, slot, "assemble", 8.0 * (double)(A.i_end - A.i_beg) * 3.0 * N * (double)n_j * 3.0 * N);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;
@@ -577,15 +578,28 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
     return gdml_fail(ctx, GDML_ERR_INVALID, "ldk (%lld) < n_cols (%lld)", (long long)ldk,
                      (long long)n_cols);
 
+  // ---- row sharding: with a communicator (gdml_comm_init, world > 1) the Nystroem matrix
+  // (index-list columns + extra rows) holds only this rank's training points
+  int64_t i_beg = 0, i_end = M;
+  const bool sharded = ctx->world > 1 && col_kind == GDML_COLS_INDEX && alloc_extra_rows > 0;
+  if (sharded) {
+    if (use_E_cstr)
+      return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "sharded assembly does not support energy constraints");
+    shard_points(ctx, M, &i_beg, &i_end, nullptr);
+  }
+  const int64_t n_rows_store = sharded ? (i_end - i_beg) * N3 : n_rows;
+
   // ---- (re)allocate the device matrix
-  const int64_t tot_rows = n_rows + alloc_extra_rows;
+  const int64_t tot_rows = n_rows_store + alloc_extra_rows;
   const int64_t ld = (n_cols + 15) / 16 * 16;  // rows start on 128-byte boundaries
   if (ctx->K) {
     GDML_TRY(ctx_free(ctx, ctx->K));
     ctx->K = nullptr;
   }
   GDML_TRY(ctx_alloc(ctx, (void**)&ctx->K, tot_rows * ld * 8));
-  ctx->K_rows = n_rows;
+  ctx->K_rows = n_rows_store;
+  ctx->K_rows_global = n_rows;
+  ctx->K_sharded = sharded;
   ctx->K_cols = n_cols;
   ctx->K_extra = alloc_extra_rows;
   ctx->K_ld = ld;
@@ -622,8 +636,11 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
       A.dbg = dbg ? atoi(dbg) : 0;
     }
     A.K = ctx->K; A.ld = ld;
-    if (assemble_wave_applicable(ctx))
-      rc = assemble_wave_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, ctx->K, ld);
+    A.i_beg = i_beg; A.i_end = i_end;
+    if (i_end <= i_beg)
+      rc = GDML_OK;
+    else if (assemble_wave_applicable(ctx))
+      rc = assemble_wave_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, ctx->K, ld, i_beg, i_end);
     else
       rc = assemble_dispatch(ctx, A, n_j);
   }
@@ -652,7 +669,7 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
   GDML_TRY(rc);
 
   if (K_host_out) {
-    HIP_CHECK(ctx, hipMemcpy2DAsync(K_host_out, ldk * 8, ctx->K, ld * 8, n_cols * 8, n_rows,
+    HIP_CHECK(ctx, hipMemcpy2DAsync(K_host_out, ldk * 8, ctx->K, ld * 8, n_cols * 8, n_rows_store,
                                     hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }

@@ -56,6 +56,7 @@ struct WaveArgs {
   const int32_t* jlist;
   const int32_t* colmap;
   int64_t j0, n_j;
+  int64_t i_beg;  // first row point handled by this launch (rows are written relative to it)
   int j_chunk;
   double* K;
   int64_t ld;
@@ -69,7 +70,7 @@ __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
   const bool act = lane < N3;
   const int c = act ? lane : 0;
   const int b = c / 3, beta = c - 3 * b;
-  const int64_t i = blockIdx.x;
+  const int64_t i = A.i_beg + blockIdx.x;
   const int64_t jb_beg = (int64_t)blockIdx.y * A.j_chunk;
   const int64_t jb_end = (jb_beg + A.j_chunk < A.n_j) ? jb_beg + A.j_chunk : A.n_j;
   if (jb_beg >= jb_end) return;
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
 
     const int64_t outcol = A.colmap ? (int64_t)A.colmap[jb * N3 + c] : jb * N3 + c;
     if (act && outcol >= 0) {
-      double* dst = A.K + (i * N3) * A.ld + outcol;
+      double* dst = A.K + ((i - A.i_beg) * N3) * A.ld + outcol;
 #pragma unroll
       for (int a = 0; a < N; ++a) {
         const double w = cp * rj[a];
@@ -189,20 +190,24 @@ bool assemble_wave_applicable(const gdml_ctx* ctx) {
 }
 
 int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist,
-                         const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld) {
+                         const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld,
+                         int64_t i_beg, int64_t i_end) {
   TrainSet& ts = ctx->ts;
   GDML_TRY(build_dense_tables(ctx));
   WaveArgs A;
   A.XF = ts.XF; A.GD = ts.GD; A.M = ts.M; A.N = ts.N; A.sig = sig; A.use_E = use_E;
   A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.n_j = n_j; A.K = K; A.ld = ld;
+  A.i_beg = i_beg;
+  const int64_t n_i = i_end - i_beg;
+  if (n_i <= 0) return GDML_OK;
   int j_chunk = 64;
   {
     const char* e = getenv("GDML_ASM_ICHUNK");
     if (e) j_chunk = atoi(e);
   }
-  while (j_chunk > 8 && ts.M * ((n_j + j_chunk - 1) / j_chunk) < 8192) j_chunk >>= 1;
+  while (j_chunk > 8 && n_i * ((n_j + j_chunk - 1) / j_chunk) < 8192) j_chunk >>= 1;
   A.j_chunk = j_chunk;
-  dim3 grid((unsigned)ts.M, (unsigned)((n_j + j_chunk - 1) / j_chunk));
+  dim3 grid((unsigned)n_i, (unsigned)((n_j + j_chunk - 1) / j_chunk));
   const int slot = ktime_begin(ctx);
   switch (ts.N) {
 #define WC(v) case v: hipLaunchKernelGGL(assemble_wave_kernel<v>, grid, dim3(64), 0, ctx->stream, A); break;
@@ -211,7 +216,7 @@ int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
 #undef WC
     default: return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_wave: N out of range");
   }
-  ktime_end(ctx, slot, "assemble", 8.0 * (double)ts.M * 3.0 * ts.N * (double)n_j * 3.0 * ts.N);
+  ktime_end(ctx, slot, "assemble", 8.0 * (double)n_i * 3.0 * ts.N * (double)n_j * 3.0 * ts.N);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;

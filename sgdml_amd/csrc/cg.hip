@@ -278,6 +278,46 @@ static int cho_factor_stable_dev(gdml_ctx* ctx, double* A, int64_t m, int64_t ld
   return GDML_OK;
 }
 
+// Row-shard geometry of the resident Nystroem matrix: this rank's rows are global rows
+// [row0, row0 + n_loc); vectors are replicated, padded to n_pad = world * chunk doubles.
+struct ShardGeo {
+  int64_t n, n_loc, row0, chunk, n_pad;
+};
+static ShardGeo shard_geo(const gdml_ctx* ctx) {
+  ShardGeo g;
+  const int64_t N3 = 3 * (int64_t)ctx->ts.N;
+  if (ctx->K_sharded) {
+    int64_t p0, p1, per;
+    shard_points(ctx, ctx->ts.M, &p0, &p1, &per);
+    g.n = ctx->K_rows_global;
+    g.n_loc = (p1 - p0) * N3;
+    g.row0 = p0 * N3;
+    g.chunk = per * N3;
+    g.n_pad = g.chunk * ctx->world;
+  } else {
+    g.n = g.n_loc = g.chunk = g.n_pad = ctx->K_rows;
+    g.row0 = 0;
+  }
+  return g;
+}
+
+// dst rows (work block) <- -K[idx[q], :] for the rows this rank owns, zero otherwise (iterative.py:250)
+__global__ void __launch_bounds__(256) gather_neg_rows_sharded_kernel(const double* __restrict__ X,
+                                                                      double* __restrict__ S, int64_t ld,
+                                                                      const int64_t* __restrict__ idx,
+                                                                      int64_t m, int64_t row0,
+                                                                      int64_t n_loc) {
+  const int64_t q = blockIdx.x;
+  const int64_t r = idx[q] - row0;
+  double* dst = S + q * ld;
+  if (r >= 0 && r < n_loc) {
+    const double* src = X + r * ld;
+    for (int64_t c = threadIdx.x; c < m; c += 256) dst[c] = -src[c];
+  } else {
+    for (int64_t c = threadIdx.x; c < m; c += 256) dst[c] = 0.0;
+  }
+}
+
 extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* idx, int64_t m,
                                     double* lev_scores_out, double* LinvKmn_host_out, int* info) {
   if (!ctx || !idx || m < 1) return GDML_ERR_INVALID;
@@ -285,10 +325,11 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
     return gdml_fail(ctx, GDML_ERR_STATE,
                      "gdml_nystroem_factor: needs the (n+m) x m matrix of gdml_assemble_K(INDEX, extra=m)");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  const int64_t n = ctx->K_rows, ld = ctx->K_ld;
+  const ShardGeo sg = shard_geo(ctx);
+  const int64_t n_loc = sg.n_loc, ld = ctx->K_ld;
   if (info) *info = 0;
-  double* X = ctx->K;
-  double* S = ctx->K + n * ld;  // m x m work block
+  double* X = ctx->K;               // this rank's rows of K_nm
+  double* S = ctx->K + n_loc * ld;  // m x m work block (replicated)
   void* tmp = nullptr;
   GDML_TRY(ctx_alloc(ctx, &tmp, m * m * 8 + m * 8));
   double* backup = (double*)tmp;
@@ -297,19 +338,21 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
   auto body = [&]() -> int {
     HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
     phase_begin(ctx);
-    // K_mm = -K[idx, :]  (psd copy, iterative.py:250)
-    hipLaunchKernelGGL(gather_neg_rows_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, ctx->K, ld,
-                       d_idx, m, n);
+    // K_mm = -K[idx, :]: every rank contributes the rows it owns, the sum replicates the block
+    hipLaunchKernelGGL(gather_neg_rows_sharded_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, X, S,
+                       ld, d_idx, m, sg.row0, n_loc);
+    GDML_TRY(comm_allreduce_sum(ctx, S, m * ld));
     int ok = 0;
     GDML_TRY(cho_factor_stable_dev(ctx, S, m, ld, backup, true, 1, &ok));  // iterative.py:263
     if (!ok)
       return gdml_fail(ctx, GDML_ERR_NOT_PD,
                        "Failed to factorize despite strong regularization (max: 10)! You could try a larger sigma.");
-    GDML_TRY(tall_trsm(ctx, S, X, n, m, ld));  // K_nm <- K_nm L_mm^-T  (iterative.py:276-286)
-    // inner = K_nm^T K_nm + lam I  (iterative.py:293-294)
+    GDML_TRY(tall_trsm(ctx, S, X, n_loc, m, ld));  // K_nm <- K_nm L_mm^-T  (iterative.py:276-286)
+    // inner = K_nm^T K_nm + lam I  (iterative.py:293-294): local SYRK, summed over the shards
     const int tiles = (int)((m + TT - 1) / TT);
     hipLaunchKernelGGL(syrk_tn_kernel, dim3((unsigned)(tiles * (tiles + 1) / 2)), dim3(256), 0,
-                       ctx->stream, X, ld, n, m, S, ld, tiles);
+                       ctx->stream, X, ld, n_loc, m, S, ld, tiles);
+    GDML_TRY(comm_allreduce_sum(ctx, S, m * ld));
     hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, S, ld, m, lam);
     GDML_TRY(cho_factor_stable_dev(ctx, S, m, ld, backup, false, -14, &ok));  // iterative.py:304-306
     if (!ok) {
@@ -318,7 +361,7 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
                        "second Nystroem Cholesky failed (the reference falls back to QR here, "
                        "iterative.py:313-324: not implemented)");
     }
-    GDML_TRY(tall_trsm(ctx, S, X, n, m, ld));  // iterative.py:335-345
+    GDML_TRY(tall_trsm(ctx, S, X, n_loc, m, ld));  // iterative.py:335-345
     GDML_TRY(phase_end(ctx, "precon"));
     return GDML_OK;
   };
@@ -326,54 +369,64 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
   if (rc == GDML_OK) {
     ctx->precon = X;
     ctx->precon_m = m;
-    ctx->precon_n = n;
+    ctx->precon_n = sg.n;
     if (lev_scores_out) {
       double* d_lev;
-      rc = ctx_slot(ctx, 2, n * 8, &d_lev);
+      rc = ctx_slot(ctx, 2, sg.n_pad * 8, &d_lev);
+      if (rc == GDML_OK && n_loc > 0)
+        hipLaunchKernelGGL(row_sqnorm_kernel, dim3(ceil_div(n_loc, 4)), dim3(256), 0, ctx->stream, X, ld,
+                           n_loc, m, d_lev + sg.row0);
+      if (rc == GDML_OK) rc = comm_allgather_inplace(ctx, d_lev, sg.chunk);
       if (rc == GDML_OK) {
-        hipLaunchKernelGGL(row_sqnorm_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, ctx->stream, X, ld, n,
-                           m, d_lev);
-        hipError_t e = hipMemcpyAsync(lev_scores_out, d_lev, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipMemcpyAsync(lev_scores_out, d_lev, sg.n * 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "lev scores: %s", hipGetErrorString(e));
       }
     }
     if (rc == GDML_OK && LinvKmn_host_out) {
-      // host gets L^-1 K_mn (m x n): transpose of X, done on the host side of the copy
-      std::vector<double> h((size_t)n * m);
-      hipError_t e = hipMemcpy2DAsync(h.data(), m * 8, X, ld * 8, m * 8, n, hipMemcpyDeviceToHost,
+      // host gets this rank's columns of L^-1 K_mn as an (m x n_loc) array: transpose of X
+      std::vector<double> h((size_t)n_loc * m);
+      hipError_t e = hipMemcpy2DAsync(h.data(), m * 8, X, ld * 8, m * 8, n_loc, hipMemcpyDeviceToHost,
                                       ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess)
         rc = gdml_fail(ctx, GDML_ERR_HIP, "factor copy: %s", hipGetErrorString(e));
       else
-        for (int64_t r = 0; r < n; ++r)
-          for (int64_t c = 0; c < m; ++c) LinvKmn_host_out[c * n + r] = h[(size_t)r * m + c];
+        for (int64_t r = 0; r < n_loc; ++r)
+          for (int64_t c = 0; c < m; ++c) LinvKmn_host_out[c * n_loc + r] = h[(size_t)r * m + c];
     }
   }
   int rc2 = ctx_free(ctx, tmp);
   return rc != GDML_OK ? rc : rc2;
 }
 
-// d_out = (X X^T d_v - d_v)/lam  on device vectors
+// d_out = (X X^T d_v - d_v)/lam on replicated (padded) device vectors; X row-sharded
 static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, double* d_out) {
   if (!ctx->precon) return gdml_fail(ctx, GDML_ERR_STATE, "no preconditioner resident");
-  const int64_t n = ctx->precon_n, m = ctx->precon_m, ld = ctx->K_ld;
+  const ShardGeo sg = shard_geo(ctx);
+  const int64_t n_loc = sg.n_loc, m = ctx->precon_m, ld = ctx->K_ld;
   int rows_per = 2048;
-  int nparts = (int)((n + rows_per - 1) / rows_per);
+  int nparts = (int)((n_loc + rows_per - 1) / rows_per);
+  if (nparts < 1) nparts = 1;
   double* buf;
   GDML_TRY(ctx_slot(ctx, 3, ((int64_t)nparts * m + m) * 8, &buf));
   double* part = buf;
   double* t = buf + (int64_t)nparts * m;
-  hipLaunchKernelGGL(gemv_t_part_kernel, dim3(ceil_div(m, 256), nparts), dim3(256), 0, ctx->stream,
-                     ctx->precon, ld, n, m, d_v, rows_per, part);
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m,
-                     nparts, t);
-  hipLaunchKernelGGL(gemv_n_precon_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, ctx->stream, ctx->precon,
-                     ld, n, m, t, d_v, 1.0 / lam, d_out);
+  if (n_loc > 0) {
+    hipLaunchKernelGGL(gemv_t_part_kernel, dim3(ceil_div(m, 256), nparts), dim3(256), 0, ctx->stream,
+                       ctx->precon, ld, n_loc, m, d_v + sg.row0, rows_per, part);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m,
+                       nparts, t);
+  } else {
+    HIP_CHECK(ctx, hipMemsetAsync(t, 0, m * 8, ctx->stream));
+  }
+  GDML_TRY(comm_allreduce_sum(ctx, t, m));
+  if (n_loc > 0)
+    hipLaunchKernelGGL(gemv_n_precon_kernel, dim3(ceil_div(n_loc, 4)), dim3(256), 0, ctx->stream,
+                       ctx->precon, ld, n_loc, m, t, d_v + sg.row0, 1.0 / lam, d_out + sg.row0);
   ctx->launch_counter += 3;
   HIP_CHECK(ctx, hipGetLastError());
-  return GDML_OK;
+  return comm_allgather_inplace(ctx, d_out, sg.chunk);
 }
 
 extern "C" int gdml_precon_apply(gdml_ctx* ctx, double lam, const double* v, int64_t n, double* out) {
@@ -381,12 +434,14 @@ extern "C" int gdml_precon_apply(gdml_ctx* ctx, double lam, const double* v, int
   if (!ctx->precon || n != ctx->precon_n)
     return gdml_fail(ctx, GDML_ERR_STATE, "gdml_precon_apply: no matching preconditioner resident");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const ShardGeo sg = shard_geo(ctx);
   void* buf = nullptr;
-  GDML_TRY(ctx_alloc(ctx, &buf, 2 * n * 8));
+  GDML_TRY(ctx_alloc(ctx, &buf, 2 * sg.n_pad * 8));
   double* dv = (double*)buf;
-  double* dout = dv + n;
+  double* dout = dv + sg.n_pad;
   int rc = GDML_OK;
-  hipError_t e = hipMemcpyAsync(dv, v, n * 8, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = hipMemsetAsync(dv, 0, 2 * sg.n_pad * 8, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dv, v, n * 8, hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "H2D: %s", hipGetErrorString(e));
   if (rc == GDML_OK) rc = precon_apply_device(ctx, lam, dv, dout);
   if (rc == GDML_OK) {
@@ -399,8 +454,9 @@ extern "C" int gdml_precon_apply(gdml_ctx* ctx, double lam, const double* v, int
 }
 
 // Preconditioned CG for A x = y, A v = -(K v - lam v)  (iterative.py:740-752; scipy cg:
-// stop when ||r|| < rtol*||y||, atol = 0).  All vectors stay on the device; two scalars per
-// iteration come back to the host.
+// stop when ||r|| < rtol*||y||, atol = 0).  All vectors stay on the device (replicated on every
+// rank when sharded: the mat-vec and the preconditioner all-gather their row shards, dot products
+// are evaluated redundantly and identically); two scalars per iteration come back to the host.
 extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const double* x0,
                         int64_t n, double rtol, int64_t maxiter, int use_precon, gdml_pcg_cb cb,
                         int64_t cb_every, void* user, double* x_out, int64_t* iters_out,
@@ -412,28 +468,36 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
     return gdml_fail(ctx, GDML_ERR_STATE,
                      "gdml_pcg: training set and operator model must be resident "
                      "(gdml_train_upload + gdml_predict_upload_model)");
+  if (ctx->world > 1 && use_E_cstr)
+    return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "sharded PCG does not support energy constraints");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int64_t n_pad = n;
+  if (ctx->world > 1) {
+    int64_t p0, p1, per;
+    shard_points(ctx, ctx->ts.M, &p0, &p1, &per);
+    n_pad = per * 3 * ctx->ts.N * ctx->world;
+  }
   void* buf = nullptr;
-  GDML_TRY(ctx_alloc(ctx, &buf, (6 * n + 256) * 8));
+  GDML_TRY(ctx_alloc(ctx, &buf, (6 * n_pad + 256) * 8));
   double* x = (double*)buf;
-  double* r = x + n;
-  double* z = r + n;
-  double* p = z + n;
-  double* q = p + n;
-  double* b = q + n;
-  double* d_part = b + n;
+  double* r = x + n_pad;
+  double* z = r + n_pad;
+  double* p = z + n_pad;
+  double* q = p + n_pad;
+  double* b = q + n_pad;
+  double* d_part = b + n_pad;
   const int grid = ceil_div(n, 256);
   std::vector<double> hx;
   int rc = GDML_OK, info = 1;
   int64_t it = 0;
   double rn = 0.0;
   auto body = [&]() -> int {
+    HIP_CHECK(ctx, hipMemsetAsync(buf, 0, (6 * n_pad + 256) * 8, ctx->stream));
     HIP_CHECK(ctx, hipMemcpyAsync(b, y, n * 8, hipMemcpyHostToDevice, ctx->stream));
     double bb = 0.0;
     GDML_TRY(dev_dot(ctx, b, b, n, d_part, &bb));
     const double bnrm = sqrt(bb);
     if (bnrm == 0.0) {
-      HIP_CHECK(ctx, hipMemsetAsync(x, 0, n * 8, ctx->stream));
       info = 0;
       return GDML_OK;
     }
@@ -444,7 +508,6 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
       HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
       hipLaunchKernelGGL(vec_axpy_kernel, dim3(grid), dim3(256), 0, ctx->stream, r, q, 1.0, n);  // r = b - A x
     } else {
-      HIP_CHECK(ctx, hipMemsetAsync(x, 0, n * 8, ctx->stream));
       HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
     double rho_prev = 0.0;
@@ -504,16 +567,4 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
   if (info_out) *info_out = info;
   int rc2 = ctx_free(ctx, buf);
   return rc != GDML_OK ? rc : rc2;
-}
-
-extern "C" int gdml_comm_unique_id(void* id128_out) { return GDML_ERR_UNSUPPORTED; }
-extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world) {
-  if (!ctx) return GDML_ERR_INVALID;
-  return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "gdml_comm_init: not built yet");
-}
-extern "C" int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out) {
-  if (!ctx) return GDML_ERR_INVALID;
-  if (rank_out) *rank_out = ctx->rank;
-  if (world_out) *world_out = ctx->world;
-  return GDML_OK;
 }

@@ -1,0 +1,148 @@
+// RCCL plumbing for the sharded iterative solver (new relative to the reference, which has no
+// collective at all: SURVEY.md section 2a).  librccl is bound at run time with dlopen/dlsym so that
+// the library has no link-time dependency on it and shares the copy another component of the
+// process (e.g. torch.distributed's "nccl" backend, which IS RCCL on ROCm) may already have loaded.
+//
+// Sharding model (one process per GPU): training points are split into W contiguous shards of
+// pts_per = ceil(M / W) points.  Vectors of length n = 3N M are replicated on every rank in buffers
+// padded to W * pts_per * 3N doubles so that all-gathers are in place with equal chunk sizes.
+#include <dlfcn.h>
+
+#include "common.h"
+
+typedef int ncclResult_t_;
+typedef struct { char internal[128]; } ncclUniqueId_;
+typedef void* ncclComm_t_;
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t_ (*GetUniqueId)(ncclUniqueId_*) = nullptr;
+  ncclResult_t_ (*CommInitRank)(ncclComm_t_*, int, ncclUniqueId_, int) = nullptr;
+  ncclResult_t_ (*CommDestroy)(ncclComm_t_) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t_) = nullptr;
+  ncclResult_t_ (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+  ncclResult_t_ (*AllGather)(const void*, void*, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
+  ncclResult_t_ (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+};
+static RcclApi g_rccl;
+static const int kNcclDouble = 8, kNcclSum = 0;
+
+static bool rccl_load(std::string* err) {
+  if (g_rccl.handle) return true;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names)  // a copy already in the process wins
+    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL)) != nullptr) break;
+  if (!h)
+    for (const char* n : names)
+      if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+  if (!h) {
+    if (err) *err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+    return false;
+  }
+  RcclApi a;
+  a.handle = h;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+  a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+  a.Broadcast = (decltype(a.Broadcast))dlsym(h, "ncclBroadcast");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather || !a.Broadcast) {
+    if (err) *err = "librccl is missing required symbols";
+    return false;
+  }
+  g_rccl = a;
+  return true;
+}
+
+static int rccl_fail(gdml_ctx* ctx, const char* what, ncclResult_t_ r) {
+  return gdml_fail(ctx, GDML_ERR_COMM, "%s failed: %s", what,
+                   g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error");
+}
+
+extern "C" int gdml_comm_unique_id(void* id128_out) {
+  if (!id128_out) return GDML_ERR_INVALID;
+  std::string err;
+  if (!rccl_load(&err)) return gdml_fail(nullptr, GDML_ERR_COMM, "%s", err.c_str());
+  ncclUniqueId_ id;
+  ncclResult_t_ r = g_rccl.GetUniqueId(&id);
+  if (r != 0) return rccl_fail(nullptr, "ncclGetUniqueId", r);
+  memcpy(id128_out, id.internal, 128);
+  return GDML_OK;
+}
+
+extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world) {
+  if (!ctx) return GDML_ERR_INVALID;
+  if (world < 1 || rank < 0 || rank >= world)
+    return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_comm_init: rank %d / world %d", rank, world);
+  if (ctx->comm) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_comm_init: communicator already initialised");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (id128 == nullptr) {
+    // "virtual rank": shard arithmetic without a communicator (collectives are skipped); used by the
+    // single-GPU tests that stitch the shards of several contexts together on the host
+    ctx->rank = rank;
+    ctx->world = world;
+    ctx->virtual_rank = true;
+    return GDML_OK;
+  }
+  std::string err;
+  if (!rccl_load(&err)) return gdml_fail(ctx, GDML_ERR_COMM, "%s", err.c_str());
+  ncclUniqueId_ id;
+  memcpy(id.internal, id128, 128);
+  ncclComm_t_ comm = nullptr;
+  ncclResult_t_ r = g_rccl.CommInitRank(&comm, world, id, rank);
+  if (r != 0) return rccl_fail(ctx, "ncclCommInitRank", r);
+  ctx->comm = comm;
+  ctx->rank = rank;
+  ctx->world = world;
+  ctx->virtual_rank = false;
+  return GDML_OK;
+}
+
+void comm_destroy(gdml_ctx* ctx) {
+  if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t_)ctx->comm);
+  ctx->comm = nullptr;
+}
+
+extern "C" int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out) {
+  if (!ctx) return GDML_ERR_INVALID;
+  if (rank_out) *rank_out = ctx->rank;
+  if (world_out) *world_out = ctx->world;
+  return GDML_OK;
+}
+
+// ---- shard arithmetic ---------------------------------------------------------------------
+void shard_points(const gdml_ctx* ctx, int64_t M, int64_t* p0, int64_t* p1, int64_t* pts_per) {
+  const int64_t W = ctx->world > 0 ? ctx->world : 1;
+  const int64_t per = (M + W - 1) / W;
+  int64_t a = per * ctx->rank, b = a + per;
+  if (a > M) a = M;
+  if (b > M) b = M;
+  *p0 = a;
+  *p1 = b;
+  if (pts_per) *pts_per = per;
+}
+
+// ---- collectives on the compute stream (no-ops for world == 1 / virtual ranks) -----------------
+int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk) {
+  if (ctx->world <= 1 || ctx->virtual_rank) return GDML_OK;
+  ncclResult_t_ r = g_rccl.AllGather(buf + (int64_t)ctx->rank * chunk, buf, (size_t)chunk, kNcclDouble,
+                                     (ncclComm_t_)ctx->comm, ctx->stream);
+  if (r != 0) return rccl_fail(ctx, "ncclAllGather", r);
+  return GDML_OK;
+}
+
+int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count) {
+  if (ctx->world <= 1 || ctx->virtual_rank) return GDML_OK;
+  // large buffers go in pieces of 2^28 doubles (2 GiB) to stay inside RCCL's comfortable sizes
+  const int64_t piece = (int64_t)1 << 28;
+  for (int64_t off = 0; off < count; off += piece) {
+    const int64_t c = (count - off < piece) ? count - off : piece;
+    ncclResult_t_ r = g_rccl.AllReduce(buf + off, buf + off, (size_t)c, kNcclDouble, kNcclSum,
+                                       (ncclComm_t_)ctx->comm, ctx->stream);
+    if (r != 0) return rccl_fail(ctx, "ncclAllReduce", r);
+  }
+  return GDML_OK;
+}

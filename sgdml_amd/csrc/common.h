@@ -99,6 +99,9 @@ struct gdml_ctx {
   // comm
   void* comm = nullptr;  // ncclComm_t
   int rank = 0, world = 1;
+  bool virtual_rank = false;   // shard arithmetic only, collectives skipped (tests)
+  bool K_sharded = false;      // resident K holds only this rank's rows (Nystroem path)
+  int64_t K_rows_global = 0;
 };
 
 int gdml_fail(gdml_ctx* ctx, int code, const char* fmt, ...);
@@ -164,6 +167,11 @@ int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t l
 int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, int64_t ld, int w,
                   int64_t m);
 int ctx_slot(gdml_ctx* ctx, int slot, int64_t bytes, double** out);
+void shard_points(const gdml_ctx* ctx, int64_t M, int64_t* p0, int64_t* p1, int64_t* pts_per);
+int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk);
+int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count);
+void comm_destroy(gdml_ctx* ctx);
 bool assemble_wave_applicable(const gdml_ctx* ctx);
 int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist,
-                         const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld);
+                         const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld,
+                         int64_t i_beg, int64_t i_end);

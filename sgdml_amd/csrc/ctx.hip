@@ -89,6 +89,7 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   if (!ctx) return GDML_OK;
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
+  comm_destroy(ctx);
   for (auto& t : ctx->pending) {
     hipEventDestroy(t.e0);
     hipEventDestroy(t.e1);

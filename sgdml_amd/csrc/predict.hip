@@ -623,17 +623,34 @@ int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, 
   TrainSet& ts = ctx->ts;
   if (!md.xp || !ts.x || md.M != ts.M)
     return gdml_fail(ctx, GDML_ERR_STATE, "kernel_matvec: training set / operator model not resident");
-  const int64_t M = ts.M, nF = M * 3 * ts.N, nE = use_E_cstr ? M : 0;
+  const int64_t M = ts.M, N3 = 3 * (int64_t)ts.N, nF = M * N3, nE = use_E_cstr ? M : 0;
   if (n != nF + nE) return gdml_fail(ctx, GDML_ERR_INVALID, "kernel_matvec: n mismatch");
   GDML_TRY(set_alphas_device(ctx, d_v, use_E_cstr ? d_v + nF : nullptr));
+  // query shard of this rank (all training points when there is no communicator); d_v / d_out are
+  // replicated vectors, padded to world * chunk doubles when sharded
+  int64_t p0 = 0, p1 = M, per = M;
+  if (ctx->world > 1) {
+    if (use_E_cstr)
+      return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "sharded mat-vec does not support energy constraints");
+    shard_points(ctx, M, &p0, &p1, &per);
+  }
+  const int64_t B = p1 - p0;
   double* dF;
-  GDML_TRY(ctx_slot(ctx, 1, (nF + M) * 8, &dF));
-  double* dE = dF + nF;
-  GDML_TRY(predict_device(ctx, ts.x, ts.g, M, use_E_cstr ? dE : nullptr, dF));
-  hipLaunchKernelGGL(matvec_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, dF, dE,
-                     d_v, nF, nE, lam, d_out);
-  ctx->launch_counter++;
-  HIP_CHECK(ctx, hipGetLastError());
+  GDML_TRY(ctx_slot(ctx, 1, (B * N3 + B + 8) * 8, &dF));
+  double* dE = dF + B * N3;
+  if (B > 0) {
+    GDML_TRY(predict_device(ctx, ts.x + p0 * ts.D, ts.g + p0 * ts.D * 3, B, use_E_cstr ? dE : nullptr, dF));
+    if (ctx->world > 1) {
+      hipLaunchKernelGGL(matvec_finish_kernel, dim3(ceil_div(B * N3, 256)), dim3(256), 0, ctx->stream, dF,
+                         dE, d_v + p0 * N3, B * N3, (int64_t)0, lam, d_out + p0 * N3);
+    } else {
+      hipLaunchKernelGGL(matvec_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, dF, dE,
+                         d_v, nF, nE, lam, d_out);
+    }
+    ctx->launch_counter++;
+    HIP_CHECK(ctx, hipGetLastError());
+  }
+  if (ctx->world > 1) GDML_TRY(comm_allgather_inplace(ctx, d_out, per * N3));
   return GDML_OK;
 }
 
@@ -670,12 +687,20 @@ extern "C" int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, con
                                   int64_t n, double* out) {
   if (!ctx || !v || !out) return GDML_ERR_INVALID;
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int64_t n_pad = n;
+  if (ctx->world > 1 && ctx->ts.x) {
+    int64_t p0, p1, per;
+    shard_points(ctx, ctx->ts.M, &p0, &p1, &per);
+    n_pad = per * 3 * ctx->ts.N * ctx->world;
+    if (n_pad < n) n_pad = n;
+  }
   void* buf = nullptr;
-  GDML_TRY(ctx_alloc(ctx, &buf, 2 * n * 8));
+  GDML_TRY(ctx_alloc(ctx, &buf, 2 * n_pad * 8));
   double* dv = (double*)buf;
-  double* dout = dv + n;
+  double* dout = dv + n_pad;
   int rc = GDML_OK;
-  hipError_t e = hipMemcpyAsync(dv, v, n * 8, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = hipMemsetAsync(buf, 0, 2 * n_pad * 8, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dv, v, n * 8, hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "H2D: %s", hipGetErrorString(e));
   if (rc == GDML_OK) {
     phase_begin(ctx);

@@ -22,6 +22,22 @@ def ctx():
     c.close()
 
 
+@pytest.fixture
+def ctx_factory():
+    from sgdml_amd import _lib
+
+    made = []
+
+    def make():
+        c = _lib.Context()
+        made.append(c)
+        return c
+
+    yield make
+    for c in made:
+        c.close()
+
+
 def test_desc(golden, ctx):
     g = golden
     M, N = g['R_train'].shape[:2]
@@ -327,3 +343,72 @@ def test_dropin_train_iterative(golden):
     pred = GDMLPredict(model)
     E, F = pred.predict(g['R_test'].reshape(len(g['R_test']), -1))
     assert np.abs(F - g['F_test']).max() <= 0.05 * np.abs(g['F_test']).max()
+
+
+# ------------------------------------------------------------------ sharding / RCCL plumbing
+
+
+def test_comm_world1_pcg(ctx_factory):
+    """A real RCCL communicator with one rank: every collective is issued (in-place all-gather /
+    all-reduce of a single chunk) and the solve must be unchanged."""
+    import os
+
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'n6_p1.npz')))
+    lam, sig = float(g['lam']), float(g['sig'])
+    tp = _tril_perms(g)
+    idx = g['col_idxs']
+    res = []
+    for with_comm in (False, True):
+        c = ctx_factory()
+        if with_comm:
+            c.comm_init(c.comm_unique_id(), 0, 1)
+            assert c.comm_info() == (0, 1)
+        c.train_upload(g['R_desc'], g['R_d_desc'], tp)
+        c.assemble_K(sig, False, idx=idx, alloc_extra_rows=len(idx))
+        lev, _, _ = c.nystroem_factor(lam, idx)
+        c.predict_upload_model(g['R_desc'], np.zeros_like(g['R_desc']), tp, sig, None)
+        x, info, iters, resid = c.pcg(lam, False, g['y'], rtol=1e-6, maxiter=3000)
+        assert info == 0
+        res.append((lev, x, iters))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-12)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-9, atol=1e-9 * np.abs(res[0][1]).max())
+
+
+@pytest.mark.parametrize('case,world', [('n6_p1', 2), ('n9_p1', 4), ('n5_p4', 3)])
+def test_virtual_rank_shards_stitch(ctx_factory, case, world):
+    """Shard arithmetic of the kernels on one GPU: 'virtual ranks' (no communicator) each produce
+    their row shard of the Nystroem matrix and of K v; stitched together they equal the unsharded
+    results."""
+    import os
+
+    from sgdml_amd.dist import shard_range
+
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), 'golden', case + '.npz')))
+    lam, sig = float(g['lam']), float(g['sig'])
+    tp = _tril_perms(g)
+    idx = g['col_idxs']
+    M, N = g['R_train'].shape[:2]
+    N3 = 3 * N
+    n = M * N3
+    ref = ctx_factory()
+    ref.train_upload(g['R_desc'], g['R_d_desc'], tp)
+    ref.predict_upload_model(g['R_desc'], np.zeros_like(g['R_desc']), tp, sig, None)
+    Kv_full = ref.kernel_matvec(lam, False, g['v'])
+    Kc_full = ref.assemble_K(sig, False, idx=idx, alloc_extra_rows=len(idx), to_host=True)[:n]
+    Kv_st = np.full(n, np.nan)
+    Kc_st = np.full_like(Kc_full, np.nan)
+    for r in range(world):
+        p0, p1, per = shard_range(r, world, M)
+        c = ctx_factory()
+        c.comm_init(None, r, world)
+        c.train_upload(g['R_desc'], g['R_d_desc'], tp)
+        c.predict_upload_model(g['R_desc'], np.zeros_like(g['R_desc']), tp, sig, None)
+        out = c.kernel_matvec(lam, False, g['v'])
+        Kv_st[p0 * N3:p1 * N3] = out[p0 * N3:p1 * N3]
+        c.assemble_K(sig, False, idx=idx, alloc_extra_rows=len(idx))
+        rows, cols, extra = c.K_shape()
+        assert rows == (p1 - p0) * N3 and cols == len(idx) and extra == len(idx)
+        Kc_st[p0 * N3:p1 * N3] = c.K_to_host()[:rows]
+    assert not np.isnan(Kv_st).any() and not np.isnan(Kc_st).any()
+    np.testing.assert_allclose(Kv_st, Kv_full, rtol=0, atol=1e-13 * np.abs(Kv_full).max())
+    np.testing.assert_allclose(Kc_st, Kc_full, rtol=0, atol=1e-14 * np.abs(Kc_full).max())
