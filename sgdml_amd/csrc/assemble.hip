@@ -38,6 +38,7 @@ struct AsmArgs {
   int64_t i_beg, i_end;  // row points handled by this launch (rows written relative to i_beg)
   int64_t n_j;   // number of column points
   int i_chunk;   // column points walked by one workgroup
+  const double* GD;  // dense m-major G table (assemble_wave.hip) or null: G_j is then staged in LDS
   int dbg;  // GDML_ASM_DEBUG ablation bits: 1 skip stores, 2 skip phase A2, 4 skip phase B
   double* K;
   int64_t ld;
@@ -74,8 +75,9 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = A.N, D = A.D, P = A.P, N3 = 3 * N, NN = N * N;
   double* xjp = smem;               // D
-  double* GJp = xjp + D;            // 3 NN
-  double* xi = GJp + 3 * NN;        // IB x D
+  const bool gjg = A.GD != nullptr;  // large molecules: G_j read from the global dense table
+  double* GJp = xjp + D;            // 3 NN (absent if gjg)
+  double* xi = GJp + (gjg ? 0 : 3 * NN);  // IB x D
   double* Gi = xi + IB * D;         // IB x 3 NN
   double* DvF = Gi + IB * 3 * NN;   // IB x NN
   double* u = DvF + IB * NN;        // IB x 3N
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
   const double e_fact = 5.0 / (3.0 * sig * sig * sig);
 
   // (j,p) tables, flattened step t = (jb - jb_beg) * P + p: permuted x_j (D) + dense permuted G_j (3 NN)
-  const int per_pt = D + 3 * NN;
+  const int per_pt = gjg ? D : D + 3 * NN;
   constexpr int PFI = 4;  // register prefetch slots per thread
   const bool use_pf = per_pt <= PFI * T;
   double pf[PFI];
@@ -180,6 +182,7 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
   for (int64_t step = 0; step < n_steps; ++step) {
     const int64_t jb = jb_beg + step / P;
     const int p = (int)(step - (step / P) * P);
+    const double* GDj = gjg ? A.GD + (A.jlist ? (int64_t)A.jlist[jb] : A.j0 + jb) * (int64_t)N * N3 : nullptr;
     __syncthreads();  // previous step's readers of the (j,p) tables and DvF/u/v/dg are done
     if (use_pf) {
 #pragma unroll
@@ -239,10 +242,16 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
       if (t < N3) {  // u[b,be] = sum_m DvF[pinv b][m] GJp[b][m][be]
         const int bb = t / 3, be = t - 3 * bb;
         const double* dr = Dv + pinv_s[bb] * N;
-        const double* gr = GJp + bb * N3 + be;
         double s = 0.0;
+        if (gjg) {
+          const double* gr = GDj + 3 * bb + be;  // G_j(b, pi m)[be] = GD[j][pi m][b][be]
+#pragma unroll 4
+          for (int m = 0; m < N; ++m) s += dr[m] * gr[perm_s[m] * N3];
+        } else {
+          const double* gr = GJp + bb * N3 + be;
 #pragma unroll 7
-        for (int m = 0; m < N; ++m) s += dr[m] * gr[3 * m];
+          for (int m = 0; m < N; ++m) s += dr[m] * gr[3 * m];
+        }
         u[ib * N3 + t] = s;
       } else if (t < 2 * N3) {  // v[a,al] = sum_m DvF[a][m] Gi[a][m][al]
         const int tt = t - N3;
@@ -258,10 +267,16 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
         const int a = tt / 9, r = tt - 9 * a;
         const int al = r / 3, be = r - 3 * al;
         const double* g1 = Gib + a * N3 + al;
-        const double* g2 = GJp + perm_s[a] * N3 + be;
         double s = 0.0;
+        if (gjg) {
+          const double* g2 = GDj + 3 * perm_s[a] + be;  // G_j(pi a, pi m)[be]
+#pragma unroll 4
+          for (int m = 0; m < N; ++m) s += g1[3 * m] * g2[perm_s[m] * N3];
+        } else {
+          const double* g2 = GJp + perm_s[a] * N3 + be;
 #pragma unroll 7
-        for (int m = 0; m < N; ++m) s += g1[3 * m] * g2[3 * m];
+          for (int m = 0; m < N; ++m) s += g1[3 * m] * g2[3 * m];
+        }
         dg[ib * 9 * N + tt] = s;
       }
     }
@@ -288,7 +303,7 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
           if (a < N) {
             double t0, t1, t2;
             if (a != ap) {
-              const double w = -cp * GJp[(b * N + a) * 3 + beta];
+              const double w = -cp * (gjg ? GDj[perm_s[a] * N3 + 3 * b + beta] : GJp[(b * N + a) * 3 + beta]);
               const double* gia = Gib + (a * N + ap) * 3;
               t0 = gia[0] * w;
               t1 = gia[1] * w;
@@ -420,9 +435,9 @@ static void launch_asm(gdml_ctx* ctx, const AsmArgs& A, dim3 grid, int T, size_t
   hipLaunchKernelGGL((assemble_kernel<AC, IB, MINW>), grid, dim3(T), lds, ctx->stream, A);
 }
 
-static size_t asm_lds_bytes(int N, int D, int IB) {
+static size_t asm_lds_bytes(int N, int D, int IB, bool gjg = false) {
   const size_t NN = (size_t)N * N;
-  size_t dbl = D + 3 * NN + (size_t)IB * (D + 3 * NN + NN + 15 * N + 16);
+  size_t dbl = D + (gjg ? 0 : 3 * NN) + (size_t)IB * (D + 3 * NN + NN + 15 * N + 16);
   size_t ints = NN + 2 * N + 3 * NN + NN;
   return dbl * 8 + ints * 4 + 16;
 }
@@ -461,9 +476,17 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   }
   const int minw = env_int("GDML_ASM_MINW", 2);
   size_t lds = asm_lds_bytes(N, D, IB);
+  A.GD = nullptr;
+  if (lds > 160 * 1024 || getenv("GDML_ASM_GJG")) {
+    // large molecule: keep only the row point's dense table in LDS, read G_j from the global table
+    extern int build_dense_tables(gdml_ctx * ctx);
+    GDML_TRY(build_dense_tables(ctx));
+    A.GD = ctx->ts.GD;
+    lds = asm_lds_bytes(N, D, IB, true);
+  }
   if (lds > 160 * 1024)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED,
-                     "assembly kernel needs %zu bytes of LDS for N=%d (limit 160 KiB)", lds, N);
+                     "assembly kernel needs %zu bytes of LDS for N=%d (limit 160 KiB, N <= 61)", lds, N);
   // column points per workgroup: long enough to amortise the resident row points, short enough
   // that the grid has >= ~8 workgroups per CU
   const int64_t n_ib = (A.i_end - A.i_beg + IB - 1) / IB;

@@ -412,3 +412,26 @@ def test_virtual_rank_shards_stitch(ctx_factory, case, world):
     assert not np.isnan(Kv_st).any() and not np.isnan(Kc_st).any()
     np.testing.assert_allclose(Kv_st, Kv_full, rtol=0, atol=1e-13 * np.abs(Kv_full).max())
     np.testing.assert_allclose(Kc_st, Kc_full, rtol=0, atol=1e-14 * np.abs(Kc_full).max())
+
+
+def test_K_large_molecule_global_table(ctx):
+    """N = 60 (C60-sized, BASELINE configs[4]): the column point's dense table no longer fits in LDS
+    next to the row point's; the kernel then reads G_j from the global dense table."""
+    N, M = 60, 3
+    ds = orc.synth_dataset(N, M, seed=11, jitter=0.1)
+    xo, go = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    ctx.train_upload(xo, go, tp)
+    K = ctx.assemble_K(40.0, False, to_host=True)
+    Ko = orc.assemble_K(xo, go, orc.tril_perms_lin_from_tril_perms(tp), 40.0)
+    assert np.abs(K - Ko).max() <= 1e-12 * np.abs(Ko).max()
+
+
+def test_K_global_table_path_with_perms(golden, ctx, monkeypatch):
+    """Same code path forced on the small fixtures (covers permutations and E-constraint rows)."""
+    g = golden
+    monkeypatch.setenv('GDML_ASM_GJG', '1')
+    monkeypatch.setenv('GDML_ASM_NO_WAVE', '1')
+    ctx.train_upload(g['R_desc'], g['R_d_desc'], _tril_perms(g))
+    K = ctx.assemble_K(float(g['sig']), bool(g['use_E_cstr']), to_host=True)
+    assert np.abs(K - g['K']).max() <= 1e-12 * np.abs(g['K']).max()
