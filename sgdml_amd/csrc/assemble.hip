@@ -39,6 +39,7 @@ struct AsmArgs {
   int64_t n_j;   // number of column points
   int i_chunk;   // column points walked by one workgroup
   const double* GD;  // dense m-major G table (assemble_wave.hip) or null: G_j is then staged in LDS
+  const double* XF;  // dense m-major x table (used together with GD)
   int dbg;  // GDML_ASM_DEBUG ablation bits: 1 skip stores, 2 skip phase A2, 4 skip phase B
   double* K;
   int64_t ld;
@@ -74,21 +75,23 @@ template <int AC, int IB, int MINW>
 __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = A.N, D = A.D, P = A.P, N3 = 3 * N, NN = N * N;
-  double* xjp = smem;               // D
-  const bool gjg = A.GD != nullptr;  // large molecules: G_j read from the global dense table
-  double* GJp = xjp + D;            // 3 NN (absent if gjg)
-  double* xi = GJp + (gjg ? 0 : 3 * NN);  // IB x D
-  double* Gi = xi + IB * D;         // IB x 3 NN
+  // gjg (large molecules): only the row points' dense G_i lives in LDS; x and G_j come from the
+  // global dense tables (XF, GD) and no index tables are needed
+  const bool gjg = A.GD != nullptr;
+  double* xjp = smem;                                  // D        (absent if gjg)
+  double* GJp = xjp + (gjg ? 0 : D);                   // 3 NN     (absent if gjg)
+  double* xi = GJp + (gjg ? 0 : 3 * NN);               // IB x D   (absent if gjg)
+  double* Gi = xi + (gjg ? 0 : IB * D);                // IB x 3 NN
   double* DvF = Gi + IB * 3 * NN;   // IB x NN
   double* u = DvF + IB * NN;        // IB x 3N
   double* vv = u + IB * N3;         // IB x 3N
   double* dg = vv + IB * N3;        // IB x 9N
   double* red = dg + IB * 9 * N;    // IB x 16
-  int* pidx = reinterpret_cast<int*>(red + IB * 16);  // NN  pair index of (a,m)
-  int* perm_s = pidx + NN;                            // N
-  int* pinv_s = perm_s + N;                           // N
-  int* stab = pinv_s + N;                             // 3 NN: offset k*3+al in g (bit 31: negate), -1: zero
-  int* mtab = stab + 3 * NN;                          // NN: m of the flattened (a,m)
+  int* perm_s = reinterpret_cast<int*>(red + IB * 16);  // N
+  int* pinv_s = perm_s + N;                             // N
+  int* pidx = pinv_s + N;                               // NN  pair index of (a,m)        (absent if gjg)
+  int* stab = pidx + NN;   // 3 NN: offset k*3+al in g (bit 31: negate), -1: zero          (absent if gjg)
+  int* mtab = stab + 3 * NN;                            // NN: m of the flattened (a,m)   (absent if gjg)
 
   const int tid = threadIdx.x, T = blockDim.x, nwaves = T >> 6;
   const int64_t i0 = A.i_beg + (int64_t)blockIdx.x * IB;
@@ -103,31 +106,42 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
   const int c = active ? item - chunk * N3 : 0;
   const int b = c / 3, beta = c - 3 * b;
 
-  for (int e = tid; e < NN; e += T) {
-    const int a = e / N, m = e - a * N;
-    pidx[e] = (a == m) ? 0 : pair_idx(a, m);
-    mtab[e] = m;
-  }
-  for (int q = tid; q < 3 * NN; q += T) {
-    const int am = q / 3, al = q - 3 * am;
-    const int a = am / N, m = am - a * N;
-    int v = -1;
-    if (a != m) v = (pair_idx(a, m) * 3 + al) | ((a < m) ? 0 : (int)0x80000000u);
-    stab[q] = v;
+  if (!gjg) {
+    for (int e = tid; e < NN; e += T) {
+      const int a = e / N, m = e - a * N;
+      pidx[e] = (a == m) ? 0 : pair_idx(a, m);
+      mtab[e] = m;
+    }
+    for (int q = tid; q < 3 * NN; q += T) {
+      const int am = q / 3, al = q - 3 * am;
+      const int a = am / N, m = am - a * N;
+      int v = -1;
+      if (a != m) v = (pair_idx(a, m) * 3 + al) | ((a < m) ? 0 : (int)0x80000000u);
+      stab[q] = v;
+    }
   }
   __syncthreads();
   // resident row points: x_i and the dense G_i
   for (int ib = 0; ib < IB; ++ib) {
     const int64_t i = (ib < nb) ? i0 + ib : i0 + nb - 1;
-    for (int k = tid; k < D; k += T) xi[ib * D + k] = A.x[i * D + k];
-    for (int q = tid; q < 3 * NN; q += T) {
-      const int t = stab[q];
-      double v = 0.0;
-      if (t != -1) {
-        v = A.g[i * 3 * D + (t & 0x7fffffff)];
-        if (t < 0) v = -v;
+    if (gjg) {
+      const double* gd = A.GD + i * (int64_t)NN * 3;
+      for (int q = tid; q < 3 * NN; q += T) {
+        const int am = q / 3, al = q - 3 * am;
+        const int a = am / N, m = am - a * N;
+        Gi[ib * 3 * NN + q] = gd[(m * N + a) * 3 + al];  // G_i(a,m)[al] = GD[i][m][a][al]
       }
-      Gi[ib * 3 * NN + q] = v;
+    } else {
+      for (int k = tid; k < D; k += T) xi[ib * D + k] = A.x[i * D + k];
+      for (int q = tid; q < 3 * NN; q += T) {
+        const int t = stab[q];
+        double v = 0.0;
+        if (t != -1) {
+          v = A.g[i * 3 * D + (t & 0x7fffffff)];
+          if (t < 0) v = -v;
+        }
+        Gi[ib * 3 * NN + q] = v;
+      }
     }
   }
 
@@ -138,7 +152,7 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
   const double e_fact = 5.0 / (3.0 * sig * sig * sig);
 
   // (j,p) tables, flattened step t = (jb - jb_beg) * P + p: permuted x_j (D) + dense permuted G_j (3 NN)
-  const int per_pt = gjg ? D : D + 3 * NN;
+  const int per_pt = gjg ? 0 : D + 3 * NN;
   constexpr int PFI = 4;  // register prefetch slots per thread
   const bool use_pf = per_pt <= PFI * T;
   double pf[PFI];
@@ -216,15 +230,30 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
     double part[IB];
 #pragma unroll
     for (int ib = 0; ib < IB; ++ib) part[ib] = 0.0;
-    for (int e = tid; e < NN; e += T) {
-      const int k = pidx[e];
-      const bool diag = mtab[e] * (N + 1) == e;
-      const double xjk = xjp[k];
+    if (gjg) {
+      const double* XFj = A.XF + (A.jlist ? (int64_t)A.jlist[jb] : A.j0 + jb) * (int64_t)NN;
+      for (int e = tid; e < NN; e += T) {
+        const int a = e / N, m = e - a * N;
+        const double xjk = XFj[perm_s[m] * N + perm_s[a]];  // x_j[pair(pi a, pi m)]
 #pragma unroll
-      for (int ib = 0; ib < IB; ++ib) {
-        const double dk = diag ? 0.0 : xi[ib * D + k] - xjk;
-        DvF[ib * NN + e] = dk;
-        part[ib] += dk * dk;
+        for (int ib = 0; ib < IB; ++ib) {
+          const int64_t i = (ib < nb) ? i0 + ib : i0 + nb - 1;
+          const double dk = (a == m) ? 0.0 : A.XF[i * (int64_t)NN + m * N + a] - xjk;
+          DvF[ib * NN + e] = dk;
+          part[ib] += dk * dk;
+        }
+      }
+    } else {
+      for (int e = tid; e < NN; e += T) {
+        const int k = pidx[e];
+        const bool diag = mtab[e] * (N + 1) == e;
+        const double xjk = xjp[k];
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) {
+          const double dk = diag ? 0.0 : xi[ib * D + k] - xjk;
+          DvF[ib * NN + e] = dk;
+          part[ib] += dk * dk;
+        }
       }
     }
 #pragma unroll
@@ -437,8 +466,8 @@ static void launch_asm(gdml_ctx* ctx, const AsmArgs& A, dim3 grid, int T, size_t
 
 static size_t asm_lds_bytes(int N, int D, int IB, bool gjg = false) {
   const size_t NN = (size_t)N * N;
-  size_t dbl = D + (gjg ? 0 : 3 * NN) + (size_t)IB * (D + 3 * NN + NN + 15 * N + 16);
-  size_t ints = NN + 2 * N + 3 * NN + NN;
+  size_t dbl = (gjg ? 0 : D + 3 * NN) + (size_t)IB * ((gjg ? 0 : D) + 3 * NN + NN + 15 * N + 16);
+  size_t ints = 2 * N + (gjg ? 0 : NN + 3 * NN + NN);
   return dbl * 8 + ints * 4 + 16;
 }
 
@@ -477,16 +506,18 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   const int minw = env_int("GDML_ASM_MINW", 2);
   size_t lds = asm_lds_bytes(N, D, IB);
   A.GD = nullptr;
+  A.XF = nullptr;
   if (lds > 160 * 1024 || getenv("GDML_ASM_GJG")) {
     // large molecule: keep only the row point's dense table in LDS, read G_j from the global table
     extern int build_dense_tables(gdml_ctx * ctx);
     GDML_TRY(build_dense_tables(ctx));
     A.GD = ctx->ts.GD;
+    A.XF = ctx->ts.XF;
     lds = asm_lds_bytes(N, D, IB, true);
   }
   if (lds > 160 * 1024)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED,
-                     "assembly kernel needs %zu bytes of LDS for N=%d (limit 160 KiB, N <= 61)", lds, N);
+                     "assembly kernel needs %zu bytes of LDS for N=%d (limit 160 KiB, N <= 66)", lds, N);
   // column points per workgroup: long enough to amortise the resident row points, short enough
   // that the grid has >= ~8 workgroups per CU
   const int64_t n_ib = (A.i_end - A.i_beg + IB - 1) / IB;
