@@ -122,12 +122,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    dist_dev = 'cpu'
     if world > 1:
         import torch  # plumbing only: rendezvous, barrier, max-reduce of the timings
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        n_dev = torch.cuda.device_count()
+        if n_dev >= world:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist_dev = 'cuda'
+        else:  # fewer GPUs than ranks (functional test of the N > 1 path on a small box)
+            dist.init_process_group('gloo')
+            local_rank = local_rank % max(1, n_dev)
 
     from sgdml_amd import _lib
 
@@ -161,7 +168,8 @@ def main():
         if dist is not None:
             import torch
 
-            torch.cuda.synchronize()
+            if dist_dev == 'cuda':
+                torch.cuda.synchronize()
             dist.barrier()
 
     phases = {'assemble': [], 'factor': [], 'solve': [], 'predict': []}
@@ -201,7 +209,7 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor(vals, device='cuda')
+        t = torch.tensor(vals, device=dist_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         vals = t.cpu().numpy()
     wall_ms, build_solve_ms, pred_ms = [float(v) for v in vals]
