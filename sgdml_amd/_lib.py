@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgdml_hip.so')
+LIB_PATH = os.environ.get('GDML_HIP_LIB', os.path.join(_HERE, 'libgdml_hip.so'))  # override: A/B builds
 
 GDML_OK = 0
 ERR_INVALID, ERR_HIP, ERR_OOM, ERR_STATE, ERR_NOT_PD, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6, -7

@@ -29,6 +29,12 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GT 128
 #define GBK 16
 #define GPITCH 17
+#ifndef GEMM_COMMIT_KS
+#define GEMM_COMMIT_KS 4   // k-step after which the prefetched tile is written to LDS (0,4,8,12)
+#endif
+#ifndef GEMM_EPI_PIPE
+#define GEMM_EPI_PIPE 0    // 1: software-pipelined epilogue (strip j+1 loads before strip j stores)
+#endif
 
 struct GemmArgs {
   const double* A;
@@ -68,14 +74,13 @@ __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int
   }
 }
 
-template <bool NEG>
 __device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid, const d2 (&r)[4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     int cidx = tid + 256 * s;
     int row = cidx >> 3, kc = (cidx & 7) * 2;
-    S[row * GPITCH + kc] = NEG ? -r[s].x : r[s].x;
-    S[row * GPITCH + kc + 1] = NEG ? -r[s].y : r[s].y;
+    S[row * GPITCH + kc] = r[s].x;
+    S[row * GPITCH + kc + 1] = r[s].y;
   }
 }
 
@@ -86,33 +91,18 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
 
-  // The accumulators start as the C tile itself (MFMA C/D layout: col = lane & 15,
-  // row = (lane >> 4) + 4 r) and the A operand is staged NEGATED, so the MFMA stream computes
-  // C - A B^T directly: the loads of C overlap the prologue's tile loads and the epilogue is a
-  // plain (fire-and-forget) store instead of a load / wait / subtract / store round trip.
-  double* Cw = g.C + (row0 + wm * 64 + lk) * g.ldc + col0 + wn * 64 + li;
   d4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (FULL) {
-          acc[i][j][r] = Cw[(i * 16 + 4 * r) * g.ldc + j * 16];
-        } else {
-          const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r, gc = col0 + wn * 64 + j * 16 + li;
-          const int64_t cr = gr < g.M ? gr : g.M - 1, cc = gc < g.N ? gc : g.N - 1;
-          acc[i][j][r] = g.C[cr * g.ldc + cc];
-        }
-      }
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
   const int64_t nk = (g.K + GBK - 1) / GBK;
   d2 ra[4], rb[4];
   gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, 0, g.K, tid, ra);
   gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, 0, g.K, tid, rb);
-  gemm_store_tile<true>(lds[0][0], tid, ra);
-  gemm_store_tile<false>(lds[0][1], tid, rb);
+  gemm_store_tile(lds[0][0], tid, ra);
+  gemm_store_tile(lds[0][1], tid, rb);
   __syncthreads();
 
   for (int64_t kt = 0; kt < nk; ++kt) {
@@ -135,18 +125,16 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
         for (int j = 0; j < 4; ++j) bb[j] = Bs[j * 16 * GPITCH + ks];
       }
-      if (g.dbg & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-      if (g.dbg & 16) __builtin_amdgcn_s_setprio(0);
-      if (ks == GBK / 2 - 4 && kt + 1 < nk && !(g.dbg & 2)) {
+      if (ks == GEMM_COMMIT_KS && kt + 1 < nk && !(g.dbg & 2)) {
         // the next tile's global loads were issued ~32 MFMAs ago: write them to the other LDS
         // buffer now so that the stores drain under the remaining MFMAs of this tile
-        gemm_store_tile<true>(lds[cur ^ 1][0], tid, ra);
-        gemm_store_tile<false>(lds[cur ^ 1][1], tid, rb);
+        gemm_store_tile(lds[cur ^ 1][0], tid, ra);
+        gemm_store_tile(lds[cur ^ 1][1], tid, rb);
       }
     }
     if (!(g.dbg & 8)) __syncthreads();
@@ -156,30 +144,68 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
     return;
   }
 
-  // ---- epilogue: store the finished tile.  The addresses are recomputed behind an opaque copy of
-  // ldc so that the 16 row pointers of the prologue do not stay live across the main loop.
-  int64_t ldc2 = g.ldc;
-  asm volatile("" : "+s"(ldc2));
-  double* Cw2 = g.C + (row0 + wm * 64 + lk) * ldc2 + col0 + wn * 64 + li;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
+  // ---- epilogue: C -= acc.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r.
+  // All loads of a 64x16 column strip are issued before the first use (no serialised round trips).
+  double* Cw = g.C + (row0 + wm * 64 + lk) * g.ldc + col0 + wn * 64 + li;
+#if GEMM_EPI_PIPE
+  if (FULL) {
+    double cv[2][4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (FULL) {
-          Cw2[(i * 16 + 4 * r) * ldc2 + j * 16] = acc[i][j][r];
-        } else {
-          const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r, gc = col0 + wn * 64 + j * 16 + li;
-          if (gr < g.M && gc < g.N) g.C[gr * g.ldc + gc] = acc[i][j][r];
-        }
+      for (int r = 0; r < 4; ++r) cv[0][i][r] = Cw[(i * 16 + 4 * r) * g.ldc];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cv[(j + 1) & 1][i][r] = Cw[(i * 16 + 4 * r) * g.ldc + (j + 1) * 16];
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[j & 1][i][r] - acc[i][j][r];
+    }
+    return;
+  }
+#endif
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double cv[4][4];
+    if (FULL) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[i][r] = Cw[(i * 16 + 4 * r) * g.ldc + j * 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[i][r] - acc[i][j][r];
+    } else {
+      const int64_t gc = col0 + wn * 64 + j * 16 + li;
+      const bool cok = gc < g.N;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
+          const bool ok = cok && gr < g.M;
+          const int64_t cr = gr < g.M ? gr : g.M - 1, cc = cok ? gc : g.N - 1;
+          cv[i][r] = g.C[cr * g.ldc + cc];
+          (void)ok;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
+          if (cok && gr < g.M) g.C[gr * g.ldc + gc] = cv[i][r] - acc[i][j][r];
+        }
+    }
+  }
 }
 
-// INTERIOR = true: guard-free tiles only (edge tiles return at once); false: the edge tiles only.
-// Two kernels so that the register allocation of the hot interior path is not burdened by the
-// guarded one.
-template <bool INTERIOR>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
   // ---- block -> tile mapping: XCD-aware 8x8 super tiles (block b runs on XCD b % 8)
@@ -204,8 +230,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   if (g.lower && tj > ti) return;
   const int64_t row0 = ti * GT, col0 = tj * GT;
   const bool full = (row0 + GT <= g.M) && (col0 + GT <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
-  if (full != INTERIOR) return;
-  gemm_tile_body<INTERIOR>(g, lds, row0, col0);
+  if (full)
+    gemm_tile_body<true>(g, lds, row0, col0);
+  else
+    gemm_tile_body<false>(g, lds, row0, col0);
 }
 
 int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
@@ -232,13 +260,8 @@ int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t l
   g.n_super = lower ? sm * (sm + 1) / 2 : sm * sn;
   int64_t groups = (g.n_super + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
   int64_t blocks = groups * 512;
-  const bool has_edge = (M % GT) || (N % GT) || (K % GBK) || !g.aligned;
-  const bool has_interior = g.aligned && (K % GBK == 0) && M >= GT && N >= GT;
   const int slot = (st == ctx->stream) ? ktime_begin(ctx) : -1;
-  if (has_interior)
-    hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
-  if (has_edge)
-    hipLaunchKernelGGL(gemm_nt_sub_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+  hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
   ktime_end(ctx, slot, "gemm_nt_sub",
             lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K);
   ctx->launch_counter++;
