@@ -555,141 +555,28 @@ __global__ void __launch_bounds__(256) trsv_bwd_kernel(const double* __restrict_
   }
 }
 
-// ---- panel-blocked triangular solves (512-wide panels: 4 launches per panel instead of 16) ----
-#define TSNB 512
-
-// Forward, diagonal part: solves L[k0:k0+nb, k0:k0+nb] z = b[k0:k0+nb] (one workgroup).
-__global__ void __launch_bounds__(256) trsv_panel_fwd_kernel(const double* __restrict__ L, int64_t ld,
-                                                             int64_t k0, int nb,
-                                                             const double* __restrict__ b,
-                                                             double* __restrict__ z_out) {
-  __shared__ __attribute__((aligned(16))) double Ls[64 * 65];
-  __shared__ double zs[TSNB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int r = tid; r < nb; r += 256) zs[r] = b[k0 + r];
-  for (int jj = 0; jj < nb; jj += 64) {
-    const int w = (nb - jj < 64) ? nb - jj : 64;
-    __syncthreads();
-    load_block64(L, ld, k0 + jj, w, Ls, tid, 256);
-    __syncthreads();
-    if (wave == 0) {
-      const double zi = tri_solve64_wave<false>(Ls, lane < w ? zs[jj + lane] : 0.0, lane);
-      if (lane < w) zs[jj + lane] = zi;
-    }
-    __syncthreads();
-    // rows of the panel below this block: zs[r] -= L[k0+r, k0+jj : k0+jj+w] . z_block
-    const double zl = lane < w ? zs[jj + lane] : 0.0;
-    for (int r = jj + w + wave; r < nb; r += 4) {
-      double v = lane < w ? L[(k0 + r) * ld + k0 + jj + lane] * zl : 0.0;
-      v = wave_sum(v);
-      if (lane == 0) zs[r] -= v;
-    }
-  }
-  __syncthreads();
-  for (int r = tid; r < nb; r += 256) z_out[k0 + r] = zs[r];
-}
-
-// Forward, rows below the panel: b[r] -= L[r, k0:k0+nb] . z[k0:k0+nb]  (one wave per row).
-__global__ void __launch_bounds__(256) trsv_update_fwd_kernel(const double* __restrict__ L, int64_t ld,
-                                                              int64_t n, int64_t k0, int nb,
-                                                              const double* __restrict__ z,
-                                                              double* __restrict__ b) {
-  __shared__ double zs[TSNB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int r = tid; r < nb; r += 256) zs[r] = z[k0 + r];
-  __syncthreads();
-  for (int64_t r = k0 + nb + (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
-    const double* row = L + r * ld + k0;
-    double v = 0.0;
-    for (int c = lane; c < nb; c += 64) v += row[c] * zs[c];
-    v = wave_sum(v);
-    if (lane == 0) b[r] -= v;
-  }
-}
-
-// Backward, diagonal part: solves L[k0:k0+nb, k0:k0+nb]^T x = z[k0:k0+nb] (one workgroup).
-__global__ void __launch_bounds__(256) trsv_panel_bwd_kernel(const double* __restrict__ L, int64_t ld,
-                                                             int64_t k0, int nb,
-                                                             const double* __restrict__ z,
-                                                             double* __restrict__ x_out) {
-  __shared__ __attribute__((aligned(16))) double Ls[64 * 65];
-  __shared__ double xs[TSNB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int r = tid; r < nb; r += 256) xs[r] = z[k0 + r];
-  const int last = ((nb - 1) / 64) * 64;
-  for (int jj = last; jj >= 0; jj -= 64) {
-    const int w = (nb - jj < 64) ? nb - jj : 64;
-    __syncthreads();
-    load_block64(L, ld, k0 + jj, w, Ls, tid, 256);
-    __syncthreads();
-    if (wave == 0) {
-      const double xi = tri_solve64_wave<true>(Ls, lane < w ? xs[jj + lane] : 0.0, lane);
-      if (lane < w) xs[jj + lane] = xi;
-    }
-    __syncthreads();
-    // columns of the panel left of this block: xs[c] -= sum_r L[k0+jj+r, k0+c] x[jj+r]
-    for (int c = tid; c < jj; c += 256) {
-      double s = 0.0;
-      for (int r = 0; r < w; ++r) s += L[(k0 + jj + r) * ld + k0 + c] * xs[jj + r];
-      xs[c] -= s;
-    }
-  }
-  __syncthreads();
-  for (int r = tid; r < nb; r += 256) x_out[k0 + r] = xs[r];
-}
-
-// Backward, columns left of the panel: z[c] -= sum_r L[k0+r, c] x[k0+r].  Thread (column c, wave w):
-// the four waves of a workgroup split the nb rows, partial sums are combined through LDS.
-__global__ void __launch_bounds__(256) trsv_update_bwd_kernel(const double* __restrict__ L, int64_t ld,
-                                                              int64_t k0, int nb,
-                                                              const double* __restrict__ x,
-                                                              double* __restrict__ z) {
-  __shared__ double xs[TSNB];
-  __shared__ double part[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int r = tid; r < nb; r += 256) xs[r] = x[k0 + r];
-  __syncthreads();
-  const int rows_per = (nb + 3) / 4;
-  const int r0 = wave * rows_per, r1 = (r0 + rows_per < nb) ? r0 + rows_per : nb;
-  for (int64_t cb = (int64_t)blockIdx.x * 64; cb < k0; cb += (int64_t)gridDim.x * 64) {
-    const int64_t c = cb + lane;
-    double s = 0.0;
-    if (c < k0) {
-#pragma unroll 8
-      for (int r = r0; r < r1; ++r) s += L[(k0 + r) * ld + c] * xs[r];
-    }
-    part[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && c < k0) z[c] -= part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-    __syncthreads();
-  }
-}
-
 // d_b: right-hand side (destroyed), d_z: scratch (n), d_x: solution (n).  All device vectors.
 int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_b,
                       double* d_z, double* d_x) {
-  hipStream_t st = ctx->stream;
-  for (int64_t k0 = 0; k0 < n; k0 += TSNB) {
-    const int nb = (int)((n - k0 < TSNB) ? n - k0 : TSNB);
-    hipLaunchKernelGGL(trsv_panel_fwd_kernel, dim3(1), dim3(256), 0, st, L, ld, k0, nb, d_b, d_z);
-    const int64_t rows = n - k0 - nb;
-    if (rows > 0) {
-      int grid = (int)((rows + 3) / 4);
-      if (grid > 2048) grid = 2048;
-      hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3(grid), dim3(256), 0, st, L, ld, n, k0, nb, d_z, d_b);
-    }
-    ctx->launch_counter += 2;
+  for (int64_t c0 = 0; c0 < n; c0 += 64) {
+    int w = (int)((n - c0 < 64) ? n - c0 : 64);
+    int64_t rows = n - c0 - w;
+    int grid = (int)((rows + 3) / 4);
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(trsv_fwd_kernel, dim3(grid), dim3(256), 0, ctx->stream, L, ld, n, c0, w, d_b,
+                       d_z);
+    ctx->launch_counter++;
   }
-  const int64_t last = ((n - 1) / TSNB) * TSNB;
-  for (int64_t k0 = last; k0 >= 0; k0 -= TSNB) {
-    const int nb = (int)((n - k0 < TSNB) ? n - k0 : TSNB);
-    hipLaunchKernelGGL(trsv_panel_bwd_kernel, dim3(1), dim3(256), 0, st, L, ld, k0, nb, d_z, d_x);
-    if (k0 > 0) {
-      int grid = (int)((k0 + 63) / 64);
-      if (grid > 2048) grid = 2048;
-      hipLaunchKernelGGL(trsv_update_bwd_kernel, dim3(grid), dim3(256), 0, st, L, ld, k0, nb, d_x, d_z);
-    }
-    ctx->launch_counter += 2;
+  int64_t last = ((n - 1) / 64) * 64;
+  for (int64_t c0 = last; c0 >= 0; c0 -= 64) {
+    int w = (int)((n - c0 < 64) ? n - c0 : 64);
+    int grid = (int)((c0 + 255) / 256);
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(trsv_bwd_kernel, dim3(grid), dim3(256), 0, ctx->stream, L, ld, c0, w, d_z,
+                       d_x);
+    ctx->launch_counter++;
   }
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;
