@@ -388,29 +388,27 @@ int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, in
 // Factor one panel: columns [k0, k0+nb), rows [k0, n), 64-wide sub-steps (potrf64 / trsm64 / K=64 gemm).
 static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0,
                         int64_t nb) {
-  if (nb <= 64) {
-    const int w = (int)nb;
-    double* Ad = A + k0 * ld + k0;
-    hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(64), 0, st, Ad, ld, w, k0, ctx->d_info);
+  for (int64_t jj = 0; jj < nb; jj += 64) {
+    const int64_t c0 = k0 + jj;
+    const int w = (int)((nb - jj < 64) ? nb - jj : 64);
+    double* Ad = A + c0 * ld + c0;
+    hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(64), 0, st, Ad, ld, w, c0, ctx->d_info);
     ctx->launch_counter++;
-    const int64_t m = n - k0 - w;
+    const int64_t m = n - c0 - w;
     if (m > 0) {
-      hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ad,
-                         A + (k0 + w) * ld + k0, ld, w, m);
+      double* X = A + (c0 + w) * ld + c0;
+      hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ad, X, ld,
+                         w, m);
       ctx->launch_counter++;
+      const int64_t ncols = k0 + nb - (c0 + w);
+      if (ncols > 0) {
+        // rest of the panel:  C[c0+w:n, c0+w:k0+nb] -= X[c0+w:n, :] X[c0+w:k0+nb, :]^T
+        GDML_TRY(launch_gemm_nt_sub(ctx, st, X, ld, X, ld, A + (c0 + w) * ld + (c0 + w), ld, m, ncols,
+                                    w, 0));
+      }
     }
-    return GDML_OK;
   }
-  // recursive halving (widths stay multiples of 64): the update between the halves is one GEMM with
-  // K = h instead of h/64 rank-64 updates, i.e. half of the in-panel flops run at K = nb/2, a
-  // quarter at K = nb/4, ... (a K=64 update is bound by the read-modify-write of C).
-  const int64_t h = ((nb / 2 + 63) / 64) * 64;
-  GDML_TRY(panel_factor(ctx, st, A, n, ld, k0, h));
-  const int64_t c1 = k0 + h, rest = nb - h;
-  // C[c1:n, c1:c1+rest] -= X[c1:n, k0:c1] X[c1:c1+rest, k0:c1]^T
-  const double* X = A + c1 * ld + k0;
-  GDML_TRY(launch_gemm_nt_sub(ctx, st, X, ld, X, ld, A + c1 * ld + c1, ld, n - c1, rest, h, 0));
-  return panel_factor(ctx, st, A, n, ld, c1, rest);
+  return GDML_OK;
 }
 
 // Right-looking blocked Cholesky with one panel of look-ahead: after panel k is factored, the
