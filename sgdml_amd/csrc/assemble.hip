@@ -646,11 +646,17 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
   // ---- (re)allocate the device matrix
   const int64_t tot_rows = n_rows_store + alloc_extra_rows;
   const int64_t ld = (n_cols + 15) / 16 * 16;  // rows start on 128-byte boundaries
-  if (ctx->K) {
+  // the buffer is reused when the size is unchanged (hyper-parameter sweeps, benchmark loops)
+  if (ctx->K && ctx->K_bytes != tot_rows * ld * 8) {
     GDML_TRY(ctx_free(ctx, ctx->K));
     ctx->K = nullptr;
+    ctx->precon = nullptr;
   }
-  GDML_TRY(ctx_alloc(ctx, (void**)&ctx->K, tot_rows * ld * 8));
+  if (!ctx->K) {
+    GDML_TRY(ctx_alloc(ctx, (void**)&ctx->K, tot_rows * ld * 8));
+    ctx->K_bytes = tot_rows * ld * 8;
+  }
+  ctx->precon = nullptr;  // a resident preconditioner lives in this buffer and is now overwritten
   ctx->K_rows = n_rows_store;
   ctx->K_rows_global = n_rows;
   ctx->K_sharded = sharded;

@@ -80,7 +80,7 @@ struct gdml_ctx {
 
   // kernel matrix / Cholesky factor
   double* K = nullptr;
-  int64_t K_rows = 0, K_cols = 0, K_extra = 0, K_ld = 0;
+  int64_t K_rows = 0, K_cols = 0, K_extra = 0, K_ld = 0, K_bytes = 0;
   bool K_factored = false;
   double K_lam = 0, K_sig = 0;
   int K_use_E = 0;
