@@ -150,6 +150,16 @@ int gdml_predict(gdml_ctx* ctx, const double* R, int64_t B, const double* lat,
 int gdml_predict_dev(gdml_ctx* ctx, const double* R_dev, int64_t B, const double* lat,
                      const double* lat_inv, double* E_dev, double* F_dev);
 
+/* Test / validation error sums evaluated on the device (replaces the body of the reference's
+ * cli.test loop, sgdml/cli.py:1564-1605 with _online_err :1170): predicts B host geometries R,
+ * scales with std and c like predict.py:1286-1288, compares with the labels and returns
+ *   sums8_out = { sum|dE|, sum dE^2, sum|dF|, sum dF^2, sum|d|F||, sum(d|F|)^2, sum a, sum a^2 },
+ * a = arccos(clip(cos(f_pred, f_ref)))/pi per atom.  E_ref may be NULL (sums 0, 1 are then 0).
+ * The caller divides by the sample sizes exactly as _online_err does. */
+int gdml_predict_errors(gdml_ctx* ctx, const double* R, int64_t B, const double* lat,
+                        const double* lat_inv, double std, double c, const double* E_ref,
+                        const double* F_ref, double* sums8_out);
+
 /* Kernel mat-vec  out = K v - lam v  through the prediction contraction (replaces
  * Iterative._K_vec, sgdml/solvers/iterative.py:183-204).  n = 3NM (+M with E constraints). */
 int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, const double* v, int64_t n,

@@ -40,6 +40,7 @@ SIGNATURES = {
     'gdml_predict': (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
     'gdml_predict_dev': (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
     'gdml_kernel_matvec': (C.c_int, [_vp, C.c_double, C.c_int, _vp, C.c_int64, _vp]),
+    'gdml_predict_errors': (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp]),
     'gdml_nystroem_factor': (C.c_int, [_vp, C.c_double, _vp, C.c_int64, _vp, _vp, C.POINTER(C.c_int)]),
     'gdml_precon_apply': (C.c_int, [_vp, C.c_double, _vp, C.c_int64, _vp]),
     'gdml_pcg': (C.c_int, [_vp, C.c_double, C.c_int, _vp, _vp, C.c_int64, C.c_double, C.c_int64, C.c_int,
@@ -290,6 +291,20 @@ class Context(object):
             lat, lat_inv = f64(lat_and_inv[0]), f64(lat_and_inv[1])
         self._check(self._lib.gdml_predict(self._h, _ptr(R), B, _ptr(lat), _ptr(lat_inv), _ptr(E), _ptr(F)))
         return E, F
+
+    def predict_errors(self, R, F_ref, E_ref=None, std=1.0, c=0.0, lat_and_inv=None):
+        """Eight error sums of a labelled batch, evaluated on the GPU (see gdml_predict_errors)."""
+        n_atoms = self.model_n_atoms
+        R = f64(R).reshape(-1, 3 * n_atoms)
+        F_ref = f64(F_ref).reshape(R.shape[0], 3 * n_atoms)
+        E_ref = None if E_ref is None else f64(E_ref).ravel()
+        lat = lat_inv = None
+        if lat_and_inv is not None:
+            lat, lat_inv = f64(lat_and_inv[0]), f64(lat_and_inv[1])
+        out = np.empty(8)
+        self._check(self._lib.gdml_predict_errors(self._h, _ptr(R), R.shape[0], _ptr(lat), _ptr(lat_inv), float(std),
+                                                  float(c), _ptr(E_ref), _ptr(F_ref), _ptr(out)))
+        return out
 
     def kernel_matvec(self, lam, use_E_cstr, v):
         v = f64(v).ravel()

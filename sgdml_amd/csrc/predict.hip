@@ -603,6 +603,105 @@ extern "C" int gdml_predict_dev(gdml_ctx* ctx, const double* R_dev, int64_t B, c
   return predict_common(ctx, R_dev, true, B, lat, lat_inv, E_dev, F_dev, true);
 }
 
+// ------------------------------------------------------------------------------------------
+// Test / validation error sums on the device (the reference's cli.test loop, sgdml/cli.py:1564-1605,
+// _online_err :1170): predictions stay in HBM, only eight sums come back.
+//   sums[0..1] = sum |dE|, sum dE^2                (0 if E_ref is NULL)
+//   sums[2..3] = sum |dF|, sum dF^2                over all 3N B force components
+//   sums[4..5] = sum |d|F||, sum (d|F|)^2          per-atom force magnitudes
+//   sums[6..7] = sum a, sum a^2, a = arccos(clip(f_pred.f_ref/(|f_pred||f_ref|)))/pi per atom
+// One thread per (geometry, atom); per-block partials are reduced in a fixed order.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) err_part_kernel(const double* __restrict__ E, const double* __restrict__ F,
+                                                       const double* __restrict__ E_ref,
+                                                       const double* __restrict__ F_ref, int64_t B, int N,
+                                                       double std, double c, double* __restrict__ part) {
+  __shared__ double red[8][4];
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (t < B * N) {
+    const int64_t q = t / N;
+    const int a = (int)(t - q * N);
+    const double* fp = F + (q * N + a) * 3;
+    const double* fr = F_ref + (q * N + a) * 3;
+    double p0 = fp[0] * std, p1 = fp[1] * std, p2 = fp[2] * std;
+    double d0 = fr[0] - p0, d1 = fr[1] - p1, d2 = fr[2] - p2;
+    v[2] = fabs(d0) + fabs(d1) + fabs(d2);
+    v[3] = d0 * d0 + d1 * d1 + d2 * d2;
+    const double mp = sqrt(p0 * p0 + p1 * p1 + p2 * p2), mr = sqrt(fr[0] * fr[0] + fr[1] * fr[1] + fr[2] * fr[2]);
+    const double dm = mp - mr;
+    v[4] = fabs(dm);
+    v[5] = dm * dm;
+    double cs = (p0 * fr[0] + p1 * fr[1] + p2 * fr[2]) / (mp * mr);
+    cs = fmin(1.0, fmax(-1.0, cs));
+    const double ang = acos(cs) * 0.31830988618379067154;  // / pi
+    v[6] = ang;  // >= 0
+    v[7] = ang * ang;
+    if (a == 0 && E_ref != nullptr) {
+      const double de = E_ref[q] - (E[q] * std + c);
+      v[0] = fabs(de);
+      v[1] = de * de;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const double s = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int k = threadIdx.x;
+    part[(int64_t)blockIdx.x * 8 + k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+  }
+}
+__global__ void __launch_bounds__(64) err_reduce_kernel(const double* __restrict__ part, int64_t nblocks,
+                                                        double* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= 8) return;
+  double s = 0.0;
+  for (int64_t b = 0; b < nblocks; ++b) s += part[b * 8 + k];
+  out[k] = s;
+}
+
+extern "C" int gdml_predict_errors(gdml_ctx* ctx, const double* R, int64_t B, const double* lat,
+                                   const double* lat_inv, double std, double c, const double* E_ref,
+                                   const double* F_ref, double* sums8_out) {
+  if (!ctx) return GDML_ERR_INVALID;
+  if (!R || !F_ref || !sums8_out || B < 1)
+    return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_predict_errors: bad arguments");
+  Model& md = ctx->model;
+  if (!md.xp) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_predict_errors: upload a model first");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int N = md.N;
+  const int64_t nF = B * 3 * N;
+  const int64_t nblocks = (B * N + 255) / 256;
+  void* buf = nullptr;
+  GDML_TRY(ctx_alloc(ctx, &buf, (3 * nF + 2 * B + nblocks * 8 + 8) * 8));
+  double* dR = (double*)buf;
+  double* dFref = dR + nF;
+  double* dF = dFref + nF;
+  double* dEref = dF + nF;
+  double* dE = dEref + B;
+  double* dpart = dE + B;
+  double* dout = dpart + nblocks * 8;
+  int rc = GDML_OK;
+  hipError_t e = hipMemcpyAsync(dR, R, nF * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dFref, F_ref, nF * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && E_ref) e = hipMemcpyAsync(dEref, E_ref, B * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+  if (rc == GDML_OK) rc = predict_common(ctx, dR, true, B, lat, lat_inv, dE, dF, true);
+  if (rc == GDML_OK) {
+    hipLaunchKernelGGL(err_part_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, dE, dF,
+                       E_ref ? dEref : nullptr, dFref, B, N, std, c, dpart);
+    hipLaunchKernelGGL(err_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, dpart, nblocks, dout);
+    e = hipMemcpyAsync(sums8_out, dout, 64, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "errors: %s", hipGetErrorString(e));
+  }
+  int rc2 = ctx_free(ctx, buf);
+  return rc != GDML_OK ? rc : rc2;
+}
+
 // out = K v - lam v  via set_alphas + training-set prediction (iterative.py:183-204).
 // d_v, d_out device vectors of length n = 3NM (+M).  Uses ctx->model built on the training set.
 __global__ void __launch_bounds__(256) matvec_finish_kernel(const double* __restrict__ F,

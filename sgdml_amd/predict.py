@@ -122,6 +122,27 @@ class GDMLPredict(object):
     def get_GPU_batch(self):
         return self.n_train
 
+    # ---- test / validation errors on the device (the loop body of sgdml/cli.py:1564-1605)
+
+    def test_errors(self, R, F, E=None):
+        """MAE / RMSE of energies, force components, force magnitudes and normalised force angles
+        for labelled geometries, with the reference's definitions (cli.py:_online_err :1170).
+        Predictions never leave the GPU.  Returns a dict of (mae, rmse) pairs."""
+        R = np.asarray(R, dtype=np.float64)
+        if R.ndim == 1:
+            R = R[None, :]
+        B = R.shape[0]
+        s = self._ctx.predict_errors(R.reshape(B, -1), F, E, std=self.std, c=self.c, lat_and_inv=self.lat_and_inv)
+        n_f, n_a = B * 3 * self.n_atoms, B * self.n_atoms
+        out = {
+            'force': (s[2] / n_f, np.sqrt(s[3] / n_f)),
+            'magnitude': (s[4] / n_a, np.sqrt(s[5] / n_a)),
+            'angle': (s[6] / n_a, np.sqrt(s[7] / n_a)),
+        }
+        if E is not None:
+            out['energy'] = (s[0] / B, np.sqrt(s[1] / B))
+        return out
+
     # ---- prediction
 
     def predict(self, R=None, return_E=True):

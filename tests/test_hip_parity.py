@@ -435,3 +435,38 @@ def test_K_global_table_path_with_perms(golden, ctx, monkeypatch):
     ctx.train_upload(g['R_desc'], g['R_d_desc'], _tril_perms(g))
     K = ctx.assemble_K(float(g['sig']), bool(g['use_E_cstr']), to_host=True)
     assert np.abs(K - g['K']).max() <= 1e-12 * np.abs(g['K']).max()
+
+
+def test_device_error_sums_match_reference_definitions(golden):
+    """gdml_predict_errors vs the reference's _online_err recipe (cli.py:1170, :1572-1605) evaluated
+    with NumPy on the reference's own predictions."""
+    from sgdml_amd.predict import GDMLPredict
+
+    g = golden
+    N = g['R_train'].shape[1]
+    m = _model(g)
+    model = {'type': 'm', 'z': np.ones(N, dtype=int), 'R_desc': m['R_desc'], 'R_d_desc_alpha': m['R_d_desc_alpha'],
+             'sig': float(g['sig']), 'c': m['c'], 'std': m['std'], 'perms': g['perms'],
+             'tril_perms_lin': g['tril_perms_lin']}
+    if 'alphas_E' in m:
+        model['alphas_E'] = m['alphas_E']
+    if 'lattice' in g:
+        model['lattice'] = g['lattice']
+    rs = np.random.RandomState(3)
+    B = len(g['R_test'])
+    F_ref = g['F_test'] + 0.05 * rs.normal(size=g['F_test'].shape)
+    E_ref = g['E_test'] + 0.1 * rs.normal(size=B)
+    pred = GDMLPredict(model)
+    got = pred.test_errors(g['R_test'].reshape(B, -1), F_ref, E_ref)
+    f_pred, e_pred = g['F_test'], g['E_test']
+    err = np.abs(F_ref - f_pred)
+    fl = cancel_floor(g)
+    tol = 1e-9 + 10 * fl
+    assert abs(got['force'][0] - err.mean()) <= tol and abs(got['force'][1] - np.sqrt((err**2).mean())) <= tol
+    e = np.abs(E_ref - e_pred)
+    assert abs(got['energy'][0] - e.mean()) <= tol * float(g['sig']) and abs(got['energy'][1] - np.sqrt((e**2).mean())) <= tol * float(g['sig'])
+    mp = np.linalg.norm(f_pred.reshape(-1, 3), axis=1)
+    mr = np.linalg.norm(F_ref.reshape(-1, 3), axis=1)
+    assert abs(got['magnitude'][0] - np.abs(mp - mr).mean()) <= tol
+    cos = np.arccos(np.clip(np.einsum('ij,ij->i', f_pred.reshape(-1, 3) / mp[:, None], F_ref.reshape(-1, 3) / mr[:, None]), -1, 1)) / np.pi
+    assert abs(got['angle'][0] - cos.mean()) <= 1e-7 + 100 * fl and abs(got['angle'][1] - np.sqrt((cos**2).mean())) <= 1e-7 + 100 * fl
