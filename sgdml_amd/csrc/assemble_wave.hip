@@ -166,141 +166,6 @@ __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// General-permutation variant (any P, any atom permutations, 3N <= 64).  Same lane = column
-// mapping, accumulators for the 3N rows stay in registers across the permutation loop.  What changes
-// with a permutation pi_p (a' = pi_p^-1(b)):
-//   u_p[c]      = sum_m (x_i[pair(a',m)] - x_j[pair(b,pi m)]) G_j(b,pi m)[be]
-//   v_p[(b,be)] = sum_m (x_i[pair(b,m)]  - x_j[pair(pi b,pi m)]) G_i(b,m)[be]
-//   K[(a,al),c] += 5 b_p v_p[(a,al)] u_p[c] + c_p G_i(a',a)[al] G_j(b,pi a)[be]      (a != a')
-//                                            - c_p sum_m G_i(a',m)[al] G_j(b,pi m)[be] (a == a')
-// The row point's data of atom a' (which differs per lane and per permutation) is gathered from a
-// dense copy of G_i / x_i in LDS; the column point's permuted rows are gathered straight from the
-// global dense tables (row pi(m) of the m-major layout is contiguous across lanes).
-// ------------------------------------------------------------------------------------------
-struct WavePermArgs {
-  const double* XF;
-  const double* GD;
-  const int32_t* perm;  // (P,N)
-  const int32_t* pinv;  // (P,N)
-  int64_t M;
-  int N, P;
-  double sig;
-  int use_E;
-  const int32_t* jlist;
-  const int32_t* colmap;
-  int64_t j0, n_j, i_beg;
-  int j_chunk;
-  double* K;
-  int64_t ld;
-};
-
-template <int N>
-__global__ void __launch_bounds__(64) assemble_wave_perm_kernel(WavePermArgs A) {
-  constexpr int N3 = 3 * N, NN = N * N;
-  __shared__ double vsh[64];
-  __shared__ double GiL[NN * 3];  // [m][a][al] = G_i(a,m)[al]
-  __shared__ double XiL[NN];      // [m][a]     = x_i[pair(a,m)]
-  const int lane = threadIdx.x;
-  const bool act = lane < N3;
-  const int c = act ? lane : 0;
-  const int b = c / 3, beta = c - 3 * b;
-  const int64_t i = A.i_beg + blockIdx.x;
-  const int64_t jb_beg = (int64_t)blockIdx.y * A.j_chunk;
-  const int64_t jb_end = (jb_beg + A.j_chunk < A.n_j) ? jb_beg + A.j_chunk : A.n_j;
-  if (jb_beg >= jb_end) return;
-  const int P = A.P;
-
-  const double sig = A.sig, inv_sig = 1.0 / sig;
-  const double sqrt5 = 2.23606797749978969641;
-  const double base_div = 5.0 / (3.0 * sig * sig * sig * sig);
-  const double e_fact = 5.0 / (3.0 * sig * sig * sig);
-
-  // resident row point: dense copies of G_i and x_i in LDS (own-atom rows and the a' gathers both
-  // read from there: the accumulators need the registers)
-  {
-    const double* gd = A.GD + i * (int64_t)NN * 3;
-    const double* xf = A.XF + i * (int64_t)NN;
-    for (int e = lane; e < NN * 3; e += 64) GiL[e] = gd[e];
-    for (int e = lane; e < NN; e += 64) XiL[e] = xf[e];
-  }
-  __syncthreads();
-  const double* RiL = GiL + 3 * b + beta;  // G_i(b,m)[be] at RiL[m * N3]
-  const double* XiO = XiL + b;             // x_i[pair(b,m)] at XiO[m * N]
-
-  for (int64_t jb = jb_beg; jb < jb_end; ++jb) {
-    const int64_t j = A.jlist ? A.jlist[jb] : A.j0 + jb;
-    const double* gdj = A.GD + j * (int64_t)NN * 3 + c;
-    const double* xfj = A.XF + j * (int64_t)NN;
-    double acc[N][3];
-#pragma unroll
-    for (int a = 0; a < N; ++a) acc[a][0] = acc[a][1] = acc[a][2] = 0.0;
-    double erow = 0.0;
-    for (int p = 0; p < P; ++p) {
-      const int32_t* perm = A.perm + (size_t)p * N;
-      const int ap = A.pinv[(size_t)p * N + b];
-      const int pb = perm[b];
-      double rj[N];
-      double ss = 0.0, u = 0.0, v = 0.0;
-#pragma unroll
-      for (int m = 0; m < N; ++m) {
-        const int pm = perm[m];  // wave-uniform
-        rj[m] = gdj[pm * N3];                                  // G_j(b, pi m)[be]
-        const double du = XiL[m * N + ap] - xfj[pm * N + b];   // x_i[pair(a',m)] - x_j[pair(b,pi m)]
-        const double dvv = XiO[m * N] - xfj[pm * N + pb];      // x_i[pair(b,m)]  - x_j[pair(pi b,pi m)]
-        ss += dvv * dvv;
-        u += du * rj[m];
-        v += dvv * RiL[m * N3];
-        if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (register pressure)
-      }
-      const double nrm2 = wave_sum(act ? ss : 0.0) * (1.0 / 6.0);
-      const double nrm = sqrt5 * sqrt(nrm2);
-      const double ex = exp(-nrm * inv_sig);
-      const double bp = ex * base_div;
-      const double cp = (sig * sig + sig * nrm) * bp;
-      const double uc = 5.0 * bp * u;
-      __builtin_amdgcn_wave_barrier();
-      vsh[lane] = v;
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-      __builtin_amdgcn_wave_barrier();
-      // diagonal 3x3 block of this column: dg[al] = sum_m G_i(a',m)[al] G_j(b,pi m)[be]
-      double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-#pragma unroll
-      for (int m = 0; m < N; ++m) {
-        const double* gi = GiL + (m * N + ap) * 3;
-        g0 += gi[0] * rj[m];
-        g1 += gi[1] * rj[m];
-        g2 += gi[2] * rj[m];
-        if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int a = 0; a < N; ++a) {
-        const double* gi = GiL + (a * N + ap) * 3;  // G_i(a',a)[.] (zero for a == a')
-        const double w = cp * rj[a];
-        const bool diag = (a == ap);
-        acc[a][0] += vsh[3 * a + 0] * uc + (diag ? -cp * g0 : gi[0] * w);
-        acc[a][1] += vsh[3 * a + 1] * uc + (diag ? -cp * g1 : gi[1] * w);
-        acc[a][2] += vsh[3 * a + 2] * uc + (diag ? -cp * g2 : gi[2] * w);
-        if ((a & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-      if (A.use_E) erow -= e_fact * (nrm + sig) * ex * u;  // train.py:235-248
-      __builtin_amdgcn_wave_barrier();
-    }
-    const int64_t outcol = A.colmap ? (int64_t)A.colmap[jb * N3 + c] : jb * N3 + c;
-    if (act && outcol >= 0) {
-      double* dst = A.K + ((i - A.i_beg) * N3) * A.ld + outcol;
-#pragma unroll
-      for (int a = 0; a < N; ++a) {
-        dst[0] = acc[a][0];
-        dst[A.ld] = acc[a][1];
-        dst[2 * A.ld] = acc[a][2];
-        dst += 3 * A.ld;
-      }
-      if (A.use_E) A.K[(A.M * N3 + i) * A.ld + outcol] = erow;
-    }
-  }
-}
-
 // Build (or rebuild) the dense tables for the resident training set.
 int build_dense_tables(gdml_ctx* ctx) {
   TrainSet& ts = ctx->ts;
@@ -315,18 +180,12 @@ int build_dense_tables(gdml_ctx* ctx) {
   return GDML_OK;
 }
 
-static bool wave_identity_only(const TrainSet& ts) {
-  if (ts.P != 1) return false;
-  for (int a = 0; a < ts.N; ++a)
-    if (ts.h_perm[a] != a) return false;
-  return true;
-}
-
 bool assemble_wave_applicable(const gdml_ctx* ctx) {
   const TrainSet& ts = ctx->ts;
   if (getenv("GDML_ASM_NO_WAVE")) return false;
-  if (ts.N > 21 || ts.N < 2) return false;
-  if (!wave_identity_only(ts) && getenv("GDML_ASM_NO_WAVE_PERM")) return false;
+  if (ts.P != 1 || ts.N > 21 || ts.N < 2) return false;
+  for (int a = 0; a < ts.N; ++a)
+    if (ts.h_perm[a] != a) return false;
   return true;
 }
 
@@ -350,23 +209,6 @@ int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   A.j_chunk = j_chunk;
   dim3 grid((unsigned)n_i, (unsigned)((n_j + j_chunk - 1) / j_chunk));
   const int slot = ktime_begin(ctx);
-  if (!wave_identity_only(ts)) {
-    WavePermArgs Q;
-    Q.XF = ts.XF; Q.GD = ts.GD; Q.perm = ts.perm; Q.pinv = ts.pinv; Q.M = ts.M; Q.N = ts.N; Q.P = ts.P;
-    Q.sig = sig; Q.use_E = use_E; Q.jlist = d_jlist; Q.colmap = d_colmap; Q.j0 = j0; Q.n_j = n_j;
-    Q.i_beg = i_beg; Q.j_chunk = j_chunk; Q.K = K; Q.ld = ld;
-    switch (ts.N) {
-#define WP(v) case v: hipLaunchKernelGGL(assemble_wave_perm_kernel<v>, grid, dim3(64), 0, ctx->stream, Q); break;
-      WP(2) WP(3) WP(4) WP(5) WP(6) WP(7) WP(8) WP(9) WP(10) WP(11) WP(12) WP(13) WP(14) WP(15) WP(16)
-      WP(17) WP(18) WP(19) WP(20) WP(21)
-#undef WP
-      default: return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_wave: N out of range");
-    }
-    ktime_end(ctx, slot, "assemble", 8.0 * (double)n_i * 3.0 * ts.N * (double)n_j * 3.0 * ts.N);
-    ctx->launch_counter++;
-    HIP_CHECK(ctx, hipGetLastError());
-    return GDML_OK;
-  }
   switch (ts.N) {
 #define WC(v) case v: hipLaunchKernelGGL(assemble_wave_kernel<v>, grid, dim3(64), 0, ctx->stream, A); break;
     WC(2) WC(3) WC(4) WC(5) WC(6) WC(7) WC(8) WC(9) WC(10) WC(11) WC(12) WC(13) WC(14) WC(15) WC(16)
