@@ -61,6 +61,7 @@ struct Model {
 
 struct gdml_ctx {
   int device = 0;
+  int num_cus = 256;  // compute units of the device (grid sizing)
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -92,8 +93,8 @@ struct gdml_ctx {
   // scratch
   double* scratch = nullptr;
   int64_t scratch_bytes = 0;
-  double* slot[4] = {nullptr, nullptr, nullptr, nullptr};  // cached work buffers (ctx_slot)
-  int64_t slot_bytes[4] = {0, 0, 0, 0};
+  double* slot[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // cached work buffers (ctx_slot)
+  int64_t slot_bytes[6] = {0, 0, 0, 0, 0, 0};
   int* d_info = nullptr;
 
   // comm

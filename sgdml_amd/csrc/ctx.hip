@@ -71,6 +71,11 @@ extern "C" int gdml_ctx_create(int device, gdml_ctx** ctx_out) {
       return hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi);
     return hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
   };
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
+      ctx->num_cus = ncu;
+  }
   if ((e = hipSetDevice(device)) != hipSuccess || (e = make_streams()) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev0)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||

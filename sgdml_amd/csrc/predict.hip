@@ -317,6 +317,277 @@ __global__ void __launch_bounds__(256, 2) predict_bulk_kernel(PredArgs A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA variant of the bulk kernel (B >= 256, D <= 256): the contractions over k and the accumulation
+// over the table rows are GEMM-shaped, so they go to v_mfma_f64_16x16x4_f64 (same peak as the fp64
+// VALU on MI355X, but one instruction carries 2048 flops and needs no per-FMA operand traffic).
+// Per workgroup: 64 queries (16 per wavefront) against one split of the table rows, 16 rows at a time:
+//   phase 1 (transposed):  P1^T = X x^T,  P2^T = JA x^T   (K = D; X/JA tile from LDS, x in registers)
+//            |d|^2 = |x|^2 + |X_r|^2 - 2 P1 (clamped at 0),  a = P2 - X_r.JA_r   (row terms precomputed)
+//            -- every Matern quantity that multiplies O(1) data is second order in n at n = 0, so the
+//            cancellation in |d|^2 for coincident points (training-set mode) is harmless;
+//   scalars: w1, b2 for the lane's 4 (row, query) pairs.  The C/D layout of the transposed product
+//            (row = l>>4 + 4 i, query = l&15) IS the A-operand layout of phase 2, so the weights go
+//            from one MFMA to the next without leaving the lane;
+//   phase 2: F_x -= [w1 | b2] [X ; JA]   (K = 32 per row tile), the 16 x D accumulators of the wave
+//            stay in registers for the whole split;  F_x += x * sum_r w1 at the end.
+// The X/JA row tiles (16 x D each) are double-buffered in LDS: the next tile is fetched into registers
+// while the current one is being used, one barrier per tile.  One workgroup per CU (the accumulators,
+// the query operand and the prefetch registers need more than 256 VGPRs).
+// ------------------------------------------------------------------------------------------
+typedef double d4p __attribute__((ext_vector_type(4)));
+
+// nX[r] = |X_r|^2, cX[r] = X_r . JA_r  (one wavefront per table row)
+__global__ void __launch_bounds__(256) row_stats_kernel(const double* __restrict__ xp,
+                                                        const double* __restrict__ jap, int64_t MP, int D,
+                                                        double* __restrict__ nX, double* __restrict__ cX) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= MP) return;
+  double s = 0.0, c = 0.0;
+  for (int k = lane; k < D; k += 64) {
+    const double x = xp[r * D + k];
+    s += x * x;
+    c += x * jap[r * D + k];
+  }
+  s = wave_sum(s);
+  c = wave_sum(c);
+  if (lane == 0) {
+    nX[r] = s;
+    cX[r] = c;
+  }
+}
+
+#ifndef PMF_ABL
+#define PMF_ABL 0
+#endif
+#define MQ 64  // queries per workgroup
+#define MR 16  // table rows per tile
+
+template <int NT>  // NT = number of 16-column tiles covering D
+__global__ void __launch_bounds__(256, 1) predict_mfma_kernel(PredArgs A, const double* __restrict__ nX,
+                                                             const double* __restrict__ cX) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 x (X tile | JA tile), each MR x P
+  constexpr int P = 16 * NT + 2;  // pitch: conflict-free for the phase-1 operand pattern
+  constexpr int KS = 4 * NT;      // k-steps of 4
+  constexpr int TILE = MR * P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int D = A.D;
+  const int64_t q0w = (int64_t)blockIdx.x * MQ + 16 * wave;
+  const int64_t myq = q0w + li;
+  const int split = blockIdx.y;
+  const int64_t r_beg = (int64_t)split * A.rows_per_split;
+  const int64_t r_end = (r_beg + A.rows_per_split < A.MP) ? r_beg + A.rows_per_split : A.MP;
+  const double sig = A.sig, inv_sig = 1.0 / sig;
+  const double sqrt5 = 2.23606797749978969641;
+  const double fact = 5.0 / (3.0 * sig * sig * sig);
+  const double dscale = 5.0 / sig;
+  const double inv_3sig = 1.0 / (3.0 * sig);
+  const bool has_aE = A.aE != nullptr;
+
+  for (int i = tid; i < 4 * TILE; i += 256) lds[i] = 0.0;  // pad columns must be finite (x is 0 there)
+
+  // query operand: lane (li, lk) holds x[q = li][4 ks + lk]  (B operand of phase 1)
+  double xA[KS];
+  double nx = 0.0;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k = 4 * ks + lk;
+    const double v = (myq < A.B && k < D) ? A.xq[myq * D + k] : 0.0;
+    xA[ks] = v;
+    nx += v * v;
+  }
+  nx += __shfl_xor(nx, 16, 64);
+  nx += __shfl_xor(nx, 32, 64);
+
+  d4p acc2[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc2[t] = (d4p){0.0, 0.0, 0.0, 0.0};
+  double w1s = 0.0, es = 0.0;
+
+  // staging: a row tile is one contiguous, 16-byte aligned block of MR * D doubles (MR and the split
+  // starts are even); thread handles the double2 elements tid + 256 s
+  typedef double d2p __attribute__((ext_vector_type(2)));
+  constexpr int NS2 = NT / 2;  // 8 D / 256 <= NT / 2 double2 per thread
+  const int nelem2 = MR * D / 2;
+  d2p px[NS2], pj[NS2];
+  auto issue = [&](int64_t r0) {
+    const int64_t lim2 = (r_end - r0) * D / 2;  // double2 elements of this tile that exist (tail: even rows)
+    const d2p* gx = reinterpret_cast<const d2p*>(A.xp + r0 * D);
+    const d2p* gj = reinterpret_cast<const d2p*>(A.jap + r0 * D);
+#pragma unroll
+    for (int s = 0; s < NS2; ++s) {
+      const int idx = tid + 256 * s;
+      const bool ok = idx < nelem2 && idx < lim2;
+      const int idc = ok ? idx : 0;  // unconditional load from a valid address, then select
+      const d2p vx = gx[idc], vj = gj[idc];
+      px[s] = ok ? vx : (d2p){0.0, 0.0};
+      pj[s] = ok ? vj : (d2p){0.0, 0.0};
+    }
+  };
+  auto commit = [&](int buf) {
+    double* Xd = lds + buf * 2 * TILE;
+    int e0 = 2 * tid;  // element index inside the tile
+    asm volatile("" : "+v"(e0));  // keep the address arithmetic inside the loop (cheaper than spilling it)
+    int row = e0 / D, k = e0 - row * D;
+    const int drow = 512 / D, dk = 512 - drow * D;
+#pragma unroll
+    for (int s = 0; s < NS2; ++s) {
+      if (tid + 256 * s < nelem2) {
+        const int o0 = row * P + k;
+        const int o1 = (k + 1 < D) ? o0 + 1 : o0 + 1 + (P - D);  // second element may start the next row
+        Xd[o0] = px[s][0];
+        Xd[o1] = px[s][1];
+        Xd[TILE + o0] = pj[s][0];
+        Xd[TILE + o1] = pj[s][1];
+      }
+      row += drow;
+      k += dk;
+      if (k >= D) {
+        k -= D;
+        row += 1;
+      }
+    }
+  };
+  __syncthreads();
+  issue(r_beg);
+  commit(0);
+  __syncthreads();
+
+  int cur = 0;
+  for (int64_t r0 = r_beg; r0 < r_end; r0 += MR) {
+    const bool has_next = r0 + MR < r_end;
+#if PMF_ABL != 4
+    if (has_next) issue(r0 + MR);
+#endif
+    // row terms of the lane's 4 pairs (row = r0 + lk + 4 rr)
+    double nXr[4], cXr[4], aer[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int64_t r = r0 + lk + 4 * rr;
+      const bool rok = r < r_end;
+      nXr[rr] = rok ? nX[r] : 0.0;
+      cXr[rr] = rok ? cX[r] : 0.0;
+      aer[rr] = (rok && has_aE) ? A.aE[r] : 0.0;
+    }
+    const double* Xs = lds + cur * 2 * TILE;
+    const double* Js = Xs + TILE;
+    // ---------------- phase 1: P^T[row][query]
+    d4p p1 = (d4p){0.0, 0.0, 0.0, 0.0}, p2 = (d4p){0.0, 0.0, 0.0, 0.0};
+    {
+      const double* xa = Xs + li * P + lk;
+      const double* ja = Js + li * P + lk;
+      constexpr int KSE = (PMF_ABL == 3 ? 4 : KS);  // ablation 3: 4 k-steps only
+      constexpr int NG = KSE / 4;                   // groups of 4 k-steps, operands read one group ahead
+      double oa[2][4], oj[2][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        oa[0][u] = xa[4 * u];
+        oj[0][u] = ja[4 * u];
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            oa[(g + 1) & 1][u] = xa[16 * (g + 1) + 4 * u];
+            oj[(g + 1) & 1][u] = ja[16 * (g + 1) + 4 * u];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[g & 1][u], xA[4 * g + u], p1, 0, 0, 0);
+          p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(oj[g & 1][u], xA[4 * g + u], p2, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---------------- Matern scalars for (row = r0 + lk + 4 rr, query = li)
+    double w1[4], b2[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const bool rok = r0 + lk + 4 * rr < r_end;
+      double s2 = nx + nXr[rr] - 2.0 * p1[rr];
+      s2 = s2 > 0.0 ? s2 : 0.0;
+      const double sa = p2[rr] - cXr[rr];
+#if PMF_ABL == 1  // ablation: no sqrt / exp
+      const double nrm = sqrt5 * s2;
+      const double ex = 1.0 - nrm * inv_sig;
+#else
+      const double nrm = sqrt5 * sqrt(s2);
+      const double ex = exp(-nrm * inv_sig);
+#endif
+      const double b = fact * ex;
+      double b2v = b * (nrm + sig);
+      double w1v = dscale * sa * b;
+      double e = sa * b2v;
+      if (has_aE) {
+        w1v += aer[rr] * b2v;
+        e += aer[rr] * (1.0 + (nrm * inv_sig) * (1.0 + nrm * inv_3sig)) * ex;
+      }
+      w1[rr] = rok ? w1v : 0.0;
+      b2[rr] = rok ? b2v : 0.0;
+      w1s += w1[rr];
+      es += rok ? e : 0.0;
+    }
+    // ---------------- phase 2: acc2[query][k] += [w1 | b2] [X ; JA]
+    {
+      constexpr int NTE = (PMF_ABL == 2 ? 1 : NT);  // ablation 2: one column tile only
+      const double* xb = Xs + lk * P + li;
+      const double* jb = Js + lk * P + li;
+      double ox[2][4], oz[2][4];  // operands of one column tile, read one tile ahead
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ox[0][u] = xb[4 * u * P];
+        oz[0][u] = jb[4 * u * P];
+      }
+#pragma unroll
+      for (int t = 0; t < NTE; ++t) {
+        if (t + 1 < NTE) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            ox[(t + 1) & 1][u] = xb[4 * u * P + 16 * (t + 1)];
+            oz[(t + 1) & 1][u] = jb[4 * u * P + 16 * (t + 1)];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1[u], ox[t & 1][u], acc2[t], 0, 0, 0);
+          acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2[u], oz[t & 1][u], acc2[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#if PMF_ABL != 4  // ablation 4: no tile refresh (no global loads, LDS writes)
+    if (has_next) commit(cur ^ 1);
+#endif
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- per-query totals live in lanes by li; the accumulators hold query lk + 4 rr
+  w1s += __shfl_xor(w1s, 16, 64);
+  w1s += __shfl_xor(w1s, 32, 64);
+  es += __shfl_xor(es, 16, 64);
+  es += __shfl_xor(es, 32, 64);
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int qsrc = lk + 4 * rr;
+    const double wt = __shfl(w1s, qsrc, 64);
+    const int64_t qi = q0w + qsrc;
+    if (qi < A.B) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int k = 16 * t + li;
+        if (k < D) A.part_F[((int64_t)split * A.B + qi) * D + k] = A.xq[qi * D + k] * wt - acc2[t][rr];
+      }
+    }
+  }
+  if (lk == 0 && myq < A.B) A.part_E[(int64_t)split * A.B + myq] = es;
+}
+
 // One workgroup per query: sum the split partials in order, then F = J_x^T F_x.
 __global__ void __launch_bounds__(256) predict_epilogue_kernel(const double* __restrict__ part_F,
                                                                const double* __restrict__ part_E,
@@ -383,14 +654,32 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   while (KPL * 64 < D) KPL <<= 1;
   if (KPL > 32) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "predict kernel supports D <= 2048");
   const bool bulk = (B >= 256) && (D <= 256) && getenv("GDML_PREDICT_V1") == nullptr;
+  const bool mfma = bulk && getenv("GDML_PREDICT_NO_MFMA") == nullptr;
   int QB = max_qb_for(KPL);
   while (QB > 1 && (B + QB - 1) / QB < 512 && QB > B) QB >>= 1;  // do not waste query slots
   while (QB > 1 && B < QB) QB >>= 1;
-  int64_t n_qt = bulk ? (B + PQ - 1) / PQ : (B + QB - 1) / QB;
-  int64_t JS = ((bulk ? 2048 : 4096) + n_qt - 1) / n_qt;
+  int64_t n_qt = mfma ? (B + MQ - 1) / MQ : bulk ? (B + PQ - 1) / PQ : (B + QB - 1) / QB;
+  int64_t JS = ((mfma ? 512 : bulk ? 2048 : 4096) + n_qt - 1) / n_qt;
   int64_t max_js = bulk ? (MP / 64 > 1 ? MP / 64 : 1) : (MP / 16 > 1 ? MP / 16 : 1);
   if (JS > max_js) JS = max_js;
   if (JS < 1) JS = 1;
+  if (mfma) {
+    // one workgroup per CU: pick the split count that minimises (rounds of workgroups) x (row tiles per
+    // workgroup + fixed per-workgroup cost of ~3 tiles)
+    const int64_t ncu = ctx->num_cus;
+    int64_t best = 1, best_cost = INT64_MAX;
+    for (int64_t js = 1; js <= 64 && js <= max_js; ++js) {
+      const int64_t rows = (((MP + js - 1) / js) + MR - 1) / MR * MR;
+      const int64_t js_eff = (MP + rows - 1) / rows;
+      const int64_t rounds = (n_qt * js_eff + ncu - 1) / ncu;
+      const int64_t cost = rounds * (rows / MR + 3);
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = js;
+      }
+    }
+    JS = best;
+  }
   int64_t rps = (MP + JS - 1) / JS;
   if (bulk) rps = (rps + PR - 1) / PR * PR;
   JS = (MP + rps - 1) / rps;
@@ -404,7 +693,28 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   A.B = B; A.MP = MP; A.D = D; A.sig = md.sig; A.JS = (int)JS; A.rows_per_split = rps;
   A.part_F = part; A.part_E = part + JS * B * (int64_t)D;
   const int slot = ktime_begin(ctx);
-  if (bulk) {
+  if (mfma) {
+    double* stats;
+    GDML_TRY(ctx_slot(ctx, 4, 2 * MP * 8, &stats));
+    hipLaunchKernelGGL(row_stats_kernel, dim3(ceil_div(MP, 4)), dim3(256), 0, ctx->stream, md.xp, md.jap, MP,
+                       D, stats, stats + MP);
+    dim3 grid((unsigned)n_qt, (unsigned)JS);
+    const int nt = 2 * ((D + 31) / 32);  // even number of 16-column tiles
+    const size_t lds_bytes = (size_t)4 * MR * (16 * nt + 2) * 8;
+    switch (nt) {
+#define MC(v)                                                                                         \
+  case v:                                                                                             \
+    hipFuncSetAttribute((const void*)predict_mfma_kernel<v>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        (int)lds_bytes);                                                              \
+    hipLaunchKernelGGL(predict_mfma_kernel<v>, grid, dim3(256), lds_bytes, ctx->stream, A, stats,      \
+                       stats + MP);                                                                   \
+    break;
+      MC(2) MC(4) MC(6) MC(8) MC(10) MC(12) MC(14) MC(16)
+#undef MC
+      default: return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "predict: bad tile count");
+    }
+    ctx->launch_counter++;
+  } else if (bulk) {
     dim3 grid((unsigned)n_qt, (unsigned)JS);
     const int nch = (D + 31) / 32;
     switch (nch) {
