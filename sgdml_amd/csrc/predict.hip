@@ -361,6 +361,24 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const double* __restrict
 #ifndef PMF_ABL
 #define PMF_ABL 0
 #endif
+// The MFMAs of this kernel are written as inline asm so that the register classes are fixed: the
+// accumulators and the query operand live in AccVGPRs for the whole kernel, LDS operands and the Matern
+// scalars in VGPRs.  (Left to itself the allocator keeps the accumulators in VGPRs and copies each one
+// to AccVGPRs and back around every chain of MFMAs, which stalls on the result of the last MFMA.)
+// Hazards the compiler cannot see through the asm are covered by mfma_results_ready().
+__device__ __forceinline__ void mfma_av(d4p& c, double a_vgpr, double b_agpr) {
+  asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a_vgpr), "a"(b_agpr));
+}
+__device__ __forceinline__ void mfma_vv(d4p& c, double a_vgpr, double b_vgpr) {
+  asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a_vgpr), "v"(b_vgpr));
+}
+// MFMA result -> non-MFMA read needs software wait states (16-pass DGEMM): 3 x 16 is ample
+__device__ __forceinline__ void mfma_results_ready(d4p& c0, d4p& c1) {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(c0), "+a"(c1));
+}
+__device__ __forceinline__ void mfma_results_ready_v(d4p& c0, d4p& c1) {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(c0), "+v"(c1));
+}
 #define MQ 64  // queries per workgroup
 #define MR 16  // table rows per tile
 
@@ -412,55 +430,59 @@ __global__ void __launch_bounds__(256, 1) predict_mfma_kernel(PredArgs A, const 
   constexpr int NS2 = NT / 2;  // 8 D / 256 <= NT / 2 double2 per thread
   const int nelem2 = MR * D / 2;
   d2p px[NS2], pj[NS2];
-  auto issue = [&](int64_t r0) {
-    const int64_t lim2 = (r_end - r0) * D / 2;  // double2 elements of this tile that exist (tail: even rows)
-    const d2p* gx = reinterpret_cast<const d2p*>(A.xp + r0 * D);
-    const d2p* gj = reinterpret_cast<const d2p*>(A.jap + r0 * D);
-#pragma unroll
-    for (int s = 0; s < NS2; ++s) {
-      const int idx = tid + 256 * s;
-      const bool ok = idx < nelem2 && idx < lim2;
-      const int idc = ok ? idx : 0;  // unconditional load from a valid address, then select
-      const d2p vx = gx[idc], vj = gj[idc];
-      px[s] = ok ? vx : (d2p){0.0, 0.0};
-      pj[s] = ok ? vj : (d2p){0.0, 0.0};
-    }
+  const d2p* gx = nullptr;
+  const d2p* gj = nullptr;
+  int64_t lim2 = 0;
+  auto issue_begin = [&](int64_t r0, bool valid) {  // valid == false: harmless reload of an existing tile
+    lim2 = valid ? (r_end - r0) * D / 2 : 0;         // double2 elements of this tile that exist
+    gx = reinterpret_cast<const d2p*>(A.xp + r0 * D);
+    gj = reinterpret_cast<const d2p*>(A.jap + r0 * D);
   };
-  auto commit = [&](int buf) {
-    double* Xd = lds + buf * 2 * TILE;
+  auto issue_step = [&](int s) {
+    const int idx = tid + 256 * s;
+    const bool ok = idx < nelem2 && idx < lim2;
+    const int idc = ok ? idx : 0;  // unconditional load from a valid address, then select
+    const d2p vx = gx[idc], vj = gj[idc];
+    px[s] = ok ? vx : (d2p){0.0, 0.0};
+    pj[s] = ok ? vj : (d2p){0.0, 0.0};
+  };
+  int c_row = 0, c_k = 0;
+  const int drow = 512 / D, dk = 512 - drow * D;
+  auto commit_begin = [&]() {
     int e0 = 2 * tid;  // element index inside the tile
     asm volatile("" : "+v"(e0));  // keep the address arithmetic inside the loop (cheaper than spilling it)
-    int row = e0 / D, k = e0 - row * D;
-    const int drow = 512 / D, dk = 512 - drow * D;
-#pragma unroll
-    for (int s = 0; s < NS2; ++s) {
-      if (tid + 256 * s < nelem2) {
-        const int o0 = row * P + k;
-        const int o1 = (k + 1 < D) ? o0 + 1 : o0 + 1 + (P - D);  // second element may start the next row
-        Xd[o0] = px[s][0];
-        Xd[o1] = px[s][1];
-        Xd[TILE + o0] = pj[s][0];
-        Xd[TILE + o1] = pj[s][1];
-      }
-      row += drow;
-      k += dk;
-      if (k >= D) {
-        k -= D;
-        row += 1;
-      }
+    c_row = e0 / D;
+    c_k = e0 - c_row * D;
+  };
+  auto commit_step = [&](int s, double* Xd) {
+    if (tid + 256 * s < nelem2) {
+      const int o0 = c_row * P + c_k;
+      const int o1 = (c_k + 1 < D) ? o0 + 1 : o0 + 1 + (P - D);  // second element may start the next row
+      Xd[o0] = px[s][0];
+      Xd[o1] = px[s][1];
+      Xd[TILE + o0] = pj[s][0];
+      Xd[TILE + o1] = pj[s][1];
+    }
+    c_row += drow;
+    c_k += dk;
+    if (c_k >= D) {
+      c_k -= D;
+      c_row += 1;
     }
   };
   __syncthreads();
-  issue(r_beg);
-  commit(0);
+  issue_begin(r_beg, true);
+#pragma unroll
+  for (int st = 0; st < NS2; ++st) issue_step(st);
+  commit_begin();
+#pragma unroll
+  for (int st = 0; st < NS2; ++st) commit_step(st, lds);
   __syncthreads();
 
   int cur = 0;
   for (int64_t r0 = r_beg; r0 < r_end; r0 += MR) {
     const bool has_next = r0 + MR < r_end;
-#if PMF_ABL != 4
-    if (has_next) issue(r0 + MR);
-#endif
+    issue_begin(has_next ? r0 + MR : r0, has_next);  // steps are interleaved with the phase-1 MFMAs
     // row terms of the lane's 4 pairs (row = r0 + lk + 4 rr)
     double nXr[4], cXr[4], aer[4];
 #pragma unroll
@@ -498,12 +520,23 @@ __global__ void __launch_bounds__(256, 1) predict_mfma_kernel(PredArgs A, const 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[g & 1][u], xA[4 * g + u], p1, 0, 0, 0);
-          p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(oj[g & 1][u], xA[4 * g + u], p2, 0, 0, 0);
+          mfma_av(p1, oa[g & 1][u], xA[4 * g + u]);
+          mfma_av(p2, oj[g & 1][u], xA[4 * g + u]);
         }
+#if PMF_ABL != 4
+        if ((g & 1) == 0 && g / 2 < NS2) {  // next tile's global loads ride in the MFMA shadow
+          issue_step(g / 2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x026, 3, 0);
+          }
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    mfma_results_ready(p1, p2);
     // ---------------- Matern scalars for (row = r0 + lk + 4 rr, query = li)
     double w1[4], b2[4];
 #pragma unroll
@@ -555,18 +588,27 @@ __global__ void __launch_bounds__(256, 1) predict_mfma_kernel(PredArgs A, const 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1[u], ox[t & 1][u], acc2[t], 0, 0, 0);
-          acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2[u], oz[t & 1][u], acc2[t], 0, 0, 0);
+          mfma_vv(acc2[t], w1[u], ox[t & 1][u]);
+          mfma_vv(acc2[t], b2[u], oz[t & 1][u]);
         }
+#if PMF_ABL != 4
+        if ((t & 1) == 0 && t / 2 < NS2) {  // LDS writes of the next tile ride in the MFMA shadow
+          if (t == 0) commit_begin();
+          commit_step(t / 2, lds + (cur ^ 1) * 2 * TILE);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x206, 6, 0);
+          }
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#if PMF_ABL != 4  // ablation 4: no tile refresh (no global loads, LDS writes)
-    if (has_next) commit(cur ^ 1);
-#endif
     __syncthreads();
     cur ^= 1;
   }
+  mfma_results_ready_v(acc2[NT - 1], acc2[NT - 2]);
   // ---- per-query totals live in lanes by li; the accumulators hold query lk + 4 rr
   w1s += __shfl_xor(w1s, 16, 64);
   w1s += __shfl_xor(w1s, 32, 64);
