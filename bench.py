@@ -219,6 +219,8 @@ def main():
         # sanity of the result that was timed: residual of the solve through the matrix-free operator
         Kv = ctx.kernel_matvec(args.lam, False, -alphas)
         resid = float(np.linalg.norm(-Kv - y) / np.linalg.norm(y))  # (-K + lam I) x = -(Kx - lam x)
+        if not resid < 1e-8:  # a fast wrong answer is not a result (tolerance of the solve parity tests)
+            raise SystemExit('bench: residual of the timed solve is %.3e (> 1e-8): refusing to report' % resid)
         roof = None
         extra = {}
         if not args.no_profile:

@@ -365,12 +365,14 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const double* __restrict
 // accumulators and the query operand live in AccVGPRs for the whole kernel, LDS operands and the Matern
 // scalars in VGPRs.  (Left to itself the allocator keeps the accumulators in VGPRs and copies each one
 // to AccVGPRs and back around every chain of MFMAs, which stalls on the result of the last MFMA.)
-// Hazards the compiler cannot see through the asm are covered by mfma_results_ready().
+// Hazards the compiler cannot see through the asm: operands written by a VALU instruction or an
+// AccVGPR copy just before the MFMA (s_nop 1 = the 2 wait states the compiler itself inserts for VALU write -> MFMA read; it mostly issues while the previous MFMA
+// still occupies the pipe, so it is free) and MFMA results read by non-MFMA code (mfma_results_ready()).
 __device__ __forceinline__ void mfma_av(d4p& c, double a_vgpr, double b_agpr) {
-  asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a_vgpr), "a"(b_agpr));
+  asm("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a_vgpr), "a"(b_agpr));
 }
 __device__ __forceinline__ void mfma_vv(d4p& c, double a_vgpr, double b_vgpr) {
-  asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a_vgpr), "v"(b_vgpr));
+  asm("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a_vgpr), "v"(b_vgpr));
 }
 // MFMA result -> non-MFMA read needs software wait states (16-pass DGEMM): 3 x 16 is ample
 __device__ __forceinline__ void mfma_results_ready(d4p& c0, d4p& c1) {
@@ -434,17 +436,17 @@ __global__ void __launch_bounds__(256, 1) predict_mfma_kernel(PredArgs A, const 
   const d2p* gj = nullptr;
   int64_t lim2 = 0;
   auto issue_begin = [&](int64_t r0, bool valid) {  // valid == false: harmless reload of an existing tile
-    lim2 = valid ? (r_end - r0) * D / 2 : 0;         // double2 elements of this tile that exist
+    lim2 = valid ? (r_end - r0) * D : 0;             // elements of this tile that exist
     gx = reinterpret_cast<const d2p*>(A.xp + r0 * D);
     gj = reinterpret_cast<const d2p*>(A.jap + r0 * D);
   };
   auto issue_step = [&](int s) {
     const int idx = tid + 256 * s;
-    const bool ok = idx < nelem2 && idx < lim2;
-    const int idc = ok ? idx : 0;  // unconditional load from a valid address, then select
-    const d2p vx = gx[idc], vj = gj[idc];
-    px[s] = ok ? vx : (d2p){0.0, 0.0};
-    pj[s] = ok ? vj : (d2p){0.0, 0.0};
+    const bool ok0 = idx < nelem2 && 2 * idx < lim2, ok1 = idx < nelem2 && 2 * idx + 1 < lim2;
+    const int idc = ok0 ? idx : 0;  // unconditional load from a valid address, then select; when the
+    const d2p vx = gx[idc], vj = gj[idc];  // table ends on an odd element the pair reads the 8-byte pad
+    px[s] = (d2p){ok0 ? vx[0] : 0.0, ok1 ? vx[1] : 0.0};
+    pj[s] = (d2p){ok0 ? vj[0] : 0.0, ok1 ? vj[1] : 0.0};
   };
   int c_row = 0, c_k = 0;
   const int drow = 512 / D, dk = 512 - drow * D;
@@ -814,8 +816,8 @@ extern "C" int gdml_predict_upload_model(gdml_ctx* ctx, const double* R_desc,
   Model& md = ctx->model;
   const int D = N * (N - 1) / 2;
   md.M = M; md.N = N; md.D = D; md.P = P; md.sig = sig;
-  GDML_TRY(ctx_alloc(ctx, (void**)&md.xp, M * P * (int64_t)D * 8));
-  GDML_TRY(ctx_alloc(ctx, (void**)&md.jap, M * P * (int64_t)D * 8));
+  GDML_TRY(ctx_alloc(ctx, (void**)&md.xp, M * P * (int64_t)D * 8 + 16));  // +pad: paired loads of an odd tail
+  GDML_TRY(ctx_alloc(ctx, (void**)&md.jap, M * P * (int64_t)D * 8 + 16));
   GDML_TRY(ctx_alloc(ctx, (void**)&md.ja, M * (int64_t)D * 8));
   GDML_TRY(ctx_alloc(ctx, (void**)&md.aE, M * P * 8));
   GDML_TRY(ctx_alloc(ctx, (void**)&md.tp, (int64_t)P * D * 4));
@@ -1117,8 +1119,8 @@ int operator_model_from_trainset(gdml_ctx* ctx, double sig) {
   if (!(md.xp && md.M == M && md.N == ts.N && md.P == P)) {
     GDML_TRY(model_free(ctx));
     md.M = M; md.N = ts.N; md.D = D; md.P = P;
-    GDML_TRY(ctx_alloc(ctx, (void**)&md.xp, M * P * (int64_t)D * 8));
-    GDML_TRY(ctx_alloc(ctx, (void**)&md.jap, M * P * (int64_t)D * 8));
+    GDML_TRY(ctx_alloc(ctx, (void**)&md.xp, M * P * (int64_t)D * 8 + 16));  // +pad: paired loads of an odd tail
+    GDML_TRY(ctx_alloc(ctx, (void**)&md.jap, M * P * (int64_t)D * 8 + 16));
     GDML_TRY(ctx_alloc(ctx, (void**)&md.ja, M * (int64_t)D * 8));
     GDML_TRY(ctx_alloc(ctx, (void**)&md.aE, M * P * 8));
     GDML_TRY(ctx_alloc(ctx, (void**)&md.tp, (int64_t)P * D * 4));

@@ -470,3 +470,61 @@ def test_device_error_sums_match_reference_definitions(golden):
     assert abs(got['magnitude'][0] - np.abs(mp - mr).mean()) <= tol
     cos = np.arccos(np.clip(np.einsum('ij,ij->i', f_pred.reshape(-1, 3) / mp[:, None], F_ref.reshape(-1, 3) / mr[:, None]), -1, 1)) / np.pi
     assert abs(got['angle'][0] - cos.mean()) <= 1e-7 + 100 * fl and abs(got['angle'][1] - np.sqrt((cos**2).mean())) <= 1e-7 + 100 * fl
+
+
+# ------------------------------------------------------------------------------------------
+# Large query batches (B >= 256) take the fp64-MFMA kernel; every tile-count instantiation
+# (D <= 32, 64, ... 256), odd table sizes, permutations and the energy-constraint terms are checked
+# against the oracle.  Tolerance: 1e-11 * max|F| (well-conditioned random coefficients).
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n_atoms,n_train,n_query,n_perms,with_aE', [
+    (6, 37, 300, 1, False),    # D = 15  (odd D, odd M: table ends on an odd element)
+    (9, 41, 257, 2, True),     # D = 36, permutations + energy constraints
+    (12, 70, 300, 1, False),   # D = 66
+    (14, 33, 256, 1, True),    # D = 91
+    (16, 50, 320, 1, False),   # D = 120
+    (18, 35, 300, 1, False),   # D = 153
+    (20, 40, 290, 1, True),    # D = 190
+    (21, 333, 1000, 1, False), # D = 210, many workgroups, ragged last split / last query tile
+    (23, 47, 300, 1, False),   # D = 253
+])
+def test_predict_large_batch_mfma(ctx_factory, n_atoms, n_train, n_query, n_perms, with_aE):
+    ds = orc.synth_dataset(n_atoms, n_train + n_query, seed=n_atoms)
+    Rf = ds['R'].reshape(n_train + n_query, -1)
+    perms = np.arange(n_atoms)[None]
+    if n_perms == 2:
+        p2 = np.arange(n_atoms)
+        p2[[0, 1]] = p2[[1, 0]]
+        perms = np.vstack([perms, p2])
+    tp = orc.tril_perms_from_atom_perms(perms)
+    xd, gd = orc.desc_from_R(Rf[:n_train])
+    rs = np.random.RandomState(5)
+    ja = rs.normal(size=xd.shape)
+    aE = rs.normal(size=n_train) if with_aE else None
+    sig = 12.0
+    c = ctx_factory()
+    c.predict_upload_model(xd, ja, tp, sig, aE)
+    E, F = c.predict(Rf[n_train:])
+    rq, rdq = orc.desc_from_R(Rf[n_train:])
+    E0, F0 = orc.predict_from_desc(rq, rdq, xd, ja, tp, sig, aE)
+    assert np.abs(F - F0).max() <= 1e-11 * np.abs(F0).max()
+    assert np.abs(E - E0).max() <= 1e-11 * np.abs(E0).max()
+
+
+@pytest.mark.parametrize('use_E_cstr', [False, True])
+def test_kernel_matvec_large_mfma(ctx_factory, use_E_cstr):
+    """Training-set mode of the same kernel (coincident points: |d|^2 from the expansion is clamped)."""
+    n_atoms, M = 7, 300
+    ds = orc.synth_dataset(n_atoms, M, seed=11)
+    Rf = ds['R'].reshape(M, -1)
+    tp = orc.tril_perms_from_atom_perms(np.arange(n_atoms)[None])
+    xd, gd = orc.desc_from_R(Rf)
+    sig, lam = 10.0, 1e-10
+    c = ctx_factory()
+    c.train_upload(xd, gd, tp)
+    c.predict_upload_model(xd, np.zeros_like(xd), tp, sig, np.zeros(M) if use_E_cstr else None)
+    rs = np.random.RandomState(2)
+    v = rs.normal(size=M * 3 * n_atoms + (M if use_E_cstr else 0))
+    Kv = c.kernel_matvec(lam, use_E_cstr, v)
+    Kv0 = orc.kernel_matvec(xd, gd, tp, sig, lam, v, use_E_cstr)
+    assert np.abs(Kv - Kv0).max() <= 1e-11 * np.abs(Kv0).max()
