@@ -17,6 +17,36 @@ __global__ void seg_kernel(double* K, int64_t ld, int N3, int M, int ichunk, int
       for (int r = wave; r < N3; r += nw)
         if (lane < N3) K[(i * N3 + r) * ld + (j + jj) * N3 + lane] = (double)lane;
 }
+// mode 3: one wavefront per row point i (4 per workgroup), walks j in groups of J; inside a group the loop
+// is row-outer / j-inner, so J adjacent 504-byte segments of one matrix row are written back to back
+__global__ void seg_rowmajor_kernel(double* K, int64_t ld, int N3, int M, int J, int jchunk) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t b = blockIdx.x; int64_t x = b & 7, l = b >> 3;
+  int64_t nchunks = (M + jchunk - 1) / jchunk;      // j chunks
+  int64_t per = nchunks / 8 > 0 ? nchunks / 8 : 1;  // chunks per XCD
+  int64_t jc = x * per + (l % per), ig = l / per;
+  int64_t i = ig * 4 + wave;
+  if (i >= M || jc >= nchunks) return;
+  for (int64_t j0 = jc * jchunk; j0 < (jc + 1) * jchunk && j0 < M; j0 += J)
+    for (int r = 0; r < N3; ++r)
+      for (int jj = 0; jj < J; ++jj)
+        if (lane < N3 && j0 + jj < M) K[(i * N3 + r) * ld + (j0 + jj) * N3 + lane] = (double)lane;
+}
+// mode 4: workgroup of W wavefronts for one row point i; wavefront w owns block column j0 + w and all
+// wavefronts walk the rows together, so W adjacent segments of one matrix row are written at the same time
+__global__ void seg_wavecols_kernel(double* K, int64_t ld, int N3, int M, int jchunk, int sync) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+  int64_t b = blockIdx.x; int64_t x = b & 7, l = b >> 3;
+  int64_t nchunks = (M + jchunk - 1) / jchunk;
+  int64_t per = nchunks / 8 > 0 ? nchunks / 8 : 1;
+  int64_t jc = x * per + (l % per), i = l / per;
+  if (i >= M || jc >= nchunks) return;
+  for (int64_t j0 = jc * jchunk; j0 < (jc + 1) * jchunk && j0 < M; j0 += W) {
+    for (int r = 0; r < N3; ++r)
+      if (lane < N3 && j0 + wave < M) K[(i * N3 + r) * ld + (j0 + wave) * N3 + lane] = (double)lane;
+    if (sync) __syncthreads();
+  }
+}
 // pairs of block columns, 16-byte stores, XCD remap
 __global__ void seg2_kernel(double* K, int64_t ld, int N3, int M, int ichunk, int nj2) {
   int64_t b = blockIdx.x; int64_t x = b & 7, l = b >> 3; int64_t per = nj2 / 8;
@@ -44,6 +74,16 @@ int main() {
     T("seg xcd-remap 8j/WG", (seg_kernel<<<dim3(M / 8 * ny), 448>>>(K, ld, N3, M, ic, 2, M)));
     T("seg pairs 16B xcd-remap", (seg2_kernel<<<dim3(M / 2 * ny), 448>>>(K, ld, N3, M, ic, M / 2)));
     T("rows 8B", (row8_kernel<<<(unsigned)n, 256>>>(K, ld, n)));
+    for (int W = 4; W <= 16; W *= 2) for (int sy = 0; sy < 2; ++sy) {
+      char nm[64]; int jchunk = 64; int64_t nch = (M + jchunk - 1) / jchunk;
+      snprintf(nm, 64, "WG/i, wave/j, W=%d sync=%d", W, sy);
+      T(nm, (seg_wavecols_kernel<<<dim3((unsigned)(nch * M)), 64 * W>>>(K, ld, N3, M, jchunk, sy)));
+    }
+    for (int J = 1; J <= 8; J *= 2) {
+      char nm[64]; int jchunk = 40; int64_t nch = (M + jchunk - 1) / jchunk;
+      snprintf(nm, 64, "wave/i row-outer J=%d", J);
+      T(nm, (seg_rowmajor_kernel<<<dim3((unsigned)(nch * (M / 4))), 256>>>(K, ld, N3, M, J, jchunk)));
+    }
   }
   return 0;
 }
