@@ -44,6 +44,7 @@ struct GemmArgs {
   int lower;
   int tiles_m, tiles_n;
   int64_t n_super;  // number of 8x8 super tiles enumerated
+  int64_t s_begin;  // first super tile of this launch (a launch may cover a sub-range)
   int super_n;      // super-tile columns
   int aligned;      // A, B 16-byte aligned with even leading dimensions (vector loads legal)
   int dbg;          // GDML_GEMM_DEBUG ablation bits: 1 no epilogue, 2 no tile loads, 4 no LDS reads, 8 no barrier
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   // ---- block -> tile mapping: XCD-aware 8x8 super tiles (block b runs on XCD b % 8)
   const int64_t b = blockIdx.x;
   const int64_t xcd = b & 7, loc = b >> 3;
-  const int64_t s = (loc >> 6) * 8 + xcd;
+  const int64_t s = g.s_begin + (loc >> 6) * 8 + xcd;
   const int within = (int)(loc & 63);
   if (s >= g.n_super) return;
   int64_t SI, SJ;
@@ -236,9 +237,11 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
     gemm_tile_body<false>(g, lds, row0, col0);
 }
 
-int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
-                              const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
-                              int64_t N, int64_t K, int lower) {
+// f0, f1: the launch covers the super tiles [f0 * n_super, f1 * n_super) (whole update: 0, 1);
+// timed: bracket with the per-kernel timers (only launches on the timing stream)
+static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
+                                   const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
+                                   int64_t N, int64_t K, int lower, double f0, double f1, bool timed) {
   if (M <= 0 || N <= 0 || K <= 0) return GDML_OK;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -257,16 +260,25 @@ int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t l
   g.tiles_n = (int)((N + GT - 1) / GT);
   int64_t sm = (g.tiles_m + 7) / 8, sn = (g.tiles_n + 7) / 8;
   g.super_n = (int)sn;
-  g.n_super = lower ? sm * (sm + 1) / 2 : sm * sn;
-  int64_t groups = (g.n_super + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
+  const int64_t n_super_all = lower ? sm * (sm + 1) / 2 : sm * sn;
+  g.s_begin = (int64_t)(f0 * (double)n_super_all);
+  g.n_super = (f1 >= 1.0) ? n_super_all : (int64_t)(f1 * (double)n_super_all);
+  if (g.n_super <= g.s_begin) return GDML_OK;
+  int64_t groups = (g.n_super - g.s_begin + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
   int64_t blocks = groups * 512;
-  const int slot = (st == ctx->stream) ? ktime_begin(ctx) : -1;
+  const int slot = (timed && st == (ctx->kt_stream ? ctx->kt_stream : ctx->stream)) ? ktime_begin(ctx) : -1;
   hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
   ktime_end(ctx, slot, "gemm_nt_sub",
             lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;
+}
+
+int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
+                              const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
+                              int64_t N, int64_t K, int lower) {
+  return launch_gemm_nt_sub_part(ctx, st, A, lda, B, ldb, C, ldc, M, N, K, lower, 0.0, 1.0, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -415,6 +427,80 @@ static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int
 // compute stream first updates only the columns of panel k+1, then (a) the panel stream factors
 // panel k+1 (latency-bound 64-wide steps) while (b) the compute stream applies the big SYRK to
 // the rest of the trailing matrix.  The two touch disjoint columns.
+// Split-stream schedule (GDML_CHOL_SPLIT, default on): the panel kernels need a CU with a free GEMM slot
+// (a GEMM workgroup takes half the registers and LDS of a CU), and while the SYRK grid has workgroups
+// pending the dispatcher refills every slot with the next GEMM workgroup -- so with plain look-ahead the
+// panel only makes progress once the SYRK has drained and ends up exposed in every step (timeline:
+// 136 ms of 1.63 s without any GEMM running).  Here the two streams carry complementary CU masks for the
+// whole factorisation: the auxiliary stream owns `aux_cus` compute units, runs panel k+1 there right away
+// and then takes a share of SYRK k sized so that both streams finish together; the main stream does the
+// rest of SYRK k on the other CUs.
+static int chol_factor_split(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int64_t NB, int aux_cus) {
+  GDML_TRY(ctx_masked_streams(ctx, aux_cus));
+  hipStream_t sm = ctx->stream_mm, sa = ctx->stream_mp;
+  hipEvent_t evA = ctx->ev_la[0], evB = ctx->ev_la[1];
+  // panel time on the auxiliary CUs: t_p(m) = pa + pb * m  [ms];  full-chip SYRK: t_s(m) = m^2 nb / rate
+  static double pa = -1.0, pb = 0.0, rate = 0.0;
+  if (pa < 0.0) {
+    const char* e;
+    pa = (e = getenv("GDML_CHOL_PANEL_A")) ? atof(e) : 0.5;
+    pb = (e = getenv("GDML_CHOL_PANEL_B")) ? atof(e) : 2.7e-3 / (double)aux_cus;  // ms per row per CU^-1
+    rate = (e = getenv("GDML_CHOL_GEMM_TF")) ? atof(e) : 57.0;
+  }
+  const double fa = (double)aux_cus / (double)ctx->num_cus;  // capacity share of the auxiliary stream
+  HIP_CHECK(ctx, hipEventRecord(evA, ctx->stream));
+  HIP_CHECK(ctx, hipStreamWaitEvent(sm, evA, 0));
+  ctx->kt_stream = sm;
+  GDML_TRY(panel_factor(ctx, sm, A, n, ld, 0, n < NB ? n : NB));
+  for (int64_t k0 = 0; k0 < n; k0 += NB) {
+    const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
+    const int64_t t0 = k0 + nb;
+    if (t0 >= n) break;
+    const int64_t nb2 = (n - t0 < NB) ? n - t0 : NB;
+    const int64_t t1 = t0 + nb2;
+    const double* P = A + t0 * ld + k0;
+    // (1) next panel's columns on the main CUs
+    GDML_TRY(launch_gemm_nt_sub(ctx, sm, P, ld, P, ld, A + t0 * ld + t0, ld, n - t0, nb2, nb, 0));
+    HIP_CHECK(ctx, hipEventRecord(evA, sm));
+    HIP_CHECK(ctx, hipStreamWaitEvent(sa, evA, 0));
+    // (2) panel k+1 on the auxiliary CUs, then its share of the trailing update
+    GDML_TRY(panel_factor(ctx, sa, A, n, ld, t0, nb2));
+    const int64_t m = n - t1;
+    double f_aux = 0.0;
+    if (m > 0) {
+      const double t_s = (double)m * (double)m * (double)nb / (rate * 1e9);  // ms on the whole chip
+      const double t_p = pa + pb * (double)(n - t0);
+      // t_p + f t_s / fa = (1 - f) t_s / (1 - fa)
+      f_aux = (t_s / (1.0 - fa) - t_p) / (t_s / fa + t_s / (1.0 - fa));
+      if (f_aux < 0.0) f_aux = 0.0;
+      if (f_aux > fa) f_aux = fa;
+      const int64_t tiles = (m + GT - 1) / GT, sup = (tiles + 7) / 8;
+      if (sup * (sup + 1) / 2 < 64) f_aux = 0.0;  // too few super tiles to split
+      const double* P1 = A + t1 * ld + k0;
+      const int slot = ktime_begin(ctx);
+      if (f_aux > 0.0)
+        GDML_TRY(launch_gemm_nt_sub_part(ctx, sa, P1, ld, P1, ld, A + t1 * ld + t1, ld, m, m, nb, 1, 1.0 - f_aux,
+                                         1.0, false));
+      HIP_CHECK(ctx, hipEventRecord(evB, sa));
+      GDML_TRY(launch_gemm_nt_sub_part(ctx, sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, m, m, nb, 1, 0.0,
+                                       1.0 - f_aux, false));
+      HIP_CHECK(ctx, hipStreamWaitEvent(sm, evB, 0));
+      ktime_end(ctx, slot, "gemm_nt_sub", (double)m * (double)(m + 1) * (double)nb);  // both parts, to the join
+    } else {
+      HIP_CHECK(ctx, hipEventRecord(evB, sa));
+      HIP_CHECK(ctx, hipStreamWaitEvent(sm, evB, 0));
+    }
+  }
+  if (ctx->profiling) {
+    HIP_CHECK(ctx, hipStreamSynchronize(sm));
+    GDML_TRY(ktime_collect(ctx));
+  }
+  ctx->kt_stream = nullptr;
+  HIP_CHECK(ctx, hipEventRecord(evA, sm));
+  HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, evA, 0));
+  return GDML_OK;
+}
+
 int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out) {
   HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   static int64_t NB = 0;  // outer panel width (GDML_CHOL_NB overrides; multiple of 64)
@@ -423,14 +509,52 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
     NB = e ? atoll(e) : 512;
     if (NB < 64 || NB % 64) NB = 512;
   }
+  {
+    static int split = -1, aux_cus = 32;
+    if (split < 0) {
+      const char* e = getenv("GDML_CHOL_SPLIT");
+      split = e ? atoi(e) : 0;
+      const char* c = getenv("GDML_CHOL_AUX_CUS");
+      if (c) aux_cus = atoi(c);
+    }
+    if (split && n > 4 * NB && getenv("GDML_NO_LOOKAHEAD") == nullptr) {
+      GDML_TRY(chol_factor_split(ctx, A, n, ld, NB, aux_cus));
+      HIP_CHECK(ctx, hipGetLastError());
+      int info = 0;
+      HIP_CHECK(ctx, hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      if (info_out) *info_out = info;
+      return GDML_OK;
+    }
+  }
   hipStream_t sm = ctx->stream, sp = ctx->stream2;
   hipEvent_t evA = ctx->ev_la[0], evB = ctx->ev_la[1];
   const bool lookahead = getenv("GDML_NO_LOOKAHEAD") == nullptr;
+  // late phase: once fewer than mask_rows rows remain the panel chain is the critical path; from then
+  // on the two streams are a CU-masked pair, so that the panel kernels never queue behind GEMM workgroups
+  static int64_t mask_rows = -1;
+  static int mask_cus = 32;
+  if (mask_rows < 0) {
+    const char* e = getenv("GDML_CHOL_MASK_ROWS");
+    mask_rows = e ? atoll(e) : 0;
+    const char* c = getenv("GDML_CHOL_MASK_CUS");
+    if (c) mask_cus = atoi(c);
+  }
+  bool masked = false;
   GDML_TRY(panel_factor(ctx, sm, A, n, ld, 0, n < NB ? n : NB));
   for (int64_t k0 = 0; k0 < n; k0 += NB) {
     const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
     const int64_t t0 = k0 + nb;
     if (t0 >= n) break;
+    if (lookahead && !masked && mask_rows > 0 && n - t0 < mask_rows) {
+      GDML_TRY(ctx_masked_streams(ctx, mask_cus));
+      HIP_CHECK(ctx, hipEventRecord(evA, sm));  // everything issued so far is on sm (sp has been joined)
+      HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_mm, evA, 0));
+      sm = ctx->stream_mm;
+      sp = ctx->stream_mp;
+      ctx->kt_stream = sm;
+      masked = true;
+    }
     const int64_t nb2 = (n - t0 < NB) ? n - t0 : NB;
     const int64_t t1 = t0 + nb2;
     const double* P = A + t0 * ld + k0;  // rows t0.. of panel k
@@ -451,6 +575,15 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
       HIP_CHECK(ctx, hipStreamWaitEvent(sm, evB, 0));
     else
       GDML_TRY(panel_factor(ctx, sm, A, n, ld, t0, nb2));
+  }
+  if (masked) {  // join the masked pair back into the context's main stream
+    if (ctx->profiling) {
+      HIP_CHECK(ctx, hipStreamSynchronize(sm));  // the timers of the late GEMMs were recorded on sm
+      GDML_TRY(ktime_collect(ctx));
+    }
+    ctx->kt_stream = nullptr;
+    HIP_CHECK(ctx, hipEventRecord(evA, sm));
+    HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, evA, 0));
   }
   HIP_CHECK(ctx, hipGetLastError());
   int info = 0;

@@ -64,6 +64,9 @@ struct gdml_ctx {
   int num_cus = 256;  // compute units of the device (grid sizing)
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;
+  hipStream_t stream_mm = nullptr, stream_mp = nullptr;  // CU-masked pair (late Cholesky panels), lazily created
+  int masked_cus = 0;                                    // CUs reserved for stream_mp
+  hipStream_t kt_stream = nullptr;                       // stream the per-kernel timers record on (default: stream)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_la[2] = {nullptr, nullptr};  // look-ahead hand-off between the two streams
   std::string err;
@@ -128,6 +131,7 @@ int ctx_free(gdml_ctx* ctx, void* p);
 int ctx_scratch(gdml_ctx* ctx, int64_t bytes, double** out);
 void phase_begin(gdml_ctx* ctx);
 // kernel timing (no-ops unless ctx->profiling)
+int ctx_masked_streams(gdml_ctx* ctx, int reserve_cus);  // creates stream_mm / stream_mp
 int ktime_begin(gdml_ctx* ctx);  // returns slot or -1
 void ktime_end(gdml_ctx* ctx, int slot, const char* name, double work);
 int ktime_collect(gdml_ctx* ctx);

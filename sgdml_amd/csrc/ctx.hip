@@ -109,6 +109,8 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   if (ctx->ev_la[1]) hipEventDestroy(ctx->ev_la[1]);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+  if (ctx->stream_mm) hipStreamDestroy(ctx->stream_mm);
+  if (ctx->stream_mp) hipStreamDestroy(ctx->stream_mp);
   delete ctx;
   return GDML_OK;
 }
@@ -206,6 +208,27 @@ int phase_end(gdml_ctx* ctx, const char* name) {
   return GDML_OK;
 }
 
+// A pair of streams with complementary CU masks: stream_mp owns `reserve_cus` compute units (mask bits
+// are dealt round-robin over the XCDs, so the first bits are spread evenly), stream_mm the rest.  Used
+// for the late panels of the Cholesky factorisation, where the panel chain is the critical path and
+// its small kernels would otherwise queue behind a full grid of GEMM workgroups.
+int ctx_masked_streams(gdml_ctx* ctx, int reserve_cus) {
+  if (ctx->stream_mm && ctx->masked_cus == reserve_cus) return GDML_OK;
+  if (ctx->stream_mm) {
+    (void)hipStreamDestroy(ctx->stream_mm);
+    (void)hipStreamDestroy(ctx->stream_mp);
+    ctx->stream_mm = ctx->stream_mp = nullptr;
+  }
+  const int ncu = ctx->num_cus;
+  if (reserve_cus <= 0 || reserve_cus >= ncu) return gdml_fail(ctx, GDML_ERR_INVALID, "bad CU reservation");
+  std::vector<uint32_t> mm((ncu + 31) / 32, 0u), mp((ncu + 31) / 32, 0u);
+  for (int c = 0; c < ncu; ++c) (c < reserve_cus ? mp : mm)[c / 32] |= 1u << (c % 32);
+  HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ctx->stream_mm, (uint32_t)mm.size(), mm.data()));
+  HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ctx->stream_mp, (uint32_t)mp.size(), mp.data()));
+  ctx->masked_cus = reserve_cus;
+  return GDML_OK;
+}
+
 static hipEvent_t pool_get(gdml_ctx* ctx) {
   if (!ctx->event_pool.empty()) {
     hipEvent_t e = ctx->event_pool.back();
@@ -223,7 +246,7 @@ int ktime_begin(gdml_ctx* ctx) {
   t.e0 = pool_get(ctx);
   t.e1 = pool_get(ctx);
   t.work = 0;
-  (void)hipEventRecord(t.e0, ctx->stream);
+  (void)hipEventRecord(t.e0, ctx->kt_stream ? ctx->kt_stream : ctx->stream);
   ctx->pending.push_back(t);
   return (int)ctx->pending.size() - 1;
 }
@@ -233,7 +256,7 @@ void ktime_end(gdml_ctx* ctx, int slot, const char* name, double work) {
   PendingTiming& t = ctx->pending[slot];
   t.name = name;
   t.work = work;
-  (void)hipEventRecord(t.e1, ctx->stream);
+  (void)hipEventRecord(t.e1, ctx->kt_stream ? ctx->kt_stream : ctx->stream);
 }
 
 int ktime_collect(gdml_ctx* ctx) {
