@@ -73,6 +73,10 @@ struct gdml_ctx {
   int64_t held = 0;
   std::map<void*, int64_t> allocs;
   std::map<std::string, PhaseStat> phases;
+  std::string phase_pending;         // phase whose end event has been recorded but not read yet
+  int64_t phase_pending_launches = 0;
+  double* h_pin = nullptr;           // pinned host staging for small transfers (single-geometry latency path)
+  int64_t h_pin_bytes = 0;
   int64_t launch_counter = 0;
   bool profiling = false;
   std::map<std::string, KernelStat> kstats;
@@ -132,6 +136,7 @@ int ctx_scratch(gdml_ctx* ctx, int64_t bytes, double** out);
 void phase_begin(gdml_ctx* ctx);
 // kernel timing (no-ops unless ctx->profiling)
 int ctx_masked_streams(gdml_ctx* ctx, int reserve_cus);  // creates stream_mm / stream_mp
+int phase_resolve(gdml_ctx* ctx);  // reads a pending phase timer (waits for its end event)
 int ktime_begin(gdml_ctx* ctx);  // returns slot or -1
 void ktime_end(gdml_ctx* ctx, int slot, const char* name, double work);
 int ktime_collect(gdml_ctx* ctx);

@@ -109,6 +109,7 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   if (ctx->ev_la[1]) hipEventDestroy(ctx->ev_la[1]);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+  if (ctx->h_pin) hipHostFree(ctx->h_pin);
   if (ctx->stream_mm) hipStreamDestroy(ctx->stream_mm);
   if (ctx->stream_mp) hipStreamDestroy(ctx->stream_mp);
   delete ctx;
@@ -192,19 +193,30 @@ int ctx_slot(gdml_ctx* ctx, int slot, int64_t bytes, double** out) {
   return GDML_OK;
 }
 
+// Phase timers are read lazily: phase_end only records the end event, so a call that returns device-side
+// results (or the single-geometry prediction path) does not pay a host synchronisation for the timer.
+int phase_resolve(gdml_ctx* ctx) {
+  if (ctx->phase_pending.empty()) return GDML_OK;
+  HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  PhaseStat& s = ctx->phases[ctx->phase_pending];
+  s.ms = ms;
+  s.launches = ctx->phase_pending_launches;
+  ctx->phase_pending.clear();
+  return GDML_OK;
+}
+
 void phase_begin(gdml_ctx* ctx) {
+  (void)phase_resolve(ctx);
   ctx->launch_counter = 0;
   (void)hipEventRecord(ctx->ev0, ctx->stream);
 }
 
 int phase_end(gdml_ctx* ctx, const char* name) {
   HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
-  float ms = 0.f;
-  HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-  PhaseStat& s = ctx->phases[name];
-  s.ms = ms;
-  s.launches = ctx->launch_counter;
+  ctx->phase_pending = name;
+  ctx->phase_pending_launches = ctx->launch_counter;
   return GDML_OK;
 }
 
@@ -301,6 +313,7 @@ extern "C" int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_ou
 extern "C" int gdml_phase_ms(gdml_ctx* ctx, const char* phase, double* ms_out,
                              int64_t* launches_out) {
   if (!ctx || !phase) return GDML_ERR_INVALID;
+  GDML_TRY(phase_resolve(ctx));
   auto it = ctx->phases.find(phase);
   if (it == ctx->phases.end()) return gdml_fail(ctx, GDML_ERR_STATE, "phase '%s' never ran", phase);
   if (ms_out) *ms_out = it->second.ms;

@@ -700,8 +700,17 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   const bool bulk = (B >= 256) && (D <= 256) && getenv("GDML_PREDICT_V1") == nullptr;
   const bool mfma = bulk && getenv("GDML_PREDICT_NO_MFMA") == nullptr;
   int QB = max_qb_for(KPL);
-  while (QB > 1 && (B + QB - 1) / QB < 512 && QB > B) QB >>= 1;  // do not waste query slots
-  while (QB > 1 && B < QB) QB >>= 1;
+  while (QB > 1 && B < QB) QB >>= 1;  // do not waste query slots
+  {
+    // small batches: fewer queries per wavefront until the grid (query tiles x row splits) fills the chip
+    static int fill = -1;
+    if (fill < 0) {
+      const char* e = getenv("GDML_PREDICT_FILL");
+      fill = e ? atoi(e) : 1024;
+    }
+    const int64_t js_cap = MP / 16 > 1 ? MP / 16 : 1;
+    while (QB > 1 && ((B + QB - 1) / QB) * js_cap < fill) QB >>= 1;
+  }
   int64_t n_qt = mfma ? (B + MQ - 1) / MQ : bulk ? (B + PQ - 1) / PQ : (B + QB - 1) / QB;
   int64_t JS = ((mfma ? 512 : bulk ? 2048 : 4096) + n_qt - 1) / n_qt;
   int64_t max_js = bulk ? (MP / 64 > 1 ? MP / 64 : 1) : (MP / 16 > 1 ? MP / 16 : 1);
@@ -899,6 +908,8 @@ static int predict_common(gdml_ctx* ctx, const double* R, bool R_on_device, int6
   const double *d_xq, *d_gq;
   double* buf = nullptr;
   double *d_E = E_out, *d_F = F_out;
+  bool use_pin = false;
+  constexpr int64_t PIN_BYTES = 1 << 20;
   if (R == nullptr) {  // training-set mode (predict.py:1221-1233)
     TrainSet& ts = ctx->ts;
     if (!ts.x || ts.N != N)
@@ -920,10 +931,23 @@ static int predict_common(gdml_ctx* ctx, const double* R, bool R_on_device, int6
     double* d_R = buf;
     double* dx = buf + nR;
     double* dg = dx + nx;
-    if (R_on_device)
+    // small host batches (the single-geometry / MD use case) are staged through pinned memory: one truly
+    // asynchronous copy in, one out, instead of three pageable copies
+    use_pin = !R_on_device && !out_on_device && (nR + B + nR) * 8 <= PIN_BYTES;
+    if (use_pin && !ctx->h_pin) {
+      if (hipHostMalloc((void**)&ctx->h_pin, PIN_BYTES, hipHostMallocDefault) == hipSuccess)
+        ctx->h_pin_bytes = PIN_BYTES;
+      else
+        use_pin = false;
+    }
+    if (R_on_device) {
       HIP_CHECK(ctx, hipMemcpyAsync(d_R, R, nR * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    else
+    } else if (use_pin) {
+      memcpy(ctx->h_pin, R, nR * 8);
+      HIP_CHECK(ctx, hipMemcpyAsync(d_R, ctx->h_pin, nR * 8, hipMemcpyHostToDevice, ctx->stream));
+    } else {
       HIP_CHECK(ctx, hipMemcpyAsync(d_R, R, nR * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (!out_on_device) {
       d_E = dg + ng;
       d_F = d_E + B;
@@ -937,9 +961,17 @@ static int predict_common(gdml_ctx* ctx, const double* R, bool R_on_device, int6
   GDML_TRY(predict_device(ctx, d_xq, d_gq, B, (E_out || !out_on_device) ? d_E : nullptr, d_F));
   GDML_TRY(phase_end(ctx, "predict"));
   if (!out_on_device) {
-    if (E_out) HIP_CHECK(ctx, hipMemcpyAsync(E_out, d_E, B * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(ctx, hipMemcpyAsync(F_out, d_F, B * 3 * N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (use_pin) {  // E and F are adjacent in the work buffer: one copy
+      double* h_out = ctx->h_pin + B * 3 * N;
+      HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_E, (B + B * 3 * N) * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      if (E_out) memcpy(E_out, h_out, B * 8);
+      memcpy(F_out, h_out + B, B * 3 * N * 8);
+    } else {
+      if (E_out) HIP_CHECK(ctx, hipMemcpyAsync(E_out, d_E, B * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(ctx, hipMemcpyAsync(F_out, d_F, B * 3 * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
   }
   return GDML_OK;
 }

@@ -1,0 +1,32 @@
+"""Single-geometry prediction latency (the ASE-calculator use case): host array in, host E/F out."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import synth_geometries
+from sgdml_amd import _lib
+
+def run(N, M, P=1):
+    R, E, F = synth_geometries(N, M + 8, seed=0)
+    Rf = R.reshape(M + 8, -1)
+    ctx = _lib.Context(0)
+    D = N * (N - 1) // 2
+    tp = np.arange(D, dtype=np.int64)[None]
+    xd, gd = ctx.desc_from_R(Rf[:M], N)
+    rs = np.random.RandomState(0)
+    ctx.predict_upload_model(xd, rs.normal(size=xd.shape), tp, 20.0, None)
+    for B in (1, 8, 64, 200):
+        q = np.ascontiguousarray(Rf[M:M + B])
+        for _ in range(50):
+            ctx.predict(q)
+        ts = []
+        for _ in range(500):
+            t0 = time.perf_counter()
+            ctx.predict(q)
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts) * 1e6
+        print('N=%d M=%d B=%d: host-to-host latency median %.1f us, p10 %.1f, p90 %.1f' % (N, M, B, np.median(ts), np.percentile(ts, 10), np.percentile(ts, 90)), flush=True)
+    ctx.close()
+
+if __name__ == '__main__':
+    run(21, 1000)
+    run(9, 200)
