@@ -117,3 +117,19 @@ def test_dataset_md5_matches_reference_recipe():
     for k in ['z', 'R', 'E', 'F']:
         h.update(hashlib.md5(ds[k].ravel()).digest())
     assert io.dataset_md5(ds) == h.hexdigest().encode('utf-8')
+
+
+def test_ase_calculator_optional_dependency():
+    """intf/ase_calc.py mirrors the reference: ASE is optional and its absence is an ImportError
+    (reference ase_calc.py:25-31)."""
+    import importlib
+    import sys
+
+    try:
+        import ase  # noqa: F401
+        pytest.skip('ASE is installed here')
+    except ImportError:
+        pass
+    sys.modules.pop('sgdml_amd.intf.ase_calc', None)
+    with pytest.raises(ImportError, match='Optional ASE dependency not found'):
+        importlib.import_module('sgdml_amd.intf.ase_calc')

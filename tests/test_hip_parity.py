@@ -528,3 +528,57 @@ def test_kernel_matvec_large_mfma(ctx_factory, use_E_cstr):
     Kv = c.kernel_matvec(lam, use_E_cstr, v)
     Kv0 = orc.kernel_matvec(xd, gd, tp, sig, lam, v, use_E_cstr)
     assert np.abs(Kv - Kv0).max() <= 1e-11 * np.abs(Kv0).max()
+
+
+def test_ase_calculator_with_stub_ase(golden, tmp_path, monkeypatch):
+    """SGDMLCalculator (reference intf/ase_calc.py) through a minimal stand-in for ASE: unit handling and
+    the results dictionary, single-geometry path."""
+    import importlib
+    import sys
+    import types
+
+    g = golden
+    if 'lattice' in g:
+        pytest.skip('calculator test uses the non-periodic fixtures')
+    ase = types.ModuleType('ase')
+    calcs = types.ModuleType('ase.calculators')
+    calc = types.ModuleType('ase.calculators.calculator')
+    units = types.ModuleType('ase.units')
+
+    class Calculator:
+        def __init__(self, *a, **k):
+            self.results = {}
+
+        def calculate(self, atoms=None, *a, **k):
+            self.atoms = atoms
+
+    calc.Calculator = Calculator
+    units.kcal, units.mol = 2.611447418269555e22, 6.022140857e23
+    for name, mod in (('ase', ase), ('ase.calculators', calcs), ('ase.calculators.calculator', calc), ('ase.units', units)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    sys.modules.pop('sgdml_amd.intf.ase_calc', None)
+    mod = importlib.import_module('sgdml_amd.intf.ase_calc')
+
+    m = _model(g)
+    m.update(type='m', z=np.ones(g['R_train'].shape[1], dtype=int) * 6, perms=g['perms'])
+    path = tmp_path / 'model.npz'
+    np.savez(path, **m)
+
+    class Atoms:
+        def __init__(self, pos):
+            self._p = pos
+
+        def get_positions(self):
+            return self._p
+
+    c = mod.SGDMLCalculator(str(path))
+    try:
+        pos = g['R_test'][0].reshape(-1, 3)
+        c.calculate(Atoms(pos))
+        k = units.kcal / units.mol
+        fl = cancel_floor(g)
+        assert abs(c.results['energy'] - g['E_test'][0] * k) <= (1e-10 * max(1.0, abs(g['E_test'][0])) + fl * float(g['sig'])) * k
+        assert np.abs(c.results['forces'] - g['F_test'][0].reshape(-1, 3) * k).max() <= (1e-10 * np.abs(g['F_test']).max() + fl) * k
+    finally:
+        del c.gdml_predict
+    sys.modules.pop('sgdml_amd.intf.ase_calc', None)
