@@ -93,6 +93,18 @@ def i64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.int64)
 
 
+def _digest(a):
+    """Content fingerprint of a contiguous array (xxhash when present, else md5)."""
+    try:
+        import xxhash
+
+        return xxhash.xxh64(memoryview(a).cast('B')).hexdigest()
+    except ImportError:  # pragma: no cover
+        import hashlib
+
+        return hashlib.md5(memoryview(a).cast('B')).hexdigest()
+
+
 def tril_perms_from_lin(tril_perms_lin, dim_d):
     """Undo the linearisation of sgdml/train.py:903-904: returns the (P,D) int64 table."""
     lin = np.asarray(tril_perms_lin, dtype=np.int64).ravel()
@@ -208,8 +220,15 @@ class Context(object):
         n_atoms = int((1 + np.sqrt(8 * D + 1)) / 2)
         if R_d_desc.shape != (M, D, 3):
             raise ValueError('R_d_desc must be the compressed (M,D,3) Jacobian')
+        # the training set (descriptors, Jacobians, permutations and the dense tables derived from them on
+        # the device) is sigma-independent: a hyper-parameter sweep over the same points uploads it once
+        fp = (R_desc.shape, tril_perms.shape, _digest(R_desc), _digest(R_d_desc), _digest(tril_perms))
+        if getattr(self, '_train_fp', None) == fp:
+            return
+        self._train_fp = None
         self._check(self._lib.gdml_train_upload(self._h, _ptr(R_desc), _ptr(R_d_desc), M, n_atoms,
                                                 _ptr(tril_perms), tril_perms.shape[0]))
+        self._train_fp = fp
         self.n_train, self.n_atoms = M, n_atoms
 
     def assemble_K(self, sig, use_E_cstr=False, points=None, idx=None, alloc_extra_rows=0, to_host=False):
