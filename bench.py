@@ -127,6 +127,8 @@ def main():
     ap.add_argument('--lam', type=float, default=1e-10)
     ap.add_argument('--cpu-sample', type=int, default=100, help='training points of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
+    ap.add_argument('--separate-solve', action='store_true',
+                    help='A/B: forward substitution as a separate triangular solve instead of inside the factorisation')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -187,9 +189,16 @@ def main():
     info_last = [0]
 
     def step(record):
-        ctx.assemble_K(sig, False)
-        info_last[0] = ctx.chol_factor(args.lam)
-        alphas = ctx.chol_solve(y)
+        # the calls of sgdml_amd.solvers.analytic.Analytic.solve
+        if args.separate_solve:
+            ctx.assemble_K(sig, False)
+            info_last[0] = ctx.chol_factor(args.lam)
+            alphas = ctx.chol_solve(y)
+        else:
+            ctx.assemble_K(sig, False, alloc_extra_rows=1)
+            ctx.chol_set_rhs(y)
+            info_last[0] = ctx.chol_factor(args.lam)
+            alphas = ctx.chol_solve(None)
         # model for prediction: J alpha on the device (training-set Jacobians are resident)
         if step.first:
             ctx.predict_upload_model(xd, np.zeros_like(xd), tp, sig, None)

@@ -122,7 +122,13 @@ int gdml_K_shape(gdml_ctx* ctx, int64_t* n_rows, int64_t* n_cols, int64_t* extra
  *   the function then returns GDML_ERR_NOT_PD and K is destroyed (re-assemble to retry).
  * gdml_chol_solve: alphas = -(A^-1 y)   (analytic.py:97-99).
  * n_refine > 0 adds that many steps of iterative refinement with the matrix-free kernel
- * operator (needs the training set of gdml_train_upload; 0 = exactly LAPACK semantics). */
+ * operator (needs the training set of gdml_train_upload; 0 = exactly LAPACK semantics).
+ * gdml_chol_set_rhs (optional, between gdml_assemble_K(..., alloc_extra_rows >= 1) and
+ *   gdml_chol_factor): hands the right-hand side over before the factorisation.  y is carried as an extra
+ *   row of the matrix, so the panel solves and trailing updates of the factorisation perform the forward
+ *   substitution L z = y on the way (cho_solve's first triangular solve, analytic.py:97, for free);
+ *   gdml_chol_solve(y = NULL) then only runs the backward substitution. */
+int gdml_chol_set_rhs(gdml_ctx* ctx, const double* y, int64_t n);
 int gdml_chol_factor(gdml_ctx* ctx, double lam, int* info);
 int gdml_chol_solve(gdml_ctx* ctx, const double* y, int64_t n, int n_refine, double* alphas_out);
 

@@ -33,6 +33,7 @@ SIGNATURES = {
     'gdml_assemble_K': (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64,
                                   C.c_int64, _vp, C.c_int64]),
     'gdml_K_shape': (C.c_int, [_vp, _ip, _ip, _ip]),
+    'gdml_chol_set_rhs': (C.c_int, [_vp, _vp, C.c_int64]),
     'gdml_chol_factor': (C.c_int, [_vp, C.c_double, C.POINTER(C.c_int)]),
     'gdml_chol_solve': (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp]),
     'gdml_predict_upload_model': (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_double, _vp]),
@@ -276,7 +277,18 @@ class Context(object):
         self._check(self._lib.gdml_chol_factor(self._h, float(lam), C.byref(info)))
         return info.value
 
-    def chol_solve(self, y, n_refine=0):
+    def chol_set_rhs(self, y):
+        """Hands y over before chol_factor (K must have been assembled with alloc_extra_rows >= 1): the
+        factorisation then performs the forward substitution and chol_solve(None) only the backward one."""
+        y = f64(y).ravel()
+        self._check(self._lib.gdml_chol_set_rhs(self._h, _ptr(y), y.size))
+
+    def chol_solve(self, y=None, n_refine=0):
+        if y is None:
+            n = self.K_shape()[0]
+            out = np.empty(n)
+            self._check(self._lib.gdml_chol_solve(self._h, None, n, int(n_refine), _ptr(out)))
+            return out
         y = f64(y).ravel()
         out = np.empty_like(y)
         self._check(self._lib.gdml_chol_solve(self._h, _ptr(y), y.size, int(n_refine), _ptr(out)))

@@ -664,6 +664,7 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
   ctx->K_extra = alloc_extra_rows;
   ctx->K_ld = ld;
   ctx->K_factored = false;
+  ctx->K_rhs_row = false;
   ctx->K_sig = sig;
   ctx->K_use_E = use_E_cstr;
 

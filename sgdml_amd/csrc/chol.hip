@@ -501,7 +501,10 @@ static int chol_factor_split(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, in
   return GDML_OK;
 }
 
-int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out) {
+// n: order of the matrix; n_rows >= n: rows n..n_rows-1 are carried along (right-hand sides stored as extra
+// rows: they go through the panel solves and trailing updates, i.e. through the forward substitution)
+int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out, int64_t n_rows) {
+  if (n_rows < n) n_rows = n;
   HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   static int64_t NB = 0;  // outer panel width (GDML_CHOL_NB overrides; multiple of 64)
   if (NB == 0) {
@@ -517,7 +520,7 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
       const char* c = getenv("GDML_CHOL_AUX_CUS");
       if (c) aux_cus = atoi(c);
     }
-    if (split && n > 4 * NB && getenv("GDML_NO_LOOKAHEAD") == nullptr) {
+    if (split && n_rows == n && n > 4 * NB && getenv("GDML_NO_LOOKAHEAD") == nullptr) {
       GDML_TRY(chol_factor_split(ctx, A, n, ld, NB, aux_cus));
       HIP_CHECK(ctx, hipGetLastError());
       int info = 0;
@@ -541,10 +544,11 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
     if (c) mask_cus = atoi(c);
   }
   bool masked = false;
-  GDML_TRY(panel_factor(ctx, sm, A, n, ld, 0, n < NB ? n : NB));
+  GDML_TRY(panel_factor(ctx, sm, A, n_rows, ld, 0, n < NB ? n : NB));
   for (int64_t k0 = 0; k0 < n; k0 += NB) {
     const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
     const int64_t t0 = k0 + nb;
+    if (t0 >= n_rows) break;
     if (t0 >= n) break;
     if (lookahead && !masked && mask_rows > 0 && n - t0 < mask_rows) {
       GDML_TRY(ctx_masked_streams(ctx, mask_cus));
@@ -559,22 +563,22 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
     const int64_t t1 = t0 + nb2;
     const double* P = A + t0 * ld + k0;  // rows t0.. of panel k
     // (1) next panel's columns: C[t0:n, t0:t1] -= P[t0:n] P[t0:t1]^T
-    GDML_TRY(launch_gemm_nt_sub(ctx, sm, P, ld, P, ld, A + t0 * ld + t0, ld, n - t0, nb2, nb, 0));
+    GDML_TRY(launch_gemm_nt_sub(ctx, sm, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, nb2, nb, 0));
     if (lookahead) {
       HIP_CHECK(ctx, hipEventRecord(evA, sm));
       HIP_CHECK(ctx, hipStreamWaitEvent(sp, evA, 0));
-      GDML_TRY(panel_factor(ctx, sp, A, n, ld, t0, nb2));
+      GDML_TRY(panel_factor(ctx, sp, A, n_rows, ld, t0, nb2));
       HIP_CHECK(ctx, hipEventRecord(evB, sp));
     }
     // (2) rest of the trailing matrix: C[t1:n, t1:n] -= P[t1:n] P[t1:n]^T  (lower)
     if (t1 < n) {
       const double* P1 = A + t1 * ld + k0;
-      GDML_TRY(launch_gemm_nt_sub(ctx, sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, n - t1, n - t1, nb, 1));
+      GDML_TRY(launch_gemm_nt_sub(ctx, sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1));
     }
     if (lookahead)
       HIP_CHECK(ctx, hipStreamWaitEvent(sm, evB, 0));
     else
-      GDML_TRY(panel_factor(ctx, sm, A, n, ld, t0, nb2));
+      GDML_TRY(panel_factor(ctx, sm, A, n_rows, ld, t0, nb2));
   }
   if (masked) {  // join the masked pair back into the context's main stream
     if (ctx->profiling) {
@@ -689,8 +693,7 @@ __global__ void __launch_bounds__(256) trsv_bwd_kernel(const double* __restrict_
 }
 
 // d_b: right-hand side (destroyed), d_z: scratch (n), d_x: solution (n).  All device vectors.
-int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_b,
-                      double* d_z, double* d_x) {
+static int chol_fwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_b, double* d_z) {
   for (int64_t c0 = 0; c0 < n; c0 += 64) {
     int w = (int)((n - c0 < 64) ? n - c0 : 64);
     int64_t rows = n - c0 - w;
@@ -701,6 +704,11 @@ int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, dou
                        d_z);
     ctx->launch_counter++;
   }
+  return GDML_OK;
+}
+
+// d_z is destroyed
+static int chol_bwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_z, double* d_x) {
   int64_t last = ((n - 1) / 64) * 64;
   for (int64_t c0 = last; c0 >= 0; c0 -= 64) {
     int w = (int)((n - c0 < 64) ? n - c0 : 64);
@@ -715,7 +723,32 @@ int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, dou
   return GDML_OK;
 }
 
+int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_b,
+                      double* d_z, double* d_x) {
+  GDML_TRY(chol_fwd_device(ctx, L, n, ld, d_b, d_z));
+  return chol_bwd_device(ctx, L, n, ld, d_z, d_x);
+}
+
 // ------------------------------------------------------------------------------------------
+extern "C" int gdml_chol_set_rhs(gdml_ctx* ctx, const double* y, int64_t n) {
+  if (!ctx || !y) return GDML_ERR_INVALID;
+  if (!ctx->K || ctx->K_rows != ctx->K_cols)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_set_rhs: assemble a square K first");
+  if (ctx->K_factored) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_set_rhs: K is already factored");
+  if (ctx->K_extra < 1)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_set_rhs: K was assembled without an extra row");
+  if (n != ctx->K_rows) return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_chol_set_rhs: n mismatch");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (ctx->d_rhs) GDML_TRY(ctx_free(ctx, ctx->d_rhs));
+  ctx->d_rhs = nullptr;
+  GDML_TRY(ctx_alloc(ctx, (void**)&ctx->d_rhs, n * 8));
+  HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_rhs, y, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(ctx, hipMemcpyAsync(ctx->K + n * ctx->K_ld, ctx->d_rhs, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // y is a pageable host array owned by the caller
+  ctx->K_rhs_row = true;
+  return GDML_OK;
+}
+
 extern "C" int gdml_chol_factor(gdml_ctx* ctx, double lam, int* info) {
   if (!ctx) return GDML_ERR_INVALID;
   if (!ctx->K) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_factor: assemble K first");
@@ -730,7 +763,7 @@ extern "C" int gdml_chol_factor(gdml_ctx* ctx, double lam, int* info) {
                      ctx->K_ld, lam);
   ctx->launch_counter++;
   int inf = 0;
-  GDML_TRY(chol_factor_device(ctx, ctx->K, n, ctx->K_ld, &inf));
+  GDML_TRY(chol_factor_device(ctx, ctx->K, n, ctx->K_ld, &inf, ctx->K_rhs_row ? n + 1 : n));
   GDML_TRY(phase_end(ctx, "factor"));
   if (info) *info = inf;
   ctx->K_lam = lam;
@@ -764,9 +797,11 @@ int operator_model_from_trainset(gdml_ctx* ctx, double sig);
 
 extern "C" int gdml_chol_solve(gdml_ctx* ctx, const double* y, int64_t n, int n_refine,
                                double* alphas_out) {
-  if (!ctx || !y || !alphas_out) return GDML_ERR_INVALID;
+  if (!ctx || !alphas_out) return GDML_ERR_INVALID;
   if (!ctx->K || !ctx->K_factored)
     return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_solve: no Cholesky factor resident");
+  if (!y && !ctx->K_rhs_row)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_solve(y = NULL) needs gdml_chol_set_rhs before the factorisation");
   if (n != ctx->K_rows) return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_chol_solve: n mismatch");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   void* buf = nullptr;
@@ -778,12 +813,20 @@ extern "C" int gdml_chol_solve(gdml_ctx* ctx, const double* y, int64_t n, int n_
   double* dr = dz + n;         // refinement correction
   double* dkv = dr + n;        // K x - lam x
   int rc = GDML_OK;
-  hipError_t e = hipMemcpyAsync(dy, y, n * 8, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(db, dy, n * 8, hipMemcpyDeviceToDevice, ctx->stream);
+  hipError_t e;
+  if (y) {
+    e = hipMemcpyAsync(dy, y, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db, dy, n * 8, hipMemcpyDeviceToDevice, ctx->stream);
+  } else {  // forward substitution already done by the factorisation: z is row n of the factor buffer
+    e = hipMemcpyAsync(dy, ctx->d_rhs, n * 8, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(dz, ctx->K + n * ctx->K_ld, n * 8, hipMemcpyDeviceToDevice, ctx->stream);
+  }
   if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "copy: %s", hipGetErrorString(e));
   if (rc == GDML_OK) {
     phase_begin(ctx);
-    rc = chol_solve_device(ctx, ctx->K, n, ctx->K_ld, db, dz, dx);
+    rc = y ? chol_solve_device(ctx, ctx->K, n, ctx->K_ld, db, dz, dx)
+           : chol_bwd_device(ctx, ctx->K, n, ctx->K_ld, dz, dx);
   }
   if (rc == GDML_OK && n_refine > 0) rc = operator_model_from_trainset(ctx, ctx->K_sig);
   for (int it = 0; rc == GDML_OK && it < n_refine; ++it) {

@@ -90,6 +90,8 @@ struct gdml_ctx {
   double* K = nullptr;
   int64_t K_rows = 0, K_cols = 0, K_extra = 0, K_ld = 0, K_bytes = 0;
   bool K_factored = false;
+  bool K_rhs_row = false;   // row K_rows of the buffer carries a right-hand side (gdml_chol_set_rhs)
+  double* d_rhs = nullptr;  // device copy of that right-hand side (iterative refinement)
   double K_lam = 0, K_sig = 0;
   int K_use_E = 0;
 
@@ -168,7 +170,7 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
 int set_alphas_device(gdml_ctx* ctx, const double* d_alphas_F, const double* d_alphas_E);
 int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, int64_t n,
                   double* d_out);
-int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info);
+int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info, int64_t n_rows = 0);
 int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_b,
                       double* d_z, double* d_x);
 int operator_model_from_trainset(gdml_ctx* ctx, double sig);

@@ -34,7 +34,11 @@ class Analytic(object):
             cb = partial(cb, disp_str='Assembling kernel matrix')
             cb(0, 100)
         start = timeit.default_timer()
-        ctx.assemble_K(sig, use_E_cstr)  # un-negated K, device resident (analytic.py:65)
+        # un-negated K, device resident (analytic.py:65); one spare row: the right-hand side rides along
+        # through the factorisation, whose panel solves and trailing updates then perform the forward
+        # substitution of cho_solve (analytic.py:97)
+        ctx.assemble_K(sig, use_E_cstr, alloc_extra_rows=1)
+        ctx.chol_set_rhs(y)
         if cb is not None:
             dur_s = timeit.default_timer() - start
             cb(DONE, sec_disp_str='took {:.1f} s'.format(dur_s) if dur_s >= 0.1 else '')
@@ -46,7 +50,7 @@ class Analytic(object):
         # numpy.linalg.LinAlgError here; the reference would retry with a dense LU
         # (analytic.py:101-114) -- there is deliberately no CPU fallback in this backend.
         ctx.chol_factor(lam)
-        alphas = ctx.chol_solve(y, n_refine=self.n_refine)  # = -A^-1 y (analytic.py:97-99)
+        alphas = ctx.chol_solve(None, n_refine=self.n_refine)  # backward substitution; = -A^-1 y (analytic.py:97-99)
 
         if self.callback is not None:
             dur_s = timeit.default_timer() - start

@@ -582,3 +582,37 @@ def test_ase_calculator_with_stub_ase(golden, tmp_path, monkeypatch):
     finally:
         del c.gdml_predict
     sys.modules.pop('sgdml_amd.intf.ase_calc', None)
+
+
+@pytest.mark.parametrize('n_atoms,M', [(5, 40), (7, 110)])
+def test_chol_rhs_row_matches_separate_solve(ctx_factory, n_atoms, M):
+    """gdml_chol_set_rhs: the right-hand side carried through the factorisation as an extra row gives the
+    same solution as the separate forward substitution (both to the solve tolerance 1e-8, and to each
+    other within the conditioning of the system); spans several panels (GDML_CHOL_NB default 512: n = 2310)."""
+    ds = orc.synth_dataset(n_atoms, M, seed=3)
+    Rf = ds['R'].reshape(M, -1)
+    tp = orc.tril_perms_from_atom_perms(np.arange(n_atoms)[None])
+    xd, gd = orc.desc_from_R(Rf)
+    sig, lam = 10.0, 1e-8
+    y = ds['F'].reshape(-1) / np.std(ds['F'])
+    c = ctx_factory()
+    c.train_upload(xd, gd, tp)
+    c.assemble_K(sig, False, alloc_extra_rows=1)
+    c.chol_set_rhs(y)
+    assert c.chol_factor(lam) == 0
+    a_fused = c.chol_solve(None)
+    a_sep = c.chol_solve(y)
+    K = orc.assemble_K(xd, gd, orc.tril_perms_lin_from_tril_perms(tp), sig)
+    A = -K + lam * np.eye(K.shape[0])
+    for a in (a_fused, a_sep):
+        assert np.linalg.norm(A @ (-a) - y) / np.linalg.norm(y) <= 1e-8
+    assert np.linalg.norm(a_fused - a_sep) <= 1e-6 * np.linalg.norm(a_sep)
+    # state errors
+    c2 = ctx_factory()
+    c2.train_upload(xd, gd, tp)
+    c2.assemble_K(sig, False)
+    with pytest.raises(Exception):
+        c2.chol_set_rhs(y)          # no spare row
+    c2.chol_factor(lam)
+    with pytest.raises(Exception):
+        c2.chol_solve(None)         # no right-hand side was handed over
