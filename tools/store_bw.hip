@@ -17,6 +17,21 @@ __global__ void seg_kernel(double* K, int64_t ld, int N3, int M, int ichunk, int
       for (int r = wave; r < N3; r += nw)
         if (lane < N3) K[(i * N3 + r) * ld + (j + jj) * N3 + lane] = (double)lane;
 }
+// non-temporal variants (streaming stores that should not allocate in L2 / MALL)
+__global__ void seg_nt_kernel(double* K, int64_t ld, int N3, int M, int ichunk, int nj) {
+  int64_t b = blockIdx.x;
+  int64_t x = b & 7, l = b >> 3; int64_t groups = nj / 8; int64_t per = groups / 8; int64_t j = (x * per + (l % per)) * 8; int64_t iy = l / per;
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int64_t i0 = iy * ichunk;
+  for (int64_t i = i0; i < i0 + ichunk && i < M; ++i)
+    for (int jj = 0; jj < 8; ++jj)
+      for (int r = wave; r < N3; r += nw)
+        if (lane < N3) __builtin_nontemporal_store((double)lane, &K[(i * N3 + r) * ld + (j + jj) * N3 + lane]);
+}
+__global__ void row8_nt_kernel(double* K, int64_t ld, int64_t n) {
+  int64_t r = blockIdx.x; double* row = K + r * ld;
+  for (int64_t c = threadIdx.x; c < n; c += blockDim.x) __builtin_nontemporal_store(1.0, &row[c]);
+}
 // mode 3: one wavefront per row point i (4 per workgroup), walks j in groups of J; inside a group the loop
 // is row-outer / j-inner, so J adjacent 504-byte segments of one matrix row are written back to back
 __global__ void seg_rowmajor_kernel(double* K, int64_t ld, int N3, int M, int J, int jchunk) {
@@ -74,6 +89,8 @@ int main() {
     T("seg xcd-remap 8j/WG", (seg_kernel<<<dim3(M / 8 * ny), 448>>>(K, ld, N3, M, ic, 2, M)));
     T("seg pairs 16B xcd-remap", (seg2_kernel<<<dim3(M / 2 * ny), 448>>>(K, ld, N3, M, ic, M / 2)));
     T("rows 8B", (row8_kernel<<<(unsigned)n, 256>>>(K, ld, n)));
+    T("rows 8B nontemporal", (row8_nt_kernel<<<(unsigned)n, 256>>>(K, ld, n)));
+    T("seg 8j/WG nontemporal", (seg_nt_kernel<<<dim3(M / 8 * ny), 448>>>(K, ld, N3, M, ic, M)));
     for (int W = 4; W <= 16; W *= 2) for (int sy = 0; sy < 2; ++sy) {
       char nm[64]; int jchunk = 64; int64_t nch = (M + jchunk - 1) / jchunk;
       snprintf(nm, 64, "WG/i, wave/j, W=%d sync=%d", W, sy);
