@@ -616,3 +616,96 @@ def test_chol_rhs_row_matches_separate_solve(ctx_factory, n_atoms, M):
     c2.chol_factor(lam)
     with pytest.raises(Exception):
         c2.chol_solve(None)         # no right-hand side was handed over
+
+
+def _device_rows(c, rows):
+    """Selected rows of the device-resident matrix (tests only)."""
+    import ctypes as C
+
+    n_rows, n_cols, extra = c.K_shape()
+    p, ld = C.c_void_p(), C.c_int64()
+    c._check(c._lib.gdml_K_dev(c._h, C.byref(p), C.byref(ld)))
+    out = np.empty((len(rows), n_cols))
+    buf = np.empty(ld.value)
+    for k, r in enumerate(rows):
+        src = C.c_void_p(p.value + int(r) * ld.value * 8)
+        c._check(c._lib.gdml_memcpy_d2h(c._h, buf.ctypes.data_as(C.c_void_p), src, buf.nbytes))
+        out[k] = buf[:n_cols]
+    return out
+
+
+def test_full_size_properties(ctx_factory):
+    """BASELINE.json configs[1] size (N=21, N_train=1000, n=63000), size-independent properties:
+    symmetry of K, agreement of the assembled rows with the matrix-free operator (two independent kernels:
+    K[r,:] v == (K v)[r]), linearity of the operator, and the round trip (-K + lam I) x = y through the
+    Cholesky path.  Tolerances: 1e-12 max|K| for entries, 1e-10 relative for operator identities, 1e-8 solve."""
+    N, M = 21, 1000
+    ds = orc.synth_dataset(N, M, seed=1, jitter=0.3)
+    Rf = ds['R'].reshape(M, -1)
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    c = ctx_factory()
+    xd, gd = c.desc_from_R(Rf, N)
+    sig, lam = 20.0, 1e-10
+    c.train_upload(xd, gd, tp)
+    c.assemble_K(sig, False, alloc_extra_rows=1)
+    n = M * 3 * N
+    rs = np.random.RandomState(0)
+    rows = np.sort(rs.choice(n, 6, replace=False))
+    Kr = _device_rows(c, rows)
+    # symmetry: K[r, c] == K[c, r] for the sampled rows against each other and against sampled columns
+    cols = np.sort(rs.choice(n, 5, replace=False))
+    Kc = _device_rows(c, cols)
+    scale = np.abs(Kr).max()
+    for a, r in enumerate(rows):
+        for b, cc in enumerate(cols):
+            assert abs(Kr[a, cc] - Kc[b, r]) <= 1e-12 * scale
+    # a few blocks against the oracle
+    for r in rows[:2]:
+        i = r // (3 * N)
+        blk = orc.assemble_K(xd[[i, 0, M - 1]], gd[[i, 0, M - 1]], orc.tril_perms_lin_from_tril_perms(tp), sig)
+        assert np.abs(Kr[list(rows).index(r), :3 * N] - blk[r - i * 3 * N, 3 * N:6 * N]).max() <= 1e-12 * scale
+    # assembled rows vs the matrix-free operator
+    c.predict_upload_model(xd, np.zeros_like(xd), tp, sig, None)
+    v = rs.normal(size=n)
+    w = rs.normal(size=n)
+    Kv = c.kernel_matvec(0.0, False, v)
+    assert np.abs(Kr @ v - Kv[rows]).max() <= 1e-10 * np.abs(Kv).max()
+    Kw = c.kernel_matvec(0.0, False, w)
+    Kvw = c.kernel_matvec(0.0, False, 2.0 * v - 3.0 * w)
+    assert np.abs(Kvw - (2.0 * Kv - 3.0 * Kw)).max() <= 1e-10 * np.abs(Kvw).max()
+    # round trip through the factorisation (right-hand side carried as the extra row)
+    y = ds['F'].reshape(-1) / np.std(ds['F'])
+    c.chol_set_rhs(y)
+    assert c.chol_factor(lam) == 0
+    x = -c.chol_solve(None)
+    Ax = -c.kernel_matvec(lam, False, x)  # (-K + lam I) x
+    assert np.linalg.norm(Ax - y) / np.linalg.norm(y) <= 1e-8
+
+
+def test_smallest_sizes_and_empty_batch(ctx_factory):
+    """Edge cases: two atoms / one training point, empty query batch, a single query given as a 1-D array."""
+    for N, M, P in ((2, 1, 1), (3, 2, 2), (2, 3, 2)):
+        ds = orc.synth_dataset(N, M + 2, seed=N + M)
+        Rf = ds['R'].reshape(M + 2, -1)
+        perms = np.arange(N)[None]
+        if P == 2:
+            perms = np.vstack([perms, perms[0][::-1] if N == 2 else np.array([1, 0, 2])])
+        tp = orc.tril_perms_from_atom_perms(perms)
+        xd, gd = orc.desc_from_R(Rf[:M])
+        c = ctx_factory()
+        x2, g2 = c.desc_from_R(Rf[:M], N)
+        assert np.abs(x2 - xd).max() <= 1e-14 * np.abs(xd).max() and np.abs(g2 - gd).max() <= 1e-14 * np.abs(gd).max()
+        c.train_upload(xd, gd, tp)
+        K = c.assemble_K(5.0, False, to_host=True)
+        K0 = orc.assemble_K(xd, gd, orc.tril_perms_lin_from_tril_perms(tp), 5.0)
+        assert np.abs(K - K0).max() <= 1e-12 * np.abs(K0).max()
+        ja = np.random.RandomState(1).normal(size=xd.shape)
+        c.predict_upload_model(xd, ja, tp, 5.0, None)
+        E, F = c.predict(Rf[M:])
+        rq, rdq = orc.desc_from_R(Rf[M:])
+        E0, F0 = orc.predict_from_desc(rq, rdq, xd, ja, tp, 5.0, None)
+        assert np.abs(F - F0).max() <= 1e-11 * max(np.abs(F0).max(), 1e-300)
+        E1, F1 = c.predict(Rf[M])  # single geometry, 1-D
+        assert F1.shape == (1, 3 * N) and np.abs(F1[0] - F[0]).max() <= 1e-14 * max(np.abs(F[0]).max(), 1e-300)
+        E_, F_ = c.predict(np.empty((0, 3 * N)))
+        assert E_.shape == (0,) and F_.shape == (0, 3 * N)
