@@ -307,13 +307,36 @@ __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int
   for (int j = 0; j < 64; ++j) {
     const double d = __shfl(row[j], j, 64);
     if (!(d > 0.0) && fail == 0) fail = j + 1;
-    const double dj = sqrt(d);
-    const double lr = row[j] / dj;
+    // 1/sqrt(d): hardware estimate + two Newton steps (full double precision), then one multiply per lane
+    // instead of a correctly rounded sqrt and a division on the 64-step critical path
+    double ri = __builtin_amdgcn_rsq(d);
+    ri = ri * (1.5 - 0.5 * d * ri * ri);
+    ri = ri * (1.5 - 0.5 * d * ri * ri);
+    const double dj = d * ri;
+    const double lr = row[j] * ri;
     row[j] = (lane == j) ? dj : lr;
     col[lane] = lr;
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    {
+      const d2* col2 = reinterpret_cast<const d2*>(col);
+      const int c0 = (j + 1) | 1;  // first odd column >= j + 1 ... pairs (c0 + 1, c0 + 2) are 16-byte aligned
+      if (((j + 1) & 1) == 0 && j + 1 < 64) {  // j + 1 even: pair (j + 1, j + 2) is aligned already
 #pragma unroll
-    for (int c = j + 1; c < 64; ++c) row[c] -= lr * col[c];
+        for (int c = j + 1; c < 64; c += 2) {
+          const d2 cc = col2[c >> 1];
+          row[c] -= lr * cc.x;
+          row[c + 1] -= lr * cc.y;
+        }
+      } else if (j + 1 < 64) {  // j + 1 odd: one single column, then aligned pairs
+        row[c0] -= lr * col[c0];
+#pragma unroll
+        for (int c = c0 + 1; c < 64; c += 2) {
+          const d2 cc = col2[c >> 1];
+          row[c] -= lr * cc.x;
+          row[c + 1] -= lr * cc.y;
+        }
+      }
+    }
   }
   if (fail != 0 && fail <= w && lane == 0) atomicCAS(info, 0, (int)(global_off + fail));
 #pragma unroll
