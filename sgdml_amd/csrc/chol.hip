@@ -363,6 +363,9 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
     Ls[e] = v;
   }
   __syncthreads();
+  __shared__ double rinv[64];  // reciprocals of the diagonal: 64 divisions per workgroup instead of 64 per row
+  if (tid < 64) rinv[tid] = 1.0 / Ls[tid * 64 + tid];
+  __syncthreads();
   const int64_t r = (int64_t)blockIdx.x * 256 + tid;
   if (r >= m) return;
   double* xr = X + r * ld;
@@ -384,7 +387,7 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
     double s = x[c];
 #pragma unroll
     for (int k = 0; k < c; ++k) s -= x[k] * Ls[c * 64 + k];
-    x[c] = s / Ls[c * 64 + c];
+    x[c] = s * rinv[c];
   }
   if (al16) {
 #pragma unroll
