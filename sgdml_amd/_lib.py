@@ -116,6 +116,8 @@ def tril_perms_from_lin(tril_perms_lin, dim_d):
 class Context(object):
     """One gdml_ctx (one GPU, own streams and device buffers)."""
 
+    max_query_batch = 1 << 17  # queries per gdml_predict call (bounds the device work buffers)
+
     def __init__(self, device=None):
         self._h = None
         lib = load()
@@ -320,7 +322,16 @@ class Context(object):
         lat = lat_inv = None
         if lat_and_inv is not None:
             lat, lat_inv = f64(lat_and_inv[0]), f64(lat_and_inv[1])
-        self._check(self._lib.gdml_predict(self._h, _ptr(R), B, _ptr(lat), _ptr(lat_inv), _ptr(E), _ptr(F)))
+        if R is None or B <= self.max_query_batch:
+            self._check(self._lib.gdml_predict(self._h, _ptr(R), B, _ptr(lat), _ptr(lat_inv), _ptr(E), _ptr(F)))
+            return E, F
+        # very large batches go through in slices so that the device work buffers stay bounded (the reference's
+        # GPU path re-batches instead of failing as well, torchtools.py:349-387)
+        for b0 in range(0, B, self.max_query_batch):
+            b1 = min(B, b0 + self.max_query_batch)
+            Ec = None if E is None else E[b0:b1]
+            self._check(self._lib.gdml_predict(self._h, _ptr(R[b0:b1]), b1 - b0, _ptr(lat), _ptr(lat_inv), _ptr(Ec),
+                                               _ptr(F[b0:b1])))
         return E, F
 
     def predict_errors(self, R, F_ref, E_ref=None, std=1.0, c=0.0, lat_and_inv=None):

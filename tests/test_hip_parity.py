@@ -709,3 +709,21 @@ def test_smallest_sizes_and_empty_batch(ctx_factory):
         assert F1.shape == (1, 3 * N) and np.abs(F1[0] - F[0]).max() <= 1e-14 * max(np.abs(F[0]).max(), 1e-300)
         E_, F_ = c.predict(np.empty((0, 3 * N)))
         assert E_.shape == (0,) and F_.shape == (0, 3 * N)
+
+
+def test_predict_sliced_batches(golden, ctx_factory):
+    """Batches above Context.max_query_batch are sent in slices; the result is the same as one call."""
+    g = golden
+    m = _model(g)
+    tp = _tril_perms(g)
+    c = ctx_factory()
+    c.predict_upload_model(np.ascontiguousarray(m['R_desc'].T), m['R_d_desc_alpha'], tp, float(g['sig']), m.get('alphas_E'))
+    R = np.tile(g['R_test'].reshape(len(g['R_test']), -1), (3, 1))
+    E0, F0 = c.predict(R, _lat(g))
+    c.max_query_batch = 4
+    E1, F1 = c.predict(R, _lat(g))
+    fl = cancel_floor(g) / float(m['std'])  # slices pick other split counts: same sum, other order
+    assert np.abs(F0 - F1).max() <= 1e-12 * np.abs(F0).max() + fl
+    assert np.abs(E0 - E1).max() <= 1e-12 * max(1.0, np.abs(E0).max()) + fl * float(g['sig'])
+    _, F2 = c.predict(R, _lat(g), return_E=False)
+    assert np.array_equal(F1, F2)
