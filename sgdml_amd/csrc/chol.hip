@@ -733,8 +733,91 @@ static int chol_fwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld
   return GDML_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward substitution L^T x = z as ONE persistent launch (default for n >= 2048; GDML_TRSV_PERSIST=0
+// restores the per-block launches).  Left-looking: the workgroup that owns 64-block k accumulates
+//   s = sum_{c > k} L[c,k]^T x_c      (rows below the block, 512-byte row segments, 4 wavefronts over the blocks c)
+// as the x_c become available, then solves the transposed diagonal block and publishes x_k.  Blocks are
+// owned cyclically (from the bottom) by one workgroup per CU, all resident at once; availability is a
+// single counter `done` (= number of finished blocks from the bottom) in global memory, advanced with a
+// release after the solution block has been written, read with an acquire by the consumers (x crosses
+// XCDs, i.e. L2s).  A workgroup only ever waits for blocks owned by workgroups with a lower index, which
+// are dispatched first, so the schedule cannot deadlock; spins are bounded anyway and report through
+// `err` instead of hanging the GPU.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) trsv_bwd_persist_kernel(const double* __restrict__ L, int64_t ld,
+                                                               int64_t n, int nbk, const double* __restrict__ z,
+                                                               double* x, int* done, int* err) {
+  __shared__ __attribute__((aligned(16))) double Ls[64 * 65];
+  __shared__ double part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int kk = blockIdx.x; kk < nbk; kk += gridDim.x) {  // kk counts blocks from the bottom
+    const int k = nbk - 1 - kk;
+    const int64_t c0 = (int64_t)k * 64;
+    const int wk = (int)((n - c0 < 64) ? n - c0 : 64);
+    load_block64(L, ld, c0, wk, Ls, tid, 256);  // diagonal block (independent of x): overlaps the waiting
+    double acc = 0.0;
+    for (int cc = wv; cc < kk; cc += 4) {  // blocks below, bottom first; this wavefront takes every 4th
+      const int c = nbk - 1 - cc;
+      int spins = 0;
+      while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= cc) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 22)) {
+          if (lane == 0) atomicExch(err, 1);
+          break;
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);  // agent scope: x_c written by another XCD is visible now
+      const int64_t r0 = (int64_t)c * 64;
+      const int rows = (int)((n - r0 < 64) ? n - r0 : 64);
+      const double xv = (lane < rows) ? __hip_atomic_load(x + r0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      const double* Lp = L + r0 * ld + c0 + lane;
+      if (rows == 64 && lane < wk) {
+#pragma unroll 16
+        for (int i = 0; i < 64; ++i) acc += Lp[(int64_t)i * ld] * __shfl(xv, i, 64);
+      } else {
+        for (int i = 0; i < rows; ++i) {
+          const double xr = __shfl(xv, i, 64);
+          if (lane < wk) acc += Lp[(int64_t)i * ld] * xr;
+        }
+      }
+    }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0) {
+      const double s = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+      const double bi = lane < wk ? z[c0 + lane] - s : 0.0;
+      const double xi = tri_solve64_wave<true>(Ls, bi, lane);
+      if (lane < wk) __hip_atomic_store(x + c0 + lane, xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      if (lane == 0) __hip_atomic_store(done, kk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+}
+
 // d_z is destroyed
 static int chol_bwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_z, double* d_x) {
+  static int persist = -1;
+  if (persist < 0) {
+    const char* e = getenv("GDML_TRSV_PERSIST");
+    persist = e ? atoi(e) : 1;
+  }
+  if (persist && n >= 2048) {
+    const int nbk = (int)((n + 63) / 64);
+    int* done = ctx->d_info + 4;
+    int* err = ctx->d_info + 5;
+    HIP_CHECK(ctx, hipMemsetAsync(done, 0, 2 * sizeof(int), ctx->stream));
+    const int grid = nbk < ctx->num_cus ? nbk : ctx->num_cus;  // one workgroup per CU, all resident
+    hipLaunchKernelGGL(trsv_bwd_persist_kernel, dim3(grid), dim3(256), 0, ctx->stream, L, ld, n, nbk, d_z, d_x,
+                       done, err);
+    ctx->launch_counter++;
+    int h_err = 0;
+    HIP_CHECK(ctx, hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_err != 0) return gdml_fail(ctx, GDML_ERR_HIP, "backward substitution: a workgroup waited too long");
+    return GDML_OK;
+  }
   int64_t last = ((n - 1) / 64) * 64;
   for (int64_t c0 = last; c0 >= 0; c0 -= 64) {
     int w = (int)((n - c0 < 64) ? n - c0 : 64);
