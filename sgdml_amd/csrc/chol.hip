@@ -287,18 +287,9 @@ int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t l
 // scaled column is exchanged through a 64-entry LDS vector (broadcast reads).  Entries above the
 // diagonal are scratch.  info (device int): first failing pivot, global 1-based (LAPACK dpotrf).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
-                                                     int64_t global_off, int* __restrict__ info) {
-  __shared__ __attribute__((aligned(16))) double T[64 * 65];
-  __shared__ __attribute__((aligned(16))) double col[64];
-  const int lane = threadIdx.x;
-  // coalesced load into LDS, identity padding outside the w x w block
-  for (int r = 0; r < 64; ++r) {
-    double v = (r == lane) ? 1.0 : 0.0;
-    if (r < w && lane < w) v = A[(int64_t)r * ld + lane];
-    T[r * 65 + lane] = v;
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+// One wavefront factors the 64 x 64 tile in T (pitch 65, identity padding outside w x w) in registers:
+// lane = row.  Returns 0 or the 1-based index of the first non-positive pivot.
+__device__ __forceinline__ int potrf64_wave(double* T, double* col, int lane) {
   double row[64];
 #pragma unroll
   for (int c = 0; c < 64; ++c) row[c] = T[lane * 65 + c];
@@ -338,12 +329,114 @@ __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int
       }
     }
   }
-  if (fail != 0 && fail <= w && lane == 0) atomicCAS(info, 0, (int)(global_off + fail));
 #pragma unroll
   for (int c = 0; c < 64; ++c) T[lane * 65 + c] = row[c];
   __builtin_amdgcn_s_waitcnt(0xc07f);
+  return fail;
+}
+
+__global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
+                                                     int64_t global_off, int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double T[64 * 65];
+  __shared__ __attribute__((aligned(16))) double col[64];
+  const int lane = threadIdx.x;
+  // coalesced load into LDS, identity padding outside the w x w block
+  for (int r = 0; r < 64; ++r) {
+    double v = (r == lane) ? 1.0 : 0.0;
+    if (r < w && lane < w) v = A[(int64_t)r * ld + lane];
+    T[r * 65 + lane] = v;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  const int fail = potrf64_wave(T, col, lane);
+  if (fail != 0 && fail <= w && lane == 0) atomicCAS(info, 0, (int)(global_off + fail));
   for (int r = 0; r < w; ++r)
     if (lane <= r && lane < w) A[(int64_t)r * ld + lane] = T[r * 65 + lane];
+}
+
+// Fused step of the panel factorisation: every workgroup factors the diagonal block itself (one wavefront,
+// redundantly -- cheaper than a separate launch on the panel's dependent chain) and then solves its 256 rows
+// below against it.  The diagonal block cannot be written back in place by this launch (other workgroups are
+// still reading the unfactored block), so workgroup 0 saves L to `Lsave` and the NEXT launch of the chain (or
+// writeback_block_kernel at the end of the panel) stores it: nothing reads a factored diagonal block again
+// before the triangular solves.
+__global__ void __launch_bounds__(256) potrf_trsm64_kernel(double* __restrict__ A, double* __restrict__ X,
+                                                           int64_t ld, int w, int64_t m, int64_t global_off,
+                                                           int* __restrict__ info, double* __restrict__ Lsave,
+                                                           const double* __restrict__ Lprev,
+                                                           double* __restrict__ Aprev, int wprev) {
+  __shared__ __attribute__((aligned(16))) double T[64 * 65];
+  __shared__ __attribute__((aligned(16))) double Ls[64 * 64];
+  __shared__ __attribute__((aligned(16))) double col[64];
+  __shared__ double rinv[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && Lprev != nullptr) {  // deferred write-back of the previous diagonal block
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      if (r < wprev && c <= r) Aprev[(int64_t)r * ld + c] = Lprev[e];
+    }
+  }
+  for (int r = wave; r < 64; r += 4) {  // coalesced load, identity padding outside the w x w block
+    double v = (r == lane) ? 1.0 : 0.0;
+    if (r < w && lane < w) v = A[(int64_t)r * ld + lane];
+    T[r * 65 + lane] = v;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int fail = potrf64_wave(T, col, lane);
+    if (blockIdx.x == 0 && fail != 0 && fail <= w && lane == 0) atomicCAS(info, 0, (int)(global_off + fail));
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const double v = (c <= r) ? T[r * 65 + c] : 0.0;  // lower triangle incl. diagonal; identity padding kept
+    Ls[e] = v;
+    if (blockIdx.x == 0) Lsave[e] = v;
+  }
+  __syncthreads();
+  if (tid < 64) rinv[tid] = 1.0 / Ls[tid * 64 + tid];
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+  if (r >= m) return;
+  double* xr = X + r * ld;
+  double x[64];
+  const bool al16 = ((reinterpret_cast<uintptr_t>(xr) & 15) == 0) && (w == 64);
+  if (al16) {
+#pragma unroll
+    for (int c = 0; c < 64; c += 2) {
+      d2 v = *reinterpret_cast<const d2*>(xr + c);
+      x[c] = v.x;
+      x[c + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 64; ++c) x[c] = (c < w) ? xr[c] : 0.0;
+  }
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    double sacc = x[c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) sacc -= x[k] * Ls[c * 64 + k];
+    x[c] = sacc * rinv[c];
+  }
+  if (al16) {
+#pragma unroll
+    for (int c = 0; c < 64; c += 2) {
+      d2 v = {x[c], x[c + 1]};
+      *reinterpret_cast<d2*>(xr + c) = v;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 64; ++c)
+      if (c < w) xr[c] = x[c];
+  }
+}
+
+__global__ void __launch_bounds__(256) writeback_block_kernel(const double* __restrict__ Lprev,
+                                                              double* __restrict__ Aprev, int64_t ld, int wprev) {
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    if (r < wprev && c <= r) Aprev[(int64_t)r * ld + c] = Lprev[e];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -426,18 +519,48 @@ int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, in
 // Factor one panel: columns [k0, k0+nb), rows [k0, n), 64-wide sub-steps (potrf64 / trsm64 / K=64 gemm).
 static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0,
                         int64_t nb) {
+  static int fused = -1;  // GDML_PANEL_FUSED=0: separate potrf64 / trsm64 launches
+  if (fused < 0) {
+    const char* e = getenv("GDML_PANEL_FUSED");
+    fused = e ? atoi(e) : 1;
+  }
+  double* save = nullptr;  // two 64 x 64 slots for the deferred write-back of the diagonal blocks
+  if (fused) GDML_TRY(ctx_slot(ctx, 5, 2 * 4096 * 8, &save));
+  const double* Lprev = nullptr;
+  double* Aprev = nullptr;
+  int wprev = 0, flip = 0;
   for (int64_t jj = 0; jj < nb; jj += 64) {
     const int64_t c0 = k0 + jj;
     const int w = (int)((nb - jj < 64) ? nb - jj : 64);
     double* Ad = A + c0 * ld + c0;
-    hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(64), 0, st, Ad, ld, w, c0, ctx->d_info);
-    ctx->launch_counter++;
     const int64_t m = n - c0 - w;
+    if (fused && m > 0) {
+      double* X = A + (c0 + w) * ld + c0;
+      double* Lsave = save + flip * 4096;
+      hipLaunchKernelGGL(potrf_trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ad, X, ld, w, m,
+                         c0, ctx->d_info, Lsave, Lprev, Aprev, wprev);
+      ctx->launch_counter++;
+      Lprev = Lsave;
+      Aprev = Ad;
+      wprev = w;
+      flip ^= 1;
+    } else {
+      if (Lprev) {  // flush the pending diagonal block before a plain step
+        hipLaunchKernelGGL(writeback_block_kernel, dim3(1), dim3(256), 0, st, Lprev, Aprev, ld, wprev);
+        ctx->launch_counter++;
+        Lprev = nullptr;
+      }
+      hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(64), 0, st, Ad, ld, w, c0, ctx->d_info);
+      ctx->launch_counter++;
+      if (m > 0) {
+        double* X = A + (c0 + w) * ld + c0;
+        hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ad, X, ld,
+                           w, m);
+        ctx->launch_counter++;
+      }
+    }
     if (m > 0) {
       double* X = A + (c0 + w) * ld + c0;
-      hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ad, X, ld,
-                         w, m);
-      ctx->launch_counter++;
       const int64_t ncols = k0 + nb - (c0 + w);
       if (ncols > 0) {
         // rest of the panel:  C[c0+w:n, c0+w:k0+nb] -= X[c0+w:n, :] X[c0+w:k0+nb, :]^T
@@ -445,6 +568,10 @@ static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int
                                     w, 0));
       }
     }
+  }
+  if (Lprev) {
+    hipLaunchKernelGGL(writeback_block_kernel, dim3(1), dim3(256), 0, st, Lprev, Aprev, ld, wprev);
+    ctx->launch_counter++;
   }
   return GDML_OK;
 }
