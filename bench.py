@@ -150,6 +150,12 @@ def main():
                     help='A/B: forward substitution as a separate triangular solve instead of inside the factorisation')
     args = ap.parse_args()
 
+    # stdout carries exactly one line (the JSON): libraries that print banners to fd 1 (gloo's rank
+    # messages, RCCL's version block) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -317,7 +323,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
 
 
 if __name__ == '__main__':
