@@ -727,3 +727,33 @@ def test_predict_sliced_batches(golden, ctx_factory):
     assert np.abs(E0 - E1).max() <= 1e-12 * max(1.0, np.abs(E0).max()) + fl * float(g['sig'])
     _, F2 = c.predict(R, _lat(g), return_E=False)
     assert np.array_equal(F1, F2)
+
+
+def test_predict_mfma_randomised(ctx_factory, monkeypatch):
+    """Seeded random shapes (atoms, table size, batch, permutations, energy terms, sigma, coefficient scale):
+    the MFMA kernel against the wave kernel on identical inputs, 1e-11 relative (observed: < 3e-14)."""
+    rs = np.random.RandomState(123)
+    for trial in range(12):
+        N = int(rs.randint(3, 24)); M = int(rs.randint(5, 300)); B = int(rs.randint(256, 900))
+        P = int(rs.choice([1, 2])); with_aE = bool(rs.randint(0, 2)); sig = float(rs.choice([5.0, 12.0, 40.0]))
+        ds = orc.synth_dataset(N, M + B, seed=trial)
+        Rf = ds['R'].reshape(M + B, -1)
+        perms = np.arange(N)[None]
+        if P == 2:
+            p2 = np.arange(N)
+            p2[[0, 1]] = p2[[1, 0]]
+            perms = np.vstack([perms, p2])
+        tp = orc.tril_perms_from_atom_perms(perms)
+        xd, gd = orc.desc_from_R(Rf[:M])
+        ja = rs.normal(size=xd.shape) * 10.0 ** rs.uniform(-2, 4)
+        aE = rs.normal(size=M) if with_aE else None
+        c = ctx_factory()
+        c.predict_upload_model(xd, ja, tp, sig, aE)
+        monkeypatch.delenv('GDML_PREDICT_V1', raising=False)
+        E1, F1 = c.predict(Rf[M:])
+        monkeypatch.setenv('GDML_PREDICT_V1', '1')
+        E0, F0 = c.predict(Rf[M:])
+        monkeypatch.delenv('GDML_PREDICT_V1', raising=False)
+        assert np.abs(F1 - F0).max() <= 1e-11 * np.abs(F0).max(), (N, M, B, P, with_aE, sig)
+        assert np.abs(E1 - E0).max() <= 1e-11 * np.abs(E0).max(), (N, M, B, P, with_aE, sig)
+        c.close()
