@@ -133,3 +133,56 @@ def test_ase_calculator_optional_dependency():
     sys.modules.pop('sgdml_amd.intf.ase_calc', None)
     with pytest.raises(ImportError, match='Optional ASE dependency not found'):
         importlib.import_module('sgdml_amd.intf.ase_calc')
+
+
+def _toy_dataset(n=40, n_atoms=4, with_E=True, seed=0):
+    rs = np.random.RandomState(seed)
+    ds = {
+        'type': 'd', 'name': np.array('toy'), 'theory': np.array('none'), 'z': np.array([6, 1, 1, 8][:n_atoms]),
+        'R': rs.normal(size=(n, n_atoms, 3)), 'F': rs.normal(size=(n, n_atoms, 3)),
+    }
+    if with_E:
+        ds['E'] = rs.normal(size=n)
+    return ds
+
+
+def test_create_task_schema_and_sampling():
+    """Host logic of GDMLTrain.create_task (reference train.py:370-524): schema keys, disjoint train/valid
+    samples from one dataset, explicit permutations, singleton rule, error conventions.  No GPU involved."""
+    from sgdml_amd.train import GDMLTrain
+
+    ds = _toy_dataset()
+    perms = np.array([[0, 1, 2, 3], [0, 2, 1, 3]])
+    np.random.seed(0)
+    tr = GDMLTrain()
+    try:
+        with pytest.raises(Exception):
+            GDMLTrain()  # one instance per process (train.py:336-342)
+        task = tr.create_task(ds, 10, ds, 12, sig=10, lam=1e-8, perms=perms)
+        for key in ('type', 'code_version', 'dataset_name', 'dataset_theory', 'z', 'R_train', 'F_train', 'E_train',
+                    'idxs_train', 'md5_train', 'idxs_valid', 'md5_valid', 'sig', 'lam', 'use_E', 'use_E_cstr',
+                    'use_sym', 'perms'):
+            assert key in task, key
+        assert task['type'] == 't' and task['R_train'].shape == (10, 4, 3) and task['E_train'].shape == (10,)
+        assert len(set(task['idxs_train'])) == 10 and len(set(task['idxs_valid'])) == 12
+        assert not set(task['idxs_train']) & set(task['idxs_valid'])  # same dataset -> disjoint
+        assert task['md5_train'] == task['md5_valid']
+        assert np.array_equal(task['perms'], perms) and task['use_E_cstr'] is False
+        # use_sym=False -> identity only
+        t2 = tr.create_task(ds, 5, ds, 5, sig=10, use_sym=False)
+        assert np.array_equal(t2['perms'], np.arange(4)[None])
+        # energy constraints need energies; use_E=False drops them and forces use_E_cstr off
+        t3 = tr.create_task(_toy_dataset(with_E=False), 5, _toy_dataset(with_E=False, seed=1), 5, sig=10,
+                            use_E=False, use_E_cstr=True, use_sym=False)
+        assert 'E_train' not in t3 and t3['use_E_cstr'] is False
+        with pytest.raises(ValueError, match='No energy labels'):
+            tr.create_task(_toy_dataset(with_E=False), 5, ds, 5, sig=10)
+        with pytest.raises(ValueError, match='do not match the number of atoms'):
+            tr.create_task(ds, 5, ds, 5, sig=10, perms=np.arange(3)[None])
+        bad = dict(ds, lattice=np.zeros((3, 3)))
+        with pytest.raises(ValueError, match='invalid lattice'):
+            tr.create_task(bad, 5, ds, 5, sig=10, use_sym=False)
+    finally:
+        tr.__del__()
+    tr2 = GDMLTrain()  # the slot is free again after __del__ (train.py:363-368)
+    tr2.__del__()
