@@ -8,10 +8,12 @@
 // strict upper triangle is scratch and may be overwritten with garbage).
 //
 // Right-looking blocked algorithm, outer panel width NB (512), inner width 64:
-//   for each panel:   for each 64-wide sub-block:  potrf64 (one workgroup, LDS)
-//                                                  trsm64  (rows below, substitution in LDS)
+//   for each panel:   for each 64-wide sub-block:  potrf_trsm64 (diagonal block factored by one wavefront per
+//                                                               workgroup, then the rows below by substitution)
 //                                                  gemm_nt (K=64 update of the rest of the panel)
 //                     syrk: trailing -= P P^T with gemm_nt (K=NB) on v_mfma_f64_16x16x4_f64
+//   one panel of look-ahead on a second stream; a right-hand side stored as an extra row is carried through
+//   (forward substitution for free); the backward substitution is one persistent launch.
 // n^3/3 of the flops are in gemm_nt; everything else is O(n^2 NB).
 #include "common.h"
 

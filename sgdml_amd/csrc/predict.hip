@@ -10,7 +10,10 @@
 //   with alphas_E: F_x += aE_j b (n+sig) d ; E' += aE_j (1 + n/sig (1 + n/(3 sig))) exp(-n/sig)
 // and finally F = J_x^T F_x (desc.py:388-408).
 //
-// Kernel layout: the descriptor index k runs across the 64 lanes of a wavefront (KPL entries per
+// Three kernels, chosen by batch size (predict_device): predict_mfma_kernel<NT> for B >= 256 and D <= 256
+// (both contractions on v_mfma_f64_16x16x4_f64, see its header below), predict_bulk_kernel<NCH> (its VALU
+// predecessor, GDML_PREDICT_NO_MFMA=1) and predict_kernel<KPL,QB> for small batches / large D:
+// Layout of predict_kernel: the descriptor index k runs across the 64 lanes of a wavefront (KPL entries per
 // lane), so every table row is one coalesced read; each wavefront owns QB queries (held in
 // registers) and a contiguous split of the table rows, reduces |d|^2 and a with cross-lane
 // shuffles, and keeps its partial F_x in registers.  Partials of the splits are summed in a fixed
