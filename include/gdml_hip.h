@@ -77,6 +77,23 @@ int gdml_profile(gdml_ctx* ctx, int enable);
 int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t* launches_out,
                      double* work_out);
 
+/* Tuning / ablation options of a context (all have built-in defaults; nothing here changes results beyond
+ * rounding).  Read at the point of use, so a value set between two calls applies to the next call.  The
+ * library reads no environment variables except GDML_OPTIONS="key=value,..." (applied at gdml_ctx_create).
+ *   asm.wave (1)          register-resident assembly kernel for P = 1, N <= 21 (0: LDS kernel)
+ *   asm.lower (1)         analytic path: assemble only blocks on/below the diagonal, as -K + lam I
+ *   asm.threads, asm.ib, asm.minw, asm.gj_global, asm.j_chunk, asm.debug   LDS-kernel shape / ablations
+ *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
+ *   chol.nb (512), chol.lookahead (1), chol.panel_fused (1), chol.panel_kernel, chol.split (0), chol.aux_cus,
+ *   chol.mask_rows, chol.mask_cus, chol.panel_a, chol.panel_b, chol.gemm_tf     factorisation schedule
+ *   trsv.persist (1)      backward substitution as one persistent launch
+ *   predict.wave_only (0), predict.mfma (1), predict.mfma_wide (1), predict.fill   prediction kernel choice
+ *   lu.nb (64)            panel width of the LU fallback
+ *   comm.force_collectives (0)  issue collectives even for world == 1 without a communicator (tests)
+ * Unknown keys return GDML_ERR_INVALID. */
+int gdml_set_option(gdml_ctx* ctx, const char* key, double value);
+int gdml_get_option(gdml_ctx* ctx, const char* key, double* value_out, int* is_set_out);
+
 /* ---- descriptors  (replaces Desc.from_R, sgdml/utils/desc.py:288-365, :208-239) --------
  * R (M,3N) -> R_desc (M,D) = 1/|r_i - r_j|, R_d_desc (M,D,3) = (r_i - r_j)/d^3.
  * lat / lat_inv: 3x3 row-major lattice (columns = vectors) and its inverse, or both NULL;
@@ -206,6 +223,21 @@ int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const d
 int gdml_comm_unique_id(void* id128_out);
 int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world);
 int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out);
+
+/* Host-staged collectives: the same sharded algorithms with the two collectives delegated to the caller
+ * (e.g. torch.distributed's gloo backend).  The library copies the device buffer to pinned host memory,
+ * calls the callback, which must complete the collective IN PLACE on that host buffer, and copies it back.
+ *   allreduce(buf, count, user): buf[0:count] <- sum over ranks
+ *   allgather(buf, chunk, user): buf holds world*chunk doubles, rank r's contribution at [r*chunk, (r+1)*chunk)
+ * A non-zero return aborts the calling operation with GDML_ERR_COMM.  Used where RCCL cannot run: several
+ * ranks sharing one GPU (tests of the sharded code path on a one-GPU box), or a node without xGMI peers. */
+typedef int (*gdml_host_allreduce)(double* buf, int64_t count, void* user);
+typedef int (*gdml_host_allgather)(double* buf, int64_t chunk, void* user);
+int gdml_comm_init_host(gdml_ctx* ctx, int rank, int world, gdml_host_allreduce allreduce,
+                        gdml_host_allgather allgather, void* user);
+
+/* Collectives issued and payload bytes handed to them by this rank since the communicator was set up. */
+int gdml_comm_stats(gdml_ctx* ctx, int64_t* calls_out, double* bytes_out);
 
 /* ---- raw device buffers for callers that keep data resident -------------------------- */
 int gdml_dev_alloc(gdml_ctx* ctx, int64_t bytes, void** dev_out);

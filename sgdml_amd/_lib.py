@@ -15,6 +15,7 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
 _vp = C.c_void_p
 PCG_CB = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, _dp, _vp)
+HOST_COLL_CB = C.CFUNCTYPE(C.c_int, _dp, C.c_int64, _vp)  # gdml_host_allreduce / gdml_host_allgather
 
 # name -> (restype, argtypes).  Must list every symbol declared in include/gdml_hip.h.
 SIGNATURES = {
@@ -49,6 +50,10 @@ SIGNATURES = {
     'gdml_comm_unique_id': (C.c_int, [_vp]),
     'gdml_comm_init': (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     'gdml_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'gdml_comm_init_host': (C.c_int, [_vp, C.c_int, C.c_int, HOST_COLL_CB, HOST_COLL_CB, _vp]),
+    'gdml_comm_stats': (C.c_int, [_vp, _ip, _dp]),
+    'gdml_set_option': (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    'gdml_get_option': (C.c_int, [_vp, C.c_char_p, _dp, C.POINTER(C.c_int)]),
     'gdml_dev_alloc': (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
     'gdml_dev_free': (C.c_int, [_vp, _vp]),
     'gdml_memcpy_h2d': (C.c_int, [_vp, _vp, _vp, C.c_int64]),
@@ -180,6 +185,45 @@ class Context(object):
         """unique_id=None creates a 'virtual rank' (shard arithmetic, no collectives; tests only)."""
         self._check(self._lib.gdml_comm_init(self._h, unique_id, int(rank), int(world)))
 
+    def comm_init_host(self, rank, world, allreduce, allgather):
+        """Host-staged collectives (gdml_comm_init_host).  allreduce(buf) / allgather(buf, chunk) receive a
+        float64 NumPy view of the pinned staging buffer and must complete the collective in place."""
+        def _ar(p, count, _user):
+            try:
+                allreduce(np.ctypeslib.as_array(p, shape=(count,)))
+                return 0
+            except BaseException as e:  # never let an exception cross the C frame
+                self._coll_exc = e
+                return 1
+
+        def _ag(p, chunk, _user):
+            try:
+                allgather(np.ctypeslib.as_array(p, shape=(chunk * world,)), int(chunk))
+                return 0
+            except BaseException as e:
+                self._coll_exc = e
+                return 1
+
+        self._coll_cbs = (HOST_COLL_CB(_ar), HOST_COLL_CB(_ag))  # keep the thunks alive
+        self._check(self._lib.gdml_comm_init_host(self._h, int(rank), int(world), self._coll_cbs[0],
+                                                  self._coll_cbs[1], None))
+
+    def comm_stats(self):
+        """(collectives issued, payload bytes handed to them by this rank)."""
+        n, b = C.c_int64(), C.c_double()
+        self._check(self._lib.gdml_comm_stats(self._h, C.byref(n), C.byref(b)))
+        return n.value, b.value
+
+    def set_option(self, key, value):
+        """Tuning / ablation option of this context (keys: include/gdml_hip.h)."""
+        self._check(self._lib.gdml_set_option(self._h, key.encode(), float(value)))
+
+    def get_option(self, key):
+        """Value of an option, or None when it was never set (built-in default applies)."""
+        v, is_set = C.c_double(), C.c_int()
+        self._check(self._lib.gdml_get_option(self._h, key.encode(), C.byref(v), C.byref(is_set)))
+        return v.value if is_set.value else None
+
     def comm_info(self):
         r, w = C.c_int(), C.c_int()
         self._check(self._lib.gdml_comm_info(self._h, C.byref(r), C.byref(w)))
@@ -259,6 +303,15 @@ class Context(object):
         self._check(self._lib.gdml_assemble_K(self._h, float(sig), int(bool(use_E_cstr)), kind, a, b, ip,
                                               n_idx, int(alloc_extra_rows), _ptr(K), n_cols))
         return K
+
+    def resident_K_bytes(self):
+        """Bytes of the kernel-matrix buffer the context keeps for reuse (0 if none)."""
+        try:
+            rows, cols, extra = self.K_shape()
+        except GDMLHipError:
+            return 0
+        ld = (cols + 15) // 16 * 16
+        return (rows + extra) * ld * 8
 
     def K_shape(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()

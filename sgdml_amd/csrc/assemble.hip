@@ -471,15 +471,10 @@ static size_t asm_lds_bytes(int N, int D, int IB, bool gjg = false) {
   return dbl * 8 + ints * 4 + 16;
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   const int N = A.N, D = A.D;
   static const int acs[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
-  const int t_target = env_int("GDML_ASM_T", 256);
+  const int t_target = ctx_opt_i(ctx, "asm.threads", 256);
   int AC = 32;
   for (int v : acs) {
     int items = ((N + v - 1) / v) * 3 * N;
@@ -492,10 +487,10 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   if (items > 512)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assembly kernel supports up to %d atoms", 64);
   int T = ((items + 63) / 64) * 64;
-  // batch of row points per iteration (GDML_ASM_IB overrides): 4 if it fits in LDS, else 2, else 1
+  // batch of row points per iteration (option asm.ib caps it): 4 if it fits in LDS, else 2, else 1
   int IB = 1;
   if (AC <= 6) {
-    const int want = env_int("GDML_ASM_IB", 2);
+    const int want = ctx_opt_i(ctx, "asm.ib", 2);
     for (int cand : {4, 2}) {
       if (cand <= want && asm_lds_bytes(N, D, cand) <= 150 * 1024) {
         IB = cand;
@@ -503,11 +498,11 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
       }
     }
   }
-  const int minw = env_int("GDML_ASM_MINW", 2);
+  const int minw = ctx_opt_i(ctx, "asm.minw", 2);
   size_t lds = asm_lds_bytes(N, D, IB);
   A.GD = nullptr;
   A.XF = nullptr;
-  if (lds > 160 * 1024 || getenv("GDML_ASM_GJG")) {
+  if (lds > 160 * 1024 || ctx_opt_i(ctx, "asm.gj_global", 0)) {
     // large molecule: keep only the row point's dense table in LDS, read G_j from the global table
     extern int build_dense_tables(gdml_ctx * ctx);
     GDML_TRY(build_dense_tables(ctx));
@@ -521,7 +516,7 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   // column points per workgroup: long enough to amortise the resident row points, short enough
   // that the grid has >= ~8 workgroups per CU
   const int64_t n_ib = (A.i_end - A.i_beg + IB - 1) / IB;
-  int j_chunk = env_int("GDML_ASM_ICHUNK", 64);
+  int j_chunk = ctx_opt_i(ctx, "asm.j_chunk", 64);
   while (j_chunk > 4 && n_ib * ((n_j + j_chunk - 1) / j_chunk) < 4096) j_chunk >>= 1;
   A.i_chunk = j_chunk;
   A.n_j = n_j;
@@ -692,10 +687,7 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
     A.x = ts.x; A.g = ts.g; A.tp = ts.tp; A.perm = ts.perm; A.pinv = ts.pinv;
     A.M = M; A.N = N; A.D = ts.D; A.P = ts.P; A.sig = sig; A.use_E = use_E_cstr;
     A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.col0 = 0; A.i_chunk = 8;
-    {
-      const char* dbg = getenv("GDML_ASM_DEBUG");
-      A.dbg = dbg ? atoi(dbg) : 0;
-    }
+    A.dbg = ctx_opt_i(ctx, "asm.debug", 0);
     A.K = ctx->K; A.ld = ld;
     A.i_beg = i_beg; A.i_end = i_end;
     if (i_end <= i_beg)

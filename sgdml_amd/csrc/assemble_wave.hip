@@ -182,7 +182,7 @@ int build_dense_tables(gdml_ctx* ctx) {
 
 bool assemble_wave_applicable(const gdml_ctx* ctx) {
   const TrainSet& ts = ctx->ts;
-  if (getenv("GDML_ASM_NO_WAVE")) return false;
+  if (!ctx_opt_i(ctx, "asm.wave", 1)) return false;
   if (ts.P != 1 || ts.N > 21 || ts.N < 2) return false;
   for (int a = 0; a < ts.N; ++a)
     if (ts.h_perm[a] != a) return false;
@@ -200,11 +200,7 @@ int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   A.i_beg = i_beg;
   const int64_t n_i = i_end - i_beg;
   if (n_i <= 0) return GDML_OK;
-  int j_chunk = 64;
-  {
-    const char* e = getenv("GDML_ASM_ICHUNK");
-    if (e) j_chunk = atoi(e);
-  }
+  int j_chunk = ctx_opt_i(ctx, "asm.j_chunk", 64);
   while (j_chunk > 8 && n_i * ((n_j + j_chunk - 1) / j_chunk) < 8192) j_chunk >>= 1;
   A.j_chunk = j_chunk;
   dim3 grid((unsigned)n_i, (unsigned)((n_j + j_chunk - 1) / j_chunk));

@@ -49,7 +49,7 @@ struct GemmArgs {
   int64_t s_begin;  // first super tile of this launch (a launch may cover a sub-range)
   int super_n;      // super-tile columns
   int aligned;      // A, B 16-byte aligned with even leading dimensions (vector loads legal)
-  int dbg;          // GDML_GEMM_DEBUG ablation bits: 1 no epilogue, 2 no tile loads, 4 no LDS reads, 8 no barrier
+  int dbg;          // option gemm.debug: ablation bits: 1 no epilogue, 2 no tile loads, 4 no LDS reads, 8 no barrier
 };
 
 template <bool FULL>
@@ -87,9 +87,12 @@ __device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid,
   }
 }
 
-template <bool FULL>
+// ABL = true only in the ablation instantiation (option gemm.debug != 0): the production kernel carries
+// none of the ablation branches.
+template <bool FULL, bool ABL>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[2][GT * GPITCH],
                                                int64_t row0, int64_t col0) {
+  const int dbg = ABL ? g.dbg : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
@@ -110,7 +113,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
-    if (kt + 1 < nk && !(g.dbg & 2)) {
+    if (kt + 1 < nk && !(dbg & 2)) {
       gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
       gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
     }
@@ -119,7 +122,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
     for (int ks = 0; ks < GBK; ks += 4) {
       double a[4], bb[4];
-      if (g.dbg & 4) {
+      if (dbg & 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = bb[i] = (double)(lane + i + ks);
       } else {
@@ -133,16 +136,16 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-      if (ks == GEMM_COMMIT_KS && kt + 1 < nk && !(g.dbg & 2)) {
+      if (ks == GEMM_COMMIT_KS && kt + 1 < nk && !(dbg & 2)) {
         // the next tile's global loads were issued ~32 MFMAs ago: write them to the other LDS
         // buffer now so that the stores drain under the remaining MFMAs of this tile
         gemm_store_tile(lds[cur ^ 1][0], tid, ra);
         gemm_store_tile(lds[cur ^ 1][1], tid, rb);
       }
     }
-    if (!(g.dbg & 8)) __syncthreads();
+    if (!(dbg & 8)) __syncthreads();
   }
-  if (g.dbg & 1) {
+  if (dbg & 1) {
     if (acc[0][0][0] == 1.2345e-300) g.C[0] = 0.0;  // keep the accumulators alive
     return;
   }
@@ -209,6 +212,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   }
 }
 
+template <bool ABL>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
   // ---- block -> tile mapping: XCD-aware 8x8 super tiles (block b runs on XCD b % 8)
@@ -234,9 +238,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   const int64_t row0 = ti * GT, col0 = tj * GT;
   const bool full = (row0 + GT <= g.M) && (col0 + GT <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
   if (full)
-    gemm_tile_body<true>(g, lds, row0, col0);
+    gemm_tile_body<true, ABL>(g, lds, row0, col0);
   else
-    gemm_tile_body<false>(g, lds, row0, col0);
+    gemm_tile_body<false, ABL>(g, lds, row0, col0);
 }
 
 // f0, f1: the launch covers the super tiles [f0 * n_super, f1 * n_super) (whole update: 0, 1);
@@ -248,14 +252,7 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.lower = lower;
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("GDML_GEMM_DEBUG");
-      dbg = e ? atoi(e) : 0;
-    }
-    g.dbg = dbg;
-  }
+  g.dbg = ctx_opt_i(ctx, "gemm.debug", 0);
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
               (lda % 2 == 0) && (ldb % 2 == 0);
   g.tiles_m = (int)((M + GT - 1) / GT);
@@ -269,7 +266,10 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   int64_t groups = (g.n_super - g.s_begin + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
   int64_t blocks = groups * 512;
   const int slot = (timed && st == (ctx->kt_stream ? ctx->kt_stream : ctx->stream)) ? ktime_begin(ctx) : -1;
-  hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+  if (g.dbg)
+    hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL(gemm_nt_sub_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   ktime_end(ctx, slot, "gemm_nt_sub",
             lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K);
   ctx->launch_counter++;
@@ -521,11 +521,7 @@ int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, in
 // Factor one panel: columns [k0, k0+nb), rows [k0, n), 64-wide sub-steps (potrf64 / trsm64 / K=64 gemm).
 static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0,
                         int64_t nb) {
-  static int fused = -1;  // GDML_PANEL_FUSED=0: separate potrf64 / trsm64 launches
-  if (fused < 0) {
-    const char* e = getenv("GDML_PANEL_FUSED");
-    fused = e ? atoi(e) : 1;
-  }
+  const int fused = ctx_opt_i(ctx, "chol.panel_fused", 1);  // 0: separate potrf64 / trsm64 launches
   double* save = nullptr;  // two 64 x 64 slots for the deferred write-back of the diagonal blocks
   if (fused) GDML_TRY(ctx_slot(ctx, 5, 2 * 4096 * 8, &save));
   const double* Lprev = nullptr;
@@ -582,7 +578,7 @@ static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int
 // compute stream first updates only the columns of panel k+1, then (a) the panel stream factors
 // panel k+1 (latency-bound 64-wide steps) while (b) the compute stream applies the big SYRK to
 // the rest of the trailing matrix.  The two touch disjoint columns.
-// Split-stream schedule (GDML_CHOL_SPLIT, default on): the panel kernels need a CU with a free GEMM slot
+// Split-stream schedule (option chol.split, off by default): the panel kernels need a CU with a free GEMM slot
 // (a GEMM workgroup takes half the registers and LDS of a CU), and while the SYRK grid has workgroups
 // pending the dispatcher refills every slot with the next GEMM workgroup -- so with plain look-ahead the
 // panel only makes progress once the SYRK has drained and ends up exposed in every step (timeline:
@@ -595,13 +591,9 @@ static int chol_factor_split(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, in
   hipStream_t sm = ctx->stream_mm, sa = ctx->stream_mp;
   hipEvent_t evA = ctx->ev_la[0], evB = ctx->ev_la[1];
   // panel time on the auxiliary CUs: t_p(m) = pa + pb * m  [ms];  full-chip SYRK: t_s(m) = m^2 nb / rate
-  static double pa = -1.0, pb = 0.0, rate = 0.0;
-  if (pa < 0.0) {
-    const char* e;
-    pa = (e = getenv("GDML_CHOL_PANEL_A")) ? atof(e) : 0.5;
-    pb = (e = getenv("GDML_CHOL_PANEL_B")) ? atof(e) : 2.7e-3 / (double)aux_cus;  // ms per row per CU^-1
-    rate = (e = getenv("GDML_CHOL_GEMM_TF")) ? atof(e) : 57.0;
-  }
+  const double pa = ctx_opt(ctx, "chol.panel_a", 0.5);
+  const double pb = ctx_opt(ctx, "chol.panel_b", 2.7e-3 / (double)aux_cus);  // ms per row per CU^-1
+  const double rate = ctx_opt(ctx, "chol.gemm_tf", 57.0);
   const double fa = (double)aux_cus / (double)ctx->num_cus;  // capacity share of the auxiliary stream
   HIP_CHECK(ctx, hipEventRecord(evA, ctx->stream));
   HIP_CHECK(ctx, hipStreamWaitEvent(sm, evA, 0));
@@ -661,21 +653,12 @@ static int chol_factor_split(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, in
 int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out, int64_t n_rows) {
   if (n_rows < n) n_rows = n;
   HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
-  static int64_t NB = 0;  // outer panel width (GDML_CHOL_NB overrides; multiple of 64)
-  if (NB == 0) {
-    const char* e = getenv("GDML_CHOL_NB");
-    NB = e ? atoll(e) : 512;
-    if (NB < 64 || NB % 64) NB = 512;
-  }
+  int64_t NB = (int64_t)ctx_opt(ctx, "chol.nb", 512);  // outer panel width (multiple of 64)
+  if (NB < 64 || NB % 64) NB = 512;
+  const bool lookahead = ctx_opt_i(ctx, "chol.lookahead", 1) != 0;
   {
-    static int split = -1, aux_cus = 32;
-    if (split < 0) {
-      const char* e = getenv("GDML_CHOL_SPLIT");
-      split = e ? atoi(e) : 0;
-      const char* c = getenv("GDML_CHOL_AUX_CUS");
-      if (c) aux_cus = atoi(c);
-    }
-    if (split && n_rows == n && n > 4 * NB && getenv("GDML_NO_LOOKAHEAD") == nullptr) {
+    const int split = ctx_opt_i(ctx, "chol.split", 0), aux_cus = ctx_opt_i(ctx, "chol.aux_cus", 32);
+    if (split && n_rows == n && n > 4 * NB && lookahead) {
       GDML_TRY(chol_factor_split(ctx, A, n, ld, NB, aux_cus));
       HIP_CHECK(ctx, hipGetLastError());
       int info = 0;
@@ -687,17 +670,10 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
   }
   hipStream_t sm = ctx->stream, sp = ctx->stream2;
   hipEvent_t evA = ctx->ev_la[0], evB = ctx->ev_la[1];
-  const bool lookahead = getenv("GDML_NO_LOOKAHEAD") == nullptr;
   // late phase: once fewer than mask_rows rows remain the panel chain is the critical path; from then
   // on the two streams are a CU-masked pair, so that the panel kernels never queue behind GEMM workgroups
-  static int64_t mask_rows = -1;
-  static int mask_cus = 32;
-  if (mask_rows < 0) {
-    const char* e = getenv("GDML_CHOL_MASK_ROWS");
-    mask_rows = e ? atoll(e) : 0;
-    const char* c = getenv("GDML_CHOL_MASK_CUS");
-    if (c) mask_cus = atoi(c);
-  }
+  const int64_t mask_rows = (int64_t)ctx_opt(ctx, "chol.mask_rows", 0);
+  const int mask_cus = ctx_opt_i(ctx, "chol.mask_cus", 32);
   bool masked = false;
   GDML_TRY(panel_factor(ctx, sm, A, n_rows, ld, 0, n < NB ? n : NB));
   for (int64_t k0 = 0; k0 < n; k0 += NB) {
@@ -863,7 +839,7 @@ static int chol_fwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward substitution L^T x = z as ONE persistent launch (default for n >= 2048; GDML_TRSV_PERSIST=0
+// Backward substitution L^T x = z as ONE persistent launch (default for n >= 2048; option trsv.persist = 0
 // restores the per-block launches).  Left-looking: the workgroup that owns 64-block k accumulates
 //   s = sum_{c > k} L[c,k]^T x_c      (rows below the block, 512-byte row segments, 4 wavefronts over the blocks c)
 // as the x_c become available, then solves the transposed diagonal block and publishes x_k.  Blocks are
@@ -927,11 +903,7 @@ __global__ void __launch_bounds__(256) trsv_bwd_persist_kernel(const double* __r
 
 // d_z is destroyed
 static int chol_bwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_z, double* d_x) {
-  static int persist = -1;
-  if (persist < 0) {
-    const char* e = getenv("GDML_TRSV_PERSIST");
-    persist = e ? atoi(e) : 1;
-  }
+  const int persist = ctx_opt_i(ctx, "trsv.persist", 1);
   if (persist && n >= 2048) {
     const int nbk = (int)((n + 63) / 64);
     int* done = ctx->d_info + 4;

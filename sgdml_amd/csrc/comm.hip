@@ -77,7 +77,8 @@ extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int wo
   if (!ctx) return GDML_ERR_INVALID;
   if (world < 1 || rank < 0 || rank >= world)
     return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_comm_init: rank %d / world %d", rank, world);
-  if (ctx->comm) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_comm_init: communicator already initialised");
+  if (ctx->comm || ctx->host_allreduce)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_comm_init: communicator already initialised");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (id128 == nullptr) {
     // "virtual rank": shard arithmetic without a communicator (collectives are skipped); used by the
@@ -98,6 +99,8 @@ extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int wo
   ctx->rank = rank;
   ctx->world = world;
   ctx->virtual_rank = false;
+  ctx->coll_calls = 0;
+  ctx->coll_bytes = 0.0;
   return GDML_OK;
 }
 
@@ -125,24 +128,91 @@ void shard_points(const gdml_ctx* ctx, int64_t M, int64_t* p0, int64_t* p1, int6
   if (pts_per) *pts_per = per;
 }
 
-// ---- collectives on the compute stream (no-ops for world == 1 / virtual ranks) -----------------
+extern "C" int gdml_comm_init_host(gdml_ctx* ctx, int rank, int world, gdml_host_allreduce allreduce,
+                                   gdml_host_allgather allgather, void* user) {
+  if (!ctx || !allreduce || !allgather) return GDML_ERR_INVALID;
+  if (world < 1 || rank < 0 || rank >= world)
+    return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_comm_init_host: rank %d / world %d", rank, world);
+  if (ctx->comm || ctx->host_allreduce)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_comm_init_host: communicator already initialised");
+  ctx->host_allreduce = allreduce;
+  ctx->host_allgather = allgather;
+  ctx->host_coll_user = user;
+  ctx->rank = rank;
+  ctx->world = world;
+  ctx->virtual_rank = false;
+  ctx->coll_calls = 0;
+  ctx->coll_bytes = 0.0;
+  return GDML_OK;
+}
+
+extern "C" int gdml_comm_stats(gdml_ctx* ctx, int64_t* calls_out, double* bytes_out) {
+  if (!ctx) return GDML_ERR_INVALID;
+  if (calls_out) *calls_out = ctx->coll_calls;
+  if (bytes_out) *bytes_out = ctx->coll_bytes;
+  return GDML_OK;
+}
+
+// ---- collectives on the compute stream -----------------------------------------------------------
+// Backend order: host-staged callbacks (gdml_comm_init_host) > RCCL communicator (gdml_comm_init with an id;
+// used for EVERY world size including 1, so a one-rank communicator exercises the same calls) > nothing
+// (single context without communicator, or a "virtual rank": the caller stitches the shards).
+static int host_stage(gdml_ctx* ctx, int64_t bytes) {
+  if (bytes <= ctx->h_coll_bytes) return GDML_OK;
+  if (ctx->h_coll) (void)hipHostFree(ctx->h_coll);
+  ctx->h_coll = nullptr;
+  ctx->h_coll_bytes = 0;
+  HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->h_coll, (size_t)bytes, hipHostMallocDefault));
+  ctx->h_coll_bytes = bytes;
+  return GDML_OK;
+}
+
 int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk) {
-  if (ctx->world <= 1 || ctx->virtual_rank) return GDML_OK;
-  ncclResult_t_ r = g_rccl.AllGather(buf + (int64_t)ctx->rank * chunk, buf, (size_t)chunk, kNcclDouble,
-                                     (ncclComm_t_)ctx->comm, ctx->stream);
-  if (r != 0) return rccl_fail(ctx, "ncclAllGather", r);
+  if (ctx->virtual_rank) return GDML_OK;
+  if (ctx->host_allgather) {
+    const int64_t tot = chunk * ctx->world;
+    GDML_TRY(host_stage(ctx, tot * 8));
+    double* mine = ctx->h_coll + (int64_t)ctx->rank * chunk;
+    HIP_CHECK(ctx, hipMemcpyAsync(mine, buf + (int64_t)ctx->rank * chunk, chunk * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->host_allgather(ctx->h_coll, chunk, ctx->host_coll_user) != 0)
+      return gdml_fail(ctx, GDML_ERR_COMM, "host all-gather callback failed");
+    HIP_CHECK(ctx, hipMemcpyAsync(buf, ctx->h_coll, tot * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next collective
+  } else if (ctx->comm) {
+    ncclResult_t_ r = g_rccl.AllGather(buf + (int64_t)ctx->rank * chunk, buf, (size_t)chunk, kNcclDouble,
+                                       (ncclComm_t_)ctx->comm, ctx->stream);
+    if (r != 0) return rccl_fail(ctx, "ncclAllGather", r);
+  } else {
+    return GDML_OK;
+  }
+  ctx->coll_calls++;
+  ctx->coll_bytes += 8.0 * (double)chunk;
   return GDML_OK;
 }
 
 int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count) {
-  if (ctx->world <= 1 || ctx->virtual_rank) return GDML_OK;
-  // large buffers go in pieces of 2^28 doubles (2 GiB) to stay inside RCCL's comfortable sizes
-  const int64_t piece = (int64_t)1 << 28;
+  if (ctx->virtual_rank) return GDML_OK;
+  if (!ctx->host_allreduce && !ctx->comm) return GDML_OK;
+  // large buffers go in pieces of 2^27 doubles (1 GiB) to stay inside comfortable message sizes
+  const int64_t piece = (int64_t)1 << 27;
   for (int64_t off = 0; off < count; off += piece) {
     const int64_t c = (count - off < piece) ? count - off : piece;
-    ncclResult_t_ r = g_rccl.AllReduce(buf + off, buf + off, (size_t)c, kNcclDouble, kNcclSum,
-                                       (ncclComm_t_)ctx->comm, ctx->stream);
-    if (r != 0) return rccl_fail(ctx, "ncclAllReduce", r);
+    if (ctx->host_allreduce) {
+      GDML_TRY(host_stage(ctx, c * 8));
+      HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_coll, buf + off, c * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->host_allreduce(ctx->h_coll, c, ctx->host_coll_user) != 0)
+        return gdml_fail(ctx, GDML_ERR_COMM, "host all-reduce callback failed");
+      HIP_CHECK(ctx, hipMemcpyAsync(buf + off, ctx->h_coll, c * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+      ncclResult_t_ r = g_rccl.AllReduce(buf + off, buf + off, (size_t)c, kNcclDouble, kNcclSum,
+                                         (ncclComm_t_)ctx->comm, ctx->stream);
+      if (r != 0) return rccl_fail(ctx, "ncclAllReduce", r);
+    }
+    ctx->coll_calls++;
+    ctx->coll_bytes += 8.0 * (double)c;
   }
   return GDML_OK;
 }

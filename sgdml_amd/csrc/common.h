@@ -70,6 +70,7 @@ struct gdml_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_la[2] = {nullptr, nullptr};  // look-ahead hand-off between the two streams
   std::string err;
+  std::map<std::string, double> opts;  // tuning / ablation options (gdml_set_option); absent key = built-in default
   int64_t held = 0;
   std::map<void*, int64_t> allocs;
   std::map<std::string, PhaseStat> phases;
@@ -110,11 +111,21 @@ struct gdml_ctx {
   void* comm = nullptr;  // ncclComm_t
   int rank = 0, world = 1;
   bool virtual_rank = false;   // shard arithmetic only, collectives skipped (tests)
+  gdml_host_allreduce host_allreduce = nullptr;  // host-staged collectives (gdml_comm_init_host)
+  gdml_host_allgather host_allgather = nullptr;
+  void* host_coll_user = nullptr;
+  double* h_coll = nullptr;    // pinned staging buffer of the host-staged collectives
+  int64_t h_coll_bytes = 0;
+  int64_t coll_calls = 0;      // collectives issued (any backend) since gdml_comm_init*
+  double coll_bytes = 0.0;     // payload bytes this rank handed to them
   bool K_sharded = false;      // resident K holds only this rank's rows (Nystroem path)
   int64_t K_rows_global = 0;
 };
 
 int gdml_fail(gdml_ctx* ctx, int code, const char* fmt, ...);
+// option lookup (ctx.hip): value of `key`, or dflt when it was never set
+double ctx_opt(const gdml_ctx* ctx, const char* key, double dflt);
+static inline int ctx_opt_i(const gdml_ctx* ctx, const char* key, int dflt) { return (int)ctx_opt(ctx, key, (double)dflt); }
 
 #define HIP_CHECK(ctx, call)                                                              \
   do {                                                                                    \
@@ -183,6 +194,7 @@ void shard_points(const gdml_ctx* ctx, int64_t M, int64_t* p0, int64_t* p1, int6
 int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk);
 int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count);
 void comm_destroy(gdml_ctx* ctx);
+static inline bool comm_active(const gdml_ctx* ctx) { return (ctx->comm || ctx->host_allreduce) && !ctx->virtual_rank; }
 bool assemble_wave_applicable(const gdml_ctx* ctx);
 int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist,
                          const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld,

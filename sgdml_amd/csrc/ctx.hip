@@ -18,7 +18,57 @@ int gdml_fail(gdml_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int gdml_abi_version(void) { return 1; }
+extern "C" int gdml_abi_version(void) { return 2; }
+
+// ---- options --------------------------------------------------------------------------------
+// Every tuning / ablation switch of the library is a (key, value) pair of the context, read at the
+// point of use (no process-wide read-once caches).  Keys are listed in include/gdml_hip.h.  The only
+// environment variable the library looks at is GDML_OPTIONS="key=value,key=value", applied once when
+// a context is created (lab convenience for the probes under tools/).
+static const char* kKnownOptions[] = {
+    "asm.wave", "asm.threads", "asm.ib", "asm.minw", "asm.gj_global", "asm.j_chunk", "asm.debug", "asm.lower",
+    "gemm.debug", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.split", "chol.aux_cus",
+    "chol.mask_rows", "chol.mask_cus", "chol.panel_a", "chol.panel_b", "chol.gemm_tf", "chol.panel_kernel",
+    "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
+    "lu.nb", "comm.force_collectives"};
+
+double ctx_opt(const gdml_ctx* ctx, const char* key, double dflt) {
+  auto it = ctx->opts.find(key);
+  return it == ctx->opts.end() ? dflt : it->second;
+}
+
+extern "C" int gdml_set_option(gdml_ctx* ctx, const char* key, double value) {
+  if (!ctx || !key) return GDML_ERR_INVALID;
+  for (const char* k : kKnownOptions)
+    if (strcmp(k, key) == 0) {
+      ctx->opts[key] = value;
+      return GDML_OK;
+    }
+  return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_set_option: unknown option '%s'", key);
+}
+
+extern "C" int gdml_get_option(gdml_ctx* ctx, const char* key, double* value_out, int* is_set_out) {
+  if (!ctx || !key) return GDML_ERR_INVALID;
+  auto it = ctx->opts.find(key);
+  if (value_out) *value_out = it == ctx->opts.end() ? 0.0 : it->second;
+  if (is_set_out) *is_set_out = it != ctx->opts.end();
+  return GDML_OK;
+}
+
+static void options_from_env(gdml_ctx* ctx) {
+  const char* e = getenv("GDML_OPTIONS");
+  if (!e) return;
+  std::string s(e);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t end = s.find(',', pos);
+    if (end == std::string::npos) end = s.size();
+    const std::string kv = s.substr(pos, end - pos);
+    const size_t eq = kv.find('=');
+    if (eq != std::string::npos) (void)gdml_set_option(ctx, kv.substr(0, eq).c_str(), atof(kv.c_str() + eq + 1));
+    pos = end + 1;
+  }
+}
 
 extern "C" int gdml_device_count(int* n_out) {
   if (!n_out) return GDML_ERR_INVALID;
@@ -44,32 +94,14 @@ extern "C" int gdml_ctx_create(int device, gdml_ctx** ctx_out) {
     return gdml_fail(nullptr, GDML_ERR_INVALID, "device %d out of range [0,%d)", device, n);
   gdml_ctx* ctx = new gdml_ctx();
   ctx->device = device;
-  // Two streams: `stream` carries the bulk kernels, `stream2` the latency-bound panel steps of the
-  // look-ahead Cholesky.  stream2 gets the highest priority; optionally (GDML_RESERVE_CUS=n) the
-  // bulk stream is masked off n compute units so that single-wave panel kernels never queue behind
-  // a full grid of GEMM workgroups.
+  // Two streams: `stream` carries the bulk kernels, `stream2` (highest priority) the latency-bound panel
+  // steps of the look-ahead Cholesky.
   auto make_streams = [&]() -> hipError_t {
     hipError_t err;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const char* pr = getenv("GDML_PANEL_PRIO");
-    const bool use_prio = pr == nullptr || atoi(pr) != 0;
-    const char* rs = getenv("GDML_RESERVE_CUS");
-    const int reserve = rs ? atoi(rs) : 0;
-    if (reserve > 0) {
-      hipDeviceProp_t prop;
-      if ((err = hipGetDeviceProperties(&prop, device)) != hipSuccess) return err;
-      const int ncu = prop.multiProcessorCount;
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-      for (int c = reserve; c < ncu; ++c) mask[c / 32] |= 1u << (c % 32);
-      if ((err = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mask.size(), mask.data())) != hipSuccess)
-        return err;
-    } else {
-      if ((err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return err;
-    }
-    if (use_prio)
-      return hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi);
-    return hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if ((err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return err;
+    return hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi);
   };
   {
     int ncu = 0;
@@ -86,6 +118,7 @@ extern "C" int gdml_ctx_create(int device, gdml_ctx** ctx_out) {
     delete ctx;
     return GDML_ERR_HIP;
   }
+  options_from_env(ctx);
   *ctx_out = ctx;
   return GDML_OK;
 }
@@ -110,6 +143,7 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
+  if (ctx->h_coll) hipHostFree(ctx->h_coll);
   if (ctx->stream_mm) hipStreamDestroy(ctx->stream_mm);
   if (ctx->stream_mp) hipStreamDestroy(ctx->stream_mp);
   delete ctx;

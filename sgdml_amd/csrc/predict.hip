@@ -700,17 +700,13 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   int KPL = 1;
   while (KPL * 64 < D) KPL <<= 1;
   if (KPL > 32) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "predict kernel supports D <= 2048");
-  const bool bulk = (B >= 256) && (D <= 256) && getenv("GDML_PREDICT_V1") == nullptr;
-  const bool mfma = bulk && getenv("GDML_PREDICT_NO_MFMA") == nullptr;
+  const bool bulk = (B >= 256) && (D <= 256) && !ctx_opt_i(ctx, "predict.wave_only", 0);
+  const bool mfma = bulk && ctx_opt_i(ctx, "predict.mfma", 1);
   int QB = max_qb_for(KPL);
   while (QB > 1 && B < QB) QB >>= 1;  // do not waste query slots
   {
     // small batches: fewer queries per wavefront until the grid (query tiles x row splits) fills the chip
-    static int fill = -1;
-    if (fill < 0) {
-      const char* e = getenv("GDML_PREDICT_FILL");
-      fill = e ? atoi(e) : 1024;
-    }
+    const int fill = ctx_opt_i(ctx, "predict.fill", 1024);
     const int64_t js_cap = MP / 16 > 1 ? MP / 16 : 1;
     while (QB > 1 && ((B + QB - 1) / QB) * js_cap < fill) QB >>= 1;
   }
@@ -1138,7 +1134,8 @@ int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, 
     ctx->launch_counter++;
     HIP_CHECK(ctx, hipGetLastError());
   }
-  if (ctx->world > 1) GDML_TRY(comm_allgather_inplace(ctx, d_out, per * N3));
+  // with a communicator the gather is issued for every world size (a one-rank communicator runs the same call)
+  if (ctx->world > 1 || comm_active(ctx)) GDML_TRY(comm_allgather_inplace(ctx, d_out, per * N3));
   return GDML_OK;
 }
 

@@ -18,15 +18,44 @@ def shard_range(rank, world, n_points):
     return a, b, per
 
 
-def init_comm_from_torch_distributed(ctx, group=None):
-    """Create the RCCL communicator of `ctx` using an initialised torch.distributed process group to
-    ship rank 0's unique id.  Returns (rank, world)."""
+def init_comm_from_torch_distributed(ctx, group=None, backend='rccl'):
+    """Create the communicator of `ctx` from an initialised torch.distributed process group (any backend,
+    it only ships the id / carries the host-staged collectives).  Returns (rank, world).
+
+    backend='rccl': RCCL over xGMI inside the library; rank 0's unique id is broadcast through the group.
+    backend='host': the library stages its two collectives through pinned host memory and the group performs
+        them (gloo): for ranks that share a GPU (RCCL refuses duplicate devices) and for tests of the sharded
+        code path on a one-GPU box."""
+    import torch
     import torch.distributed as dist
 
     from . import _lib
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    payload = [_lib.Context.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(payload, src=0, group=group)
-    ctx.comm_init(payload[0], rank, world)
+    if backend == 'rccl':
+        payload = [_lib.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(payload, src=0, group=group)
+        ctx.comm_init(payload[0], rank, world)
+    elif backend == 'host':
+        def allreduce(buf):
+            dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM, group=group)
+
+        def allgather(buf, chunk):
+            t = torch.from_numpy(buf)
+            mine = t[rank * chunk:(rank + 1) * chunk].clone()
+            dist.all_gather(list(t.split(chunk)), mine, group=group)
+
+        ctx.comm_init_host(rank, world, allreduce, allgather)
+    else:
+        raise ValueError("backend must be 'rccl' or 'host'")
+    ctx._bcast = lambda arr, src=0: broadcast_array(arr, src=src, group=group)
     return rank, world
+
+
+def broadcast_array(arr, src=0, group=None):
+    """Broadcast a NumPy array (shape and dtype included) from rank `src`; every rank gets a copy."""
+    import torch.distributed as dist
+
+    payload = [arr if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(payload, src=src, group=group)
+    return payload[0]

@@ -72,5 +72,5 @@ class Analytic(object):
     def est_device_memory(n_train, n_atoms, use_E_cstr=False):
         """HBM needed by this backend: K is factored in place -> one n x n fp64 matrix."""
         n = n_train * 3 * n_atoms + (n_train if use_E_cstr else 0)
-        ld = n
-        return ld * n * 8 + 8 * n * 8
+        ld = (n + 15) // 16 * 16  # rows start on 128-byte boundaries (gdml_assemble_K)
+        return (n + 1) * ld * 8 + 8 * n * 8  # + the right-hand-side row, + solve vectors

@@ -44,6 +44,12 @@ class Iterative(object):
     def _ctx(self):
         return self.gdml_train._context()
 
+    def _sync(self, arr):
+        """Sharded mode (GDMLTrain.init_distributed): every random draw is rank 0's, broadcast to all ranks --
+        the shards of one Nystroem factor must agree on the inducing columns.  Single process: identity."""
+        bcast = getattr(self._ctx(), '_bcast', None)
+        return arr if bcast is None else np.asarray(bcast(np.asarray(arr)))
+
     def _upload(self, R_desc, R_d_desc, tril_perms_lin):
         dim_d = R_desc.shape[1]
         self._tril_perms = _lib.tril_perms_from_lin(tril_perms_lin, dim_d)
@@ -99,9 +105,9 @@ class Iterative(object):
         n_train, dim_d = R_d_desc.shape[:2]
         dim_i = 3 * int((1 + np.sqrt(8 * dim_d + 1)) / 2)
         dim_m = dim_i * min(n_inducing_pts, 10)
-        lev_approx_idxs = np.sort(
+        lev_approx_idxs = self._sync(np.sort(
             np.random.choice(n_train * dim_i + (n_train if use_E_cstr else 0), dim_m, replace=False)
-        )
+        ))
         self._nystroem_cholesky_factor(
             R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr=use_E_cstr, col_idxs=lev_approx_idxs,
             callback_task_name='lev. scores', callback=callback, want_factor=False,
@@ -111,7 +117,7 @@ class Iterative(object):
     def inducing_pts_from_lev_scores(self, lev_scores, N):
         """Sample N columns with probability proportional to the leverage scores (iterative.py:401-411)."""
         idxs = np.random.choice(np.arange(lev_scores.size), N, replace=False, p=lev_scores / lev_scores.sum())
-        return np.sort(idxs)
+        return self._sync(np.sort(idxs))
 
     # ------------------------------------------------------------------ solve
 
@@ -147,7 +153,7 @@ class Iterative(object):
         start = timeit.default_timer()
         lev_scores = None
         if n_inducing_pts_init is not None and n_inducing_pts_init == n_inducing_pts:
-            inducing_pts_idxs = task['inducing_pts_idxs']
+            inducing_pts_idxs = self._sync(task['inducing_pts_idxs'])
         else:
             lev_scores = self._lev_scores(R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr, n_inducing_pts)
             inducing_pts_idxs = self.inducing_pts_from_lev_scores(lev_scores, n_inducing_pts * dim_i)
@@ -207,6 +213,10 @@ class Iterative(object):
                     'solver_tol': tol, 'solver_iters': state['num_iters'] + 1, 'solver_resid': resid,
                     'norm_y_train': np.linalg.norm(y), 'inducing_pts_idxs': inducing_pts_idxs, 'c': 0,
                 })
+                if 'E_train' in task:  # integration constant of the checkpoint (iterative.py:711-720)
+                    ctx.set_alphas(alphas_F, alphas_E)
+                    E_pred, _ = ctx.predict(None)
+                    unconv_model['c'] = np.mean(np.squeeze(task['E_train']) - E_pred * y_std)
                 save_progr_callback(unconv_model)
 
             state['num_iters'] += 1
@@ -231,7 +241,9 @@ class Iterative(object):
             steps_hist.clear()
             if num_restarts == MAX_NUM_RESTARTS:
                 info = 1
-                alphas = state['alpha_t']
+                # state['alpha_t'] is the CG iterate x of (-K + lam I) x = y; the coefficients are -x like on every
+                # other exit (the reference returns +x here, iterative.py:762: sign-flipped forces -- not reproduced)
+                alphas = -state['alpha_t']
                 break
             n_inducing_pts = min(int(np.ceil(1.2 * n_inducing_pts)), n_train)
             inducing_pts_idxs = self.inducing_pts_from_lev_scores(lev_scores, n_inducing_pts * dim_i)

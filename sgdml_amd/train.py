@@ -27,6 +27,7 @@ class GDMLTrain(object):
                 'You can not create multiple instances of this class. Please reuse your first one.'
             )
         _instance_alive = True
+        self._owns_singleton = True
         self.log = logging.getLogger(__name__)
         self._max_memory = max_memory  # [GB] soft limit on DEVICE memory for this backend
         self._max_processes = max_processes
@@ -36,7 +37,8 @@ class GDMLTrain(object):
 
     def __del__(self):
         global _instance_alive
-        _instance_alive = False
+        if getattr(self, '_owns_singleton', False):  # an instance whose __init__ raised never owned it
+            _instance_alive = False
         ctx = getattr(self, '_ctx', None)
         if ctx is not None:
             ctx.close()
@@ -46,9 +48,21 @@ class GDMLTrain(object):
             self._ctx = _lib.Context()
         return self._ctx
 
+    def init_distributed(self, group=None, backend='rccl'):
+        """Shard the iterative solver over the ranks of an initialised torch.distributed process group (one
+        process per GPU): row-sharded Nystroem factor, query-sharded kernel mat-vec, RCCL all-reduce /
+        all-gather inside the library (csrc/comm.hip).  backend='host' stages the collectives through the
+        group instead (ranks sharing a GPU).  The reference's only multi-GPU path is nn.DataParallel
+        (train.py:1463-1469).  Returns (rank, world)."""
+        from . import dist as _dist
+
+        return _dist.init_comm_from_torch_distributed(self._context(), group=group, backend=backend)
+
     def _device_budget_bytes(self):
-        _, free_b, total_b = self._context().mem_info()
-        budget = free_b
+        ctx = self._context()
+        _, free_b, total_b = ctx.mem_info()
+        # the context keeps the previous kernel matrix resident for reuse: that memory is available to the next one
+        budget = free_b + ctx.resident_K_bytes()
         if self._max_memory is not None:
             budget = min(budget, int(self._max_memory) * 1024**3)
         return budget
@@ -144,22 +158,21 @@ class GDMLTrain(object):
                     )
                     task['perms'] = train_dataset['perms']
                 else:
-                    # Symmetry discovery (sgdml/utils/perm.py) is one-off CPU preprocessing outside
-                    # the accelerated path: reuse the reference's.
-                    try:
-                        from sgdml.utils import perm as ref_perm
-                    except ImportError:
-                        raise NotImplementedError(
-                            'Automatic permutation discovery is not part of this backend: pass `perms` '
-                            '(P x N) or store them in the dataset, or install sgdml for its utils.perm.'
-                        )
+                    # Symmetry discovery (train.py:560-584): own host implementation, utils/perm.py
+                    from .utils import perm as perm_mod
+
                     lat_and_inv = None
                     if 'lattice' in task:
                         lat_and_inv = (task['lattice'], np.linalg.inv(task['lattice']))
+                    n_train_pts = R_train.shape[0]
                     R_sync = R_train
-                    if R_train.shape[0] > 1000:
-                        R_sync = R_train[np.random.choice(R_train.shape[0], 1000, replace=False)]
-                    task['perms'] = ref_perm.find_perms(
+                    if n_train_pts > 1000:  # train.py:565-573: at most 1000 geometries enter the matching
+                        R_sync = R_train[np.random.choice(n_train_pts, 1000, replace=False), :, :]
+                        self.log.info(
+                            'Symmetry search has been restricted to a random subset of 1000/{:d} training points '
+                            'for faster convergence.'.format(n_train_pts)
+                        )
+                    task['perms'] = perm_mod.find_perms(
                         R_sync, train_dataset['z'], lat_and_inv=lat_and_inv, callback=callback,
                         max_processes=self._max_processes,
                     )

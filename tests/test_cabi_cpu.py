@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     src = open(os.path.join(ROOT, 'include', 'gdml_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(gdml_[a-zA-Z0-9_]+)\s*\(', src)) - {'gdml_pcg_cb'})
+    return sorted(set(re.findall(r'\b(gdml_[a-zA-Z0-9_]+)\s*\(', src)) - {'gdml_pcg_cb', 'gdml_host_allreduce', 'gdml_host_allgather'})
 
 
 def test_header_and_ctypes_table_agree():
@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
     lib = _lib.load()
     for name in _header_functions():
         assert hasattr(lib, name), name
-    assert lib.gdml_abi_version() == 1
+    assert lib.gdml_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -49,13 +49,32 @@ def test_no_cpu_fallback_without_gpu():
         t.__del__()
 
 
-def test_product_package_never_imports_oracle():
+def test_product_package_never_imports_oracle_or_reference():
+    """The product (sgdml_amd/, bench.py outside its cpu_baseline leg) must reach neither the oracle nor the
+    reference package: no `oracle` token at all, no `import sgdml` / `from sgdml` / `sgdml.` module access."""
+    ref_import = re.compile(r'^\s*(import\s+sgdml(\s|\.|$)|from\s+sgdml(\s|\.))', re.M)
+    ref_dyn = re.compile(r"import_module\(\s*['\"]sgdml(['\".])|__import__\(\s*['\"]sgdml(['\".])")
     pkg = os.path.join(ROOT, 'sgdml_amd')
+    seen = 0
     for dp, _, fs in os.walk(pkg):
         for f in fs:
             if f.endswith(('.py', '.hip', '.h')):
-                txt = open(os.path.join(dp, f)).read()
-                assert 'oracle' not in txt.replace('no CPU fallback', ''), os.path.join(dp, f)
+                path = os.path.join(dp, f)
+                txt = open(path).read()
+                seen += 1
+                assert 'oracle' not in txt.replace('no CPU fallback', ''), path
+                if f.endswith('.py'):
+                    assert not ref_import.search(txt), path
+                    assert not ref_dyn.search(txt), path
+    assert seen > 10
+
+
+def test_options_env_is_the_only_environment_variable_the_library_reads():
+    for f in os.listdir(os.path.join(ROOT, 'sgdml_amd', 'csrc')):
+        if f.endswith(('.hip', '.h')):
+            txt = open(os.path.join(ROOT, 'sgdml_amd', 'csrc', f)).read()
+            for m in re.finditer(r'getenv\("([A-Z_]+)"\)', txt):
+                assert m.group(1) == 'GDML_OPTIONS', (f, m.group(1))
 
 
 def test_tril_perms_roundtrip():
@@ -186,3 +205,67 @@ def test_create_task_schema_and_sampling():
         tr.__del__()
     tr2 = GDMLTrain()  # the slot is free again after __del__ (train.py:363-368)
     tr2.__del__()
+
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def test_find_perms_matches_reference():
+    """Own symmetry discovery (sgdml_amd/utils/perm.py) vs the reference's find_perms output on three seeded
+    molecules (tests/golden/make_golden_r2.py::case_perm_c3): same group, same order."""
+    from sgdml_amd.utils import perm
+
+    g = np.load(os.path.join(GOLD, 'perm_c3.npz'))
+    assert np.array_equal(perm.find_perms(g['R'], g['z']), g['perms'])
+    assert np.array_equal(perm.find_perms(g['R2'], g['z2']), g['perms2'])
+    lat = g['lat']
+    assert np.array_equal(perm.find_perms(g['R2'], g['z2'], lat_and_inv=(lat, np.linalg.inv(lat))), g['perms3'])
+    assert g['perms'].shape[0] == 6 and g['perms2'].shape[0] == 3
+
+
+def test_perm_group_helpers():
+    from sgdml_amd.utils import perm
+
+    gens = np.array([[0, 1, 2, 3, 4], [1, 2, 0, 3, 4], [0, 1, 2, 4, 3]])
+    grp = perm.complete_sym_group(gens)
+    assert grp.shape == (6, 5) and len({tuple(p) for p in grp}) == 6
+    assert np.array_equal(grp[:3], gens)  # candidates first, discoveries appended
+    assert perm.complete_sym_group(gens, n_perms_max=5) is None  # closure abandoned at the cap
+    assert sorted(map(sorted, perm.to_cycles([1, 2, 0, 4, 3]))) == [[0, 1, 2], [3, 4]]
+    # a 2-cycle that overlaps a 3-cycle of another candidate is dropped, the 3-cycle survives
+    kept = perm.salvage_subgroup(np.array([[0, 1, 2, 3], [1, 2, 0, 3], [1, 0, 2, 3]]))
+    assert [tuple(p) for p in kept] == [(0, 1, 2, 3), (1, 2, 0, 3)]
+
+
+def test_create_task_discovers_perms_without_reference():
+    from sgdml_amd.train import GDMLTrain
+
+    g = np.load(os.path.join(GOLD, 'perm_c3.npz'))
+    n = g['R'].shape[0]
+    rs = np.random.RandomState(0)
+    ds = {'type': 'd', 'name': np.array('c3'), 'theory': np.array('none'), 'z': g['z'], 'R': g['R'],
+          'F': rs.normal(size=g['R'].shape), 'E': rs.normal(size=n)}
+    tr = GDMLTrain()
+    try:
+        np.random.seed(1)
+        task = tr.create_task(ds, n, ds, 0, sig=10)
+        assert {tuple(p) for p in task['perms']} == {tuple(p) for p in g['perms']}
+    finally:
+        tr.__del__()
+
+
+def test_draw_strat_sample_reproduces_reference_indices():
+    """draw_strat_sample restates train.py:1537-1646 because the RNG call sequence must be identical for a
+    drop-in: under the same seed it returns the reference's indices (fixtures from make_golden_r2.py)."""
+    from sgdml_amd.train import GDMLTrain
+
+    g = np.load(os.path.join(GOLD, 'strat_sample.npz'))
+    t = GDMLTrain()
+    try:
+        for k in range(int(g['n_cases'])):
+            excl = g['excl%d' % k]
+            np.random.seed(int(g['seed%d' % k]))
+            idx = t.draw_strat_sample(g['T'], int(g['n%d' % k]), excl_idxs=excl if excl.size else None)
+            assert np.array_equal(np.asarray(idx, dtype=np.int64), g['idx%d' % k]), k
+    finally:
+        t.__del__()

@@ -427,11 +427,11 @@ def test_K_large_molecule_global_table(ctx):
     assert np.abs(K - Ko).max() <= 1e-12 * np.abs(Ko).max()
 
 
-def test_K_global_table_path_with_perms(golden, ctx, monkeypatch):
+def test_K_global_table_path_with_perms(golden, ctx):
     """Same code path forced on the small fixtures (covers permutations and E-constraint rows)."""
     g = golden
-    monkeypatch.setenv('GDML_ASM_GJG', '1')
-    monkeypatch.setenv('GDML_ASM_NO_WAVE', '1')
+    ctx.set_option('asm.gj_global', 1)
+    ctx.set_option('asm.wave', 0)
     ctx.train_upload(g['R_desc'], g['R_d_desc'], _tril_perms(g))
     K = ctx.assemble_K(float(g['sig']), bool(g['use_E_cstr']), to_host=True)
     assert np.abs(K - g['K']).max() <= 1e-12 * np.abs(g['K']).max()
@@ -749,11 +749,10 @@ def test_predict_mfma_randomised(ctx_factory, monkeypatch):
         aE = rs.normal(size=M) if with_aE else None
         c = ctx_factory()
         c.predict_upload_model(xd, ja, tp, sig, aE)
-        monkeypatch.delenv('GDML_PREDICT_V1', raising=False)
         E1, F1 = c.predict(Rf[M:])
-        monkeypatch.setenv('GDML_PREDICT_V1', '1')
+        c.set_option('predict.wave_only', 1)
         E0, F0 = c.predict(Rf[M:])
-        monkeypatch.delenv('GDML_PREDICT_V1', raising=False)
+        c.set_option('predict.wave_only', 0)
         assert np.abs(F1 - F0).max() <= 1e-11 * np.abs(F0).max(), (N, M, B, P, with_aE, sig)
         assert np.abs(E1 - E0).max() <= 1e-11 * np.abs(E0).max(), (N, M, B, P, with_aE, sig)
         c.close()
