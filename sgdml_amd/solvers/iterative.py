@@ -137,6 +137,8 @@ class Iterative(object):
         budget = free_b if self._max_memory is None else min(free_b, int(self._max_memory) * 1024**3)
         n_inducing_pts = min(n_train, Iterative.max_n_inducing_pts_device(n_train, n_atoms, 0.8 * budget))
         n_inducing_pts = max(1, n_inducing_pts)
+        if getattr(self.gdml_train, '_force_n_inducing_pts', None):
+            n_inducing_pts = min(n_train, int(self.gdml_train._force_n_inducing_pts))
         n_inducing_pts_init = (
             len(task['inducing_pts_idxs']) // dim_i if 'inducing_pts_idxs' in task else None
         )

@@ -34,6 +34,7 @@ class GDMLTrain(object):
         self._use_torch = use_torch  # accepted for API compatibility; the HIP backend always runs
         self._ctx = None
         self._force_solver = None  # testing hook: 'analytic' or 'cg' overrides the memory-based choice
+        self._force_n_inducing_pts = None  # testing hook: inducing points of the iterative solver (else memory model)
 
     def __del__(self):
         global _instance_alive
