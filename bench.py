@@ -3,18 +3,25 @@
 Benchmark of the sGDML hot path on MI355X (BASELINE.json metric: kernel-matrix build+solve
 wall-clock [s] and predict forces/s at N_train=1000, aspirin-sized = 21 atoms).
 
-One "step" = one pass of the hot path over one synthetic batch, with all inputs resident in HBM
-before the timed region starts:
-    assemble K (63 000 x 63 000 fp64, stays in HBM)  ->  in-place fp64 MFMA Cholesky of -K + lam I
-    ->  two triangular solves (alphas)  ->  batched force/energy prediction of B query geometries.
-
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N=1: plain python)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-With N > 1 every rank trains an independent model of the reference's hyper-parameter grid
-(sgdml/cli.py:806: one task per sigma, no data-path collective) -> "scaling": "weak".
+N = 1 (headline, BASELINE.json configs[1]): one "step" = one pass of the hot path over one synthetic batch,
+all inputs resident in HBM before the timed region starts:
+    assemble -K + lam I (63 000 x 63 000 fp64, lower blocks, stays in HBM)  ->  in-place fp64 MFMA Cholesky
+    ->  triangular solves (alphas)  ->  batched force/energy prediction of B query geometries.
+  `value` = build+solve seconds.  The line also carries `configs`: configs[0]-shaped sigma sweep
+  (N=9, P=6, M=200, 9 sigmas, 1000 validation + 5000 test geometries, sgdml_amd.sweep) and the configs[2]
+  workload below measured on this one GPU (the 1-GPU point of the strong-scaling curve), and `cpu_baseline`.
 
-Prints ONE JSON line (rank 0).  `value` = build+solve seconds per model (max over ranks).
+N > 1 (BASELINE.json configs[2]: aspirin N_train=5000, iterative solver sharded over the GPUs with RCCL):
+  one "step" = assemble this rank's rows of K_nm (n x m, m = 3N k inducing columns), Nystroem factor (RCCL
+  all-reduce of the m x m blocks), then a FIXED number of PCG iterations (query-sharded mat-vec + all-gather,
+  row-sharded preconditioner: all-reduce of an m-vector + all-gather).  Total work is fixed -> "strong";
+  `value` = seconds per step (max over ranks).  `one_gpu_s_per_step`: the same step unsharded on rank 0's GPU,
+  measured in the same run.  The sigma-grid replicas of round 1 (weak scaling, no collective) are gone.
+
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import ctypes as C
@@ -54,84 +61,170 @@ def synth_geometries(n_atoms, n_frames, seed=0, jitter=0.3, n_conformers=4, spac
     return R, E, F
 
 
-def cpu_baseline(n_atoms, sample_M, sig, lam, full_M):
-    """Times the oracle (NumPy port of the reference's algorithm) on a bounded sample on the host
-    and extrapolates assembly ~ M^2 and Cholesky ~ M^3 to the benchmark size."""
+def cpu_baseline(n_atoms, sig, lam, full_M, M_single=100, M_threads=300):
+    """The oracle (NumPy port of the reference's algorithm, kind = "port") timed on the host cores on bounded
+    samples of the same workload: M_single training points on ONE thread and M_threads points with the BLAS /
+    LAPACK pool unrestricted (all host cores).  MEASURED numbers are reported as they are; the extrapolation to
+    the benchmark size (assembly ~ M^2, factorisation ~ M^3) is reported separately and labelled."""
     from oracle import gdml_oracle as orc
 
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
-    big_M = sample_M  # the all-cores run uses the same sample
-    R, E, F = synth_geometries(n_atoms, big_M + 64, seed=0)
+    R, E, F = synth_geometries(n_atoms, max(M_single, M_threads) + 64, seed=0)
     Rf = R.reshape(len(R), -1)
     tp = orc.tril_perms_from_atom_perms(np.arange(n_atoms)[None])
     lin = orc.tril_perms_lin_from_tril_perms(tp)
 
-    def run(sample_M):
-        xo, go = orc.desc_from_R(Rf[:sample_M])
+    def run(m):
+        xo, go = orc.desc_from_R(Rf[:m])
         t0 = time.perf_counter()
         K = orc.assemble_K(xo, go, lin, sig)
         t1 = time.perf_counter()
-        y = F[:sample_M].ravel() / np.std(F[:sample_M])
+        y = F[:m].ravel() / np.std(F[:m])
         alphas, used_lu = orc.analytic_solve(K, y, lam)
         t2 = time.perf_counter()
-        JA = orc.d_desc_dot_vec(go, alphas.reshape(sample_M, -1))
-        xq, gq = orc.desc_from_R(Rf[sample_M:sample_M + 64])
+        JA = orc.d_desc_dot_vec(go, alphas.reshape(m, -1))
+        xq, gq = orc.desc_from_R(Rf[m:m + 64])
         orc.predict_from_desc(xq, gq, xo, JA, tp, sig)
         t3 = time.perf_counter()
-        return t1 - t0, t2 - t1, (t3 - t2), used_lu
-
-    import os
+        return {'M': m, 'n': m * 3 * n_atoms, 'assemble_s': t1 - t0, 'solve_s': t2 - t1,
+                'predict_geoms_per_s': 64.0 / (t3 - t2), 'lu_fallback': bool(used_lu)}
 
     cores = os.cpu_count() or 1
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
-            ta1, tc1, tp1, lu1 = run(sample_M)
+            m1 = run(M_single)
     else:
-        ta1, tc1, tp1, lu1 = run(sample_M)
-    ta, tc, tpred, used_lu = run(big_M)  # BLAS/LAPACK threads unrestricted: all host cores
-    # threaded LAPACK is far from its asymptotic rate at the sample's n = 3N M; time dpotrf + dpotrs on a
-    # larger SPD matrix as well and extrapolate the factorisation from there (cubic), whichever is lower
-    import scipy.linalg as sla
+        m1 = run(M_single)
+    mt = run(M_threads)  # BLAS/LAPACK threads unrestricted: all host cores
 
-    n_big = 16000
-    rs = np.random.RandomState(0)
-    G = rs.standard_normal((n_big, 256))
-    Abig = G @ G.T
-    Abig[np.diag_indices(n_big)] += n_big
-    t0 = time.perf_counter()
-    cf = sla.cho_factor(Abig, overwrite_a=True, check_finite=False)
-    sla.cho_solve(cf, np.ones(n_big), check_finite=False)
-    t_big = time.perf_counter() - t0
-    del Abig, cf, G
-    n_full = full_M * 3 * n_atoms
-    tc_full_from_big = t_big * (n_full / float(n_big)) ** 3
-    s1, s = full_M / float(sample_M), full_M / float(big_M)
-    est1 = ta1 * s1**2 + tc1 * s1**3
-    est = ta * s**2 + min(tc * s**3, tc_full_from_big)
-    geoms_per_s = max(64.0 / tpred / s, 64.0 / tp1 / s1)  # predict cost ~ M per query
-    best_is_threaded = est <= est1
+    def extrap(m):
+        sc = full_M / float(m['M'])
+        return m['assemble_s'] * sc**2 + m['solve_s'] * sc**3
+
+    est1, estt = extrap(m1), extrap(mt)
+    best_threads = estt <= est1
     return {
-        'value': min(est, est1),  # the faster of the two host configurations
+        'value': min(est1, estt),  # EXTRAPOLATED build+solve seconds at the benchmark size (see `measured`)
         'unit': 's',
-        'cores': cores if best_is_threaded else 1,
+        'cores': cores if best_threads else 1,
         'kind': 'port',
-        'sample': (
-            'oracle (NumPy port of train.py:97-302 + scipy cho_factor/cho_solve) at M={} with the BLAS/LAPACK '
-            'thread pool unrestricted on {} host cores: assemble {:.2f} s, Cholesky+solve {:.2f} s{}; extrapolated to '
-            'M={} by M^2 / M^3, the factorisation alternatively from dpotrf+dpotrs at n=16000 ({:.2f} s, cubic), the '
-            'lower of the two used; predict {:.0f} geoms/s extrapolated (~1/M).  Single thread at M={}: assemble '
-            '{:.2f} s, Cholesky+solve {:.2f} s -> {:.0f} s extrapolated'
-        ).format(
-            big_M, cores, ta, tc, ' (LU fallback)' if used_lu else '', full_M, t_big, geoms_per_s, sample_M, ta1, tc1,
-            est1,
-        ),
-        'predict_geoms_per_s': geoms_per_s,
-        'value_single_thread': est1,
-        'value_all_cores': est,
+        'sample': ('oracle/gdml_oracle.py (NumPy restatement of train.py:97-302 + scipy cho_factor/cho_solve) '
+                   'measured at M={} (n={}) on 1 thread and at M={} (n={}) with the BLAS/LAPACK pool on all {} '
+                   'host cores; `value` extrapolates the faster of the two to M={} (assembly ~M^2, solve ~M^3)'
+                   ).format(m1['M'], m1['n'], mt['M'], mt['n'], cores, full_M),
+        'measured': {'one_thread': m1, 'all_cores': mt},
+        'extrapolated_s': {'one_thread': est1, 'all_cores': estt},
+        'predict_geoms_per_s': max(m1['predict_geoms_per_s'] * m1['M'], mt['predict_geoms_per_s'] * mt['M']) / full_M,
+        'host': {'nproc': cores},
     }
+
+
+# ----------------------------------------------------------------------------------------------------------
+# BASELINE configs[2]: aspirin-sized N_train = 5000, Nystroem-preconditioned CG (sharded when the context has a
+# communicator).  One step = K_nm rows + Nystroem factor + a fixed number of PCG iterations.
+def make_cg_workload(ctx, n_atoms, n_train, k_inducing, sig, lam):
+    R, E, F = synth_geometries(n_atoms, n_train, seed=0)  # identical on every rank
+    N3 = 3 * n_atoms
+    y = F.ravel().copy()
+    y /= np.std(y)
+    tp = np.arange(n_atoms * (n_atoms - 1) // 2, dtype=np.int64)[None]
+    xd, gd = ctx.desc_from_R(R.reshape(n_train, -1), n_atoms)
+    ctx.train_upload(xd, gd, tp)
+    ctx.predict_upload_model(xd, np.zeros_like(xd), tp, sig, None)
+    pts = np.sort(np.random.RandomState(1).choice(n_train, k_inducing, replace=False))
+    idx = (pts[:, None] * N3 + np.arange(N3)[None]).ravel().astype(np.int64)
+    return {'y': y, 'idx': idx, 'sig': sig, 'lam': lam, 'n': n_train * N3, 'm': idx.size}
+
+
+def cg_step(ctx, wl, n_iters):
+    ctx.assemble_K(wl['sig'], False, idx=wl['idx'], alloc_extra_rows=wl['m'])
+    ctx.nystroem_factor(wl['lam'], wl['idx'])
+    x, info, iters, resid = ctx.pcg(wl['lam'], False, wl['y'], rtol=0.0, maxiter=n_iters)  # rtol 0: exactly n_iters
+    assert iters == n_iters, (iters, n_iters)
+    return resid, {k: ctx.phase_ms(k)[0] for k in ('assemble', 'precon', 'pcg')}
+
+
+def time_cg(ctx, wl, n_iters, steps, warmup, barrier):
+    for _ in range(warmup):
+        cg_step(ctx, wl, n_iters)
+    barrier()
+    c0, b0 = ctx.comm_stats()
+    t0 = time.perf_counter()
+    ph = []
+    for _ in range(steps):
+        resid, p = cg_step(ctx, wl, n_iters)
+        ph.append(p)
+    barrier()
+    t1 = time.perf_counter()
+    c1, b1 = ctx.comm_stats()
+    phases = {k: float(np.mean([p[k] for p in ph])) for k in ph[0]}
+    return {'s_per_step': (t1 - t0) / max(1, steps), 'phases_ms': phases, 'ms_per_pcg_iteration': phases['pcg'] / n_iters,
+            'resid_over_norm_y': float(resid / np.linalg.norm(wl['y'])),
+            'collectives_per_step': (c1 - c0) / max(1, steps), 'collective_bytes_per_step_per_rank': (b1 - b0) / max(1, steps)}
+
+
+def cg_algorithmic_bytes(wl, n_iters, world):
+    """HBM bytes one rank's dominant kernels must move per step: the preconditioner factor X (n/W x m fp64) is read
+    twice per PCG iteration (X^T v, then X t), K_nm is written once; the mat-vec tables are cache resident."""
+    x_bytes = 8.0 * wl['n'] * wl['m'] / world
+    return x_bytes * (1 + 2 * n_iters), 2.0 * x_bytes
+
+
+def sigma_sweep_config0(n_train=200, n_valid=1000, n_test=5000, sigs=None):
+    """BASELINE configs[0] shape (`sgdml all <9 atoms> 200 1000 5000`): N=9, P=6, the whole train -> validate ->
+    select -> test loop of sgdml_amd.sweep on synthetic geometries."""
+    from sgdml_amd.sweep import sigma_sweep
+    from sgdml_amd.train import GDMLTrain
+
+    N = 9
+    n_all = n_train + n_valid + n_test + 64
+    R, E, F = synth_geometries(N, n_all, seed=5)
+    ds = {'type': 'd', 'name': np.array('synth9'), 'theory': np.array('pair'), 'z': np.array([6, 6, 8, 1, 1, 1, 1, 1, 1]),
+          'R': R, 'E': E, 'F': F}
+    perms = [tuple(range(N))]
+    gens = [(1, 2, 0, 3, 4, 5, 6, 7, 8), (0, 1, 2, 4, 3, 5, 6, 7, 8)]
+    frontier = list(perms)
+    while frontier:
+        nxt = []
+        for a in frontier:
+            for g in gens:
+                c = tuple(a[i] for i in g)
+                if c not in perms:
+                    perms.append(c)
+                    nxt.append(c)
+        frontier = nxt
+    np.random.seed(0)
+    tr = GDMLTrain()
+    try:
+        t0 = time.perf_counter()
+        best, table, tm = sigma_sweep(tr, ds, n_train, n_valid, n_test, sigs=sigs, perms=np.array(perms), early_stop=False)
+        wall = time.perf_counter() - t0
+    finally:
+        tr.__del__()
+    geoms = tm['n_models'] * tm['n_valid'] + tm['n_test']
+    return {
+        'config': 'configs[0] shape: N=9 P={} N_train={} sigma grid of {} models, {} validation + {} test geometries '
+                  '(sgdml_amd.sweep.sigma_sweep = the loop of `sgdml all`)'.format(len(perms), n_train, tm['n_models'],
+                                                                                 tm['n_valid'], tm['n_test']),
+        'wall_s': wall, 'create_task_s': tm['create_task_s'], 'train_s': tm['train_s'],
+        'validate_s': tm['validate_s'], 'test_s': tm['test_s'],
+        'validate_test_geoms_per_s': geoms / max(1e-9, tm['validate_s'] + tm['test_s']),
+        'best_sig': float(best['sig']), 'best_f_rmse': best['f_err']['rmse'],
+        'valid_f_rmse_by_sig': {str(r[0]): r[4] for r in table},
+    }
+
+
+def load_pmc_traffic():
+    """HBM traffic of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected
+    as MI355X_MICROARCH.md prescribes), committed by tools/pmc_traffic.py as profiles/hbm_traffic.json."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 def main():
@@ -144,10 +237,15 @@ def main():
     ap.add_argument('--n-query', type=int, default=1000)
     ap.add_argument('--sig', type=float, default=20.0)
     ap.add_argument('--lam', type=float, default=1e-10)
-    ap.add_argument('--cpu-sample', type=int, default=100, help='training points of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU-baseline leg')
+    ap.add_argument('--no-configs', action='store_true', help='N=1: skip the configs[0] sweep and the configs[2] point')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--separate-solve', action='store_true',
                     help='A/B: forward substitution as a separate triangular solve instead of inside the factorisation')
+    ap.add_argument('--cg-n-train', type=int, default=5000)
+    ap.add_argument('--cg-inducing', type=int, default=200)
+    ap.add_argument('--cg-iters', type=int, default=50, help='PCG iterations per step of the configs[2] workload')
+    ap.add_argument('--comm', default='auto', help="N>1: 'rccl', 'host' (gloo-staged), or auto (rccl if every rank has a GPU)")
     args = ap.parse_args()
 
     # stdout carries exactly one line (the JSON): libraries that print banners to fd 1 (gloo's rank
@@ -158,36 +256,98 @@ def main():
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    out = run_sharded_cg(args, rank, world) if world > 1 else run_analytic(args)
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+
+
+def run_sharded_cg(args, rank, world):
+    """N > 1: the configs[2] workload sharded over the ranks (one process per GPU, RCCL inside the library)."""
+    import torch  # plumbing only: rendezvous, barrier, max-reduce of the timings (CPU tensors over gloo)
+    import torch.distributed as dist
+
+    from sgdml_amd import _lib
+    from sgdml_amd.dist import init_comm_from_torch_distributed
+
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    dist_dev = 'cpu'
-    if world > 1:
-        import torch  # plumbing only: rendezvous, barrier, max-reduce of the timings
-        import torch.distributed as dist
+    dist.init_process_group('gloo')
+    n_dev = _lib.device_count()
+    comm = args.comm
+    if comm == 'auto':
+        comm = 'rccl' if n_dev >= world else 'host'  # fewer GPUs than ranks: functional run, ranks share GPUs
+    ctx = _lib.Context(local_rank % max(1, n_dev))
+    init_comm_from_torch_distributed(ctx, backend=comm)
 
-        n_dev = torch.cuda.device_count()
-        if n_dev >= world:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-            dist_dev = 'cuda'
-        else:  # fewer GPUs than ranks (functional test of the N > 1 path on a small box)
-            dist.init_process_group('gloo')
-            local_rank = local_rank % max(1, n_dev)
+    def barrier():
+        ctx.sync()
+        dist.barrier()
 
+    N, M, k = args.n_atoms, args.cg_n_train, args.cg_inducing
+    wl = make_cg_workload(ctx, N, M, k, args.sig, args.lam)
+    res = time_cg(ctx, wl, args.cg_iters, args.steps, args.warmup, barrier)
+    t = torch.tensor([res['s_per_step'], res['phases_ms']['assemble'], res['phases_ms']['precon'], res['phases_ms']['pcg']],
+                     dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    s_per_step, asm_ms, pre_ms, pcg_ms = [float(v) for v in t]
+    ctx.close()
+
+    one_gpu = None
+    if rank == 0:  # the 1-GPU point of the curve, same run, same GPU as rank 0
+        c1 = _lib.Context(local_rank % max(1, n_dev))
+        wl1 = make_cg_workload(c1, N, M, k, args.sig, args.lam)
+        one_gpu = time_cg(c1, wl1, args.cg_iters, 1, 1, c1.sync)
+        c1.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank != 0:
+        return None
+    tot_bytes, iter_bytes = cg_algorithmic_bytes(wl, args.cg_iters, world)
+    ach = iter_bytes / (pcg_ms / args.cg_iters * 1e-3) / 1e9
+    return {
+        'metric': 'sharded Nystroem-PCG solve wall-clock per step (K_nm rows + preconditioner + {} PCG iterations), '
+                  'N_train={} {}-atom (aspirin-sized)'.format(args.cg_iters, M, N),
+        'value': s_per_step, 'unit': 's', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': s_per_step * 1e3, 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'aspirin-sized N=21 N_train={} iterative solver (Nystroem-preconditioned CG, k={} inducing '
+                               'points, {} iterations per step), kernel rows sharded over {} GPUs with {} '
+                               '(BASELINE.json configs[2])'.format(M, k, args.cg_iters, world,
+                                                                   'RCCL' if comm == 'rccl' else 'host-staged gloo collectives'),
+                   'n_atoms': N, 'n_train': M, 'n_inducing_points': k, 'matrix_n': wl['n'], 'precon_m': wl['m'],
+                   'pcg_iterations_per_step': args.cg_iters, 'sig': args.sig, 'lam': args.lam,
+                   'parallelism': 'row-sharded Nystroem factor + query-sharded mat-vec over {} ranks'.format(world),
+                   'collectives': comm},
+        'phases_ms': {'assemble': asm_ms, 'precon': pre_ms, 'pcg': pcg_ms},
+        'ms_per_pcg_iteration': pcg_ms / args.cg_iters,
+        'collectives_per_step': res['collectives_per_step'],
+        'collective_bytes_per_step_per_rank': res['collective_bytes_per_step_per_rank'],
+        'resid_over_norm_y': res['resid_over_norm_y'],
+        'one_gpu_s_per_step': None if one_gpu is None else one_gpu['s_per_step'],
+        'one_gpu': one_gpu,
+        'roofline': {'kernel': 'gemv_t_part_kernel + gemv_n_precon_kernel (preconditioner X^T v, X t of one PCG iteration)',
+                     'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                     'traffic': None,
+                     'note': 'achieved = 2 x (n/W x m x 8 B) per iteration / whole-iteration time (mat-vec, dots and '
+                             'collectives included)'},
+        'cpu_baseline': None,
+    }
+
+
+def run_analytic(args):
     from sgdml_amd import _lib
 
     N, M, B = args.n_atoms, args.n_train, args.n_query
     N3 = 3 * N
     n = M * N3
-    # every rank = one task of the sigma grid (cli.py:806) on its own seeded data
-    sig = args.sig + 10.0 * rank
-    R, E, F = synth_geometries(N, M + B, seed=rank)
+    sig = args.sig
+    R, E, F = synth_geometries(N, M + B, seed=0)
     Rf = R.reshape(M + B, -1)
     y = F[:M].ravel().copy()
     y_std = np.std(y)
     y /= y_std
 
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(0)
     tp = np.zeros((1, N * (N - 1) // 2), dtype=np.int64)
     tp[0] = np.arange(tp.shape[1])
     xd, gd = ctx.desc_from_R(Rf[:M], N)
@@ -201,26 +361,17 @@ def main():
     Rq = np.ascontiguousarray(Rf[M:])
     ctx._check(lib.gdml_memcpy_h2d(ctx._h, dR, Rq.ctypes.data_as(C.c_void_p), Rq.nbytes))
 
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            import torch
-
-            if dist_dev == 'cuda':
-                torch.cuda.synchronize()
-            dist.barrier()
-
     phases = {'assemble': [], 'factor': [], 'solve': [], 'predict': []}
     info_last = [0]
 
     def step(record):
         # the calls of sgdml_amd.solvers.analytic.Analytic.solve
         if args.separate_solve:
-            ctx.assemble_K(sig, False)
+            ctx.assemble_K(sig, False, for_cholesky=args.lam)
             info_last[0] = ctx.chol_factor(args.lam)
             alphas = ctx.chol_solve(y)
         else:
-            ctx.assemble_K(sig, False, alloc_extra_rows=1)
+            ctx.assemble_K(sig, False, alloc_extra_rows=1, for_cholesky=args.lam)
             ctx.chol_set_rhs(y)
             info_last[0] = ctx.chol_factor(args.lam)
             alphas = ctx.chol_solve(None)
@@ -240,91 +391,99 @@ def main():
         step(False)
     if not args.no_profile:
         ctx.profile(True)
-    barrier()
+    ctx.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         alphas = step(True)
-    barrier()
+    ctx.sync()
     t1 = time.perf_counter()
     wall_ms = (t1 - t0) * 1e3 / max(1, args.steps)
-
     build_solve_ms = float(np.mean(phases['assemble']) + np.mean(phases['factor']) + np.mean(phases['solve']))
     pred_ms = float(np.mean(phases['predict']))
-    vals = np.array([wall_ms, build_solve_ms, pred_ms])
-    if dist is not None:
-        import torch
 
-        t = torch.tensor(vals, device=dist_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        vals = t.cpu().numpy()
-    wall_ms, build_solve_ms, pred_ms = [float(v) for v in vals]
-
-    out = None
-    if rank == 0:
-        # sanity of the result that was timed: residual of the solve through the matrix-free operator
-        Kv = ctx.kernel_matvec(args.lam, False, -alphas)
-        resid = float(np.linalg.norm(-Kv - y) / np.linalg.norm(y))  # (-K + lam I) x = -(Kx - lam x)
-        if not resid < 1e-8:  # a fast wrong answer is not a result (tolerance of the solve parity tests)
-            raise SystemExit('bench: residual of the timed solve is %.3e (> 1e-8): refusing to report' % resid)
-        roof = None
-        extra = {}
-        if not args.no_profile:
-            g_ms, g_n, g_fl = ctx.kernel_stat('gemm_nt_sub')
-            a_ms, a_n, a_by = ctx.kernel_stat('assemble')
-            p_ms, p_n, p_fl = ctx.kernel_stat('predict')
-            if g_ms > 0:
-                ach = g_fl / (g_ms * 1e-3) / 1e12
-                roof = {'kernel': 'gemm_nt_sub_kernel (fp64 MFMA SYRK/GEMM of the blocked Cholesky)',
-                        'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                        'frac': ach / FP64_MFMA_PEAK_TF, 'traffic': None,
-                        'launches': g_n, 'avg_launch_ms': g_ms / max(1, g_n),
-                        'algorithmic_flops_per_launch': g_fl / max(1, g_n)}
-            if a_ms > 0:
-                ach = a_by / (a_ms * 1e-3) / 1e9
-                extra['roofline_assemble'] = {'kernel': 'assemble_kernel', 'bound': 'hbm', 'achieved': ach,
-                                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                                              'traffic': None, 'avg_launch_ms': a_ms / max(1, a_n)}
-            if p_ms > 0:
-                extra['predict_kernel'] = {'kernel': 'predict_kernel', 'avg_launch_ms': p_ms / max(1, p_n),
-                                           'algorithmic_TFLOPs': p_fl / (p_ms * 1e-3) / 1e12}
-        chol_tf = (n**3 / 3.0) / (np.mean(phases['factor']) * 1e-3) / 1e12
-        out = {
-            'metric': 'kernel-matrix build+solve wall-clock, N_train={} {}-atom (aspirin-sized)'.format(M, N),
-            'value': build_solve_ms / 1e3,
-            'unit': 's',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': wall_ms,
-            'higher_is_better': False,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'f64',
-            'data': 'synthetic',
-            'config': {'workload': 'aspirin-sized N=21 N_train={} analytic Cholesky, 1xMI355X per model '
-                                   '(BASELINE.json configs[1])'.format(M),
-                       'n_atoms': N, 'n_train': M, 'n_perms': 1, 'sig': sig, 'lam': args.lam,
-                       'matrix_n': n, 'query_batch': B, 'parallelism': 'replicas (one sigma-grid task per GPU)'},
-            'phases_ms': {k: float(np.mean(v)) for k, v in phases.items()},
-            'cholesky_info': info_last[0],
-            'solve_rel_residual': resid,
-            'cholesky_TFLOPs_whole_factorization': chol_tf,
-            'predict': {'geoms_per_s': world * B / (pred_ms * 1e-3), 'forces_per_s': world * B * N3 / (pred_ms * 1e-3),
-                        'batch': B, 'ms': pred_ms},
-            'roofline': roof,
-        }
-        out.update(extra)
-        if args.cpu_sample > 0:
-            out['cpu_baseline'] = cpu_baseline(N, args.cpu_sample, args.sig, args.lam, M)
-        else:
-            out['cpu_baseline'] = None
+    # sanity of the result that was timed: residual of the solve through the matrix-free operator
+    Kv = ctx.kernel_matvec(args.lam, False, -alphas)
+    resid = float(np.linalg.norm(-Kv - y) / np.linalg.norm(y))  # (-K + lam I) x = -(Kx - lam x)
+    if not resid < 1e-8:  # a fast wrong answer is not a result (tolerance of the solve parity tests)
+        raise SystemExit('bench: residual of the timed solve is %.3e (> 1e-8): refusing to report' % resid)
+    roof = None
+    extra = {}
+    traffic = load_pmc_traffic()
+    if not args.no_profile:
+        g_ms, g_n, g_fl = ctx.kernel_stat('gemm_nt_sub')
+        a_ms, a_n, a_by = ctx.kernel_stat('assemble')
+        p_ms, p_n, p_fl = ctx.kernel_stat('predict')
+        if g_ms > 0:
+            ach = g_fl / (g_ms * 1e-3) / 1e12
+            tr = traffic.get('gemm_nt_sub', {})
+            roof = {'kernel': 'gemm_nt_sub_kernel (fp64 MFMA SYRK/GEMM of the blocked Cholesky)',
+                    'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                    'frac': ach / FP64_MFMA_PEAK_TF, 'traffic': tr.get('hbm_bytes_per_launch'),
+                    'traffic_source': tr.get('source'),
+                    'launches': g_n, 'avg_launch_ms': g_ms / max(1, g_n),
+                    'algorithmic_flops_per_launch': g_fl / max(1, g_n)}
+        if a_ms > 0:
+            ach = a_by / (a_ms * 1e-3) / 1e9
+            tr = traffic.get('assemble', {})
+            extra['roofline_assemble'] = {'kernel': 'assemble_wave_kernel (-K + lam I, blocks on/below the diagonal)',
+                                          'bound': 'hbm', 'achieved': ach,
+                                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                                          'traffic': tr.get('hbm_bytes_per_launch'), 'traffic_source': tr.get('source'),
+                                          'algorithmic_bytes_per_launch': a_by / max(1, a_n),
+                                          'avg_launch_ms': a_ms / max(1, a_n)}
+        if p_ms > 0:
+            extra['predict_kernel'] = {'kernel': 'predict_kernel', 'avg_launch_ms': p_ms / max(1, p_n),
+                                       'algorithmic_TFLOPs': p_fl / (p_ms * 1e-3) / 1e12}
+    chol_tf = (n**3 / 3.0) / (np.mean(phases['factor']) * 1e-3) / 1e12
+    out = {
+        'metric': 'kernel-matrix build+solve wall-clock, N_train={} {}-atom (aspirin-sized)'.format(M, N),
+        'value': build_solve_ms / 1e3,
+        'unit': 's',
+        'n_gpus': 1,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': wall_ms,
+        'higher_is_better': False,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': 'aspirin-sized N=21 N_train={} analytic Cholesky, 1xMI355X '
+                               '(BASELINE.json configs[1])'.format(M),
+                   'n_atoms': N, 'n_train': M, 'n_perms': 1, 'sig': sig, 'lam': args.lam,
+                   'matrix_n': n, 'query_batch': B, 'parallelism': 'single GPU'},
+        'phases_ms': {k: float(np.mean(v)) for k, v in phases.items()},
+        'cholesky_info': info_last[0],
+        'solve_rel_residual': resid,
+        'cholesky_TFLOPs_whole_factorization': chol_tf,
+        'predict': {'geoms_per_s': B / (pred_ms * 1e-3), 'forces_per_s': B * N3 / (pred_ms * 1e-3),
+                    'batch': B, 'ms': pred_ms},
+        'roofline': roof,
+    }
+    out.update(extra)
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    if not args.no_configs:
+        cfgs = []
+        try:
+            cfgs.append(sigma_sweep_config0())
+        except Exception as e:  # the headline must not die with an extra
+            cfgs.append({'config': 'configs[0] sweep', 'error': repr(e)})
+        try:
+            c2 = _lib.Context(0)
+            wl = make_cg_workload(c2, N, args.cg_n_train, args.cg_inducing, args.sig, args.lam)
+            r2 = time_cg(c2, wl, args.cg_iters, 1, 1, c2.sync)
+            c2.close()
+            tot_bytes, iter_bytes = cg_algorithmic_bytes(wl, args.cg_iters, 1)
+            r2['config'] = ('configs[2] workload on ONE GPU (1-GPU point of the strong-scaling curve `bench.py --gpus N` '
+                            'measures): N=21 N_train={} k={} inducing points, {} PCG iterations per step').format(
+                                args.cg_n_train, args.cg_inducing, args.cg_iters)
+            r2['precon_hbm_GBs'] = iter_bytes / (r2['ms_per_pcg_iteration'] * 1e-3) / 1e9
+            cfgs.append(r2)
+        except Exception as e:
+            cfgs.append({'config': 'configs[2] one-GPU point', 'error': repr(e)})
+        out['configs'] = cfgs
+    out['cpu_baseline'] = None if args.no_cpu else cpu_baseline(N, args.sig, args.lam, M)
+    return out
 
 
 if __name__ == '__main__':

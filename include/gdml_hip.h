@@ -128,6 +128,16 @@ int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind, int
                     int64_t col_b, const int64_t* idx, int64_t n_idx, int64_t alloc_extra_rows,
                     double* K_host_out, int64_t ldk);
 
+/* Analytic path (Analytic.solve, analytic.py:65-94): the system matrix A = -K + lam I in the form
+ * gdml_chol_factor consumes, assembled in one pass -- sign flip (analytic.py:65) and regularisation
+ * (analytic.py:82) fused into the stores, and only the blocks on/below the block diagonal written (the
+ * factorisation never reads the strict upper triangle): 4 n^2 bytes of HBM traffic instead of 8 n^2 written +
+ * 8 n^2 re-read and re-written.  All columns, matrix stays on the device; alloc_extra_rows as above (1 for
+ * gdml_chol_set_rhs).  Where the fused form is not available (permutations, energy constraints, N > 21) this is
+ * gdml_assemble_K(GDML_COLS_ALL) and gdml_chol_factor applies sign and shift itself.  gdml_chol_factor must be
+ * called with the same lam. */
+int gdml_assemble_A(gdml_ctx* ctx, double sig, double lam, int use_E_cstr, int64_t alloc_extra_rows);
+
 /* Shape of the device-resident matrix produced by the last gdml_assemble_K. */
 int gdml_K_shape(gdml_ctx* ctx, int64_t* n_rows, int64_t* n_cols, int64_t* extra_rows);
 

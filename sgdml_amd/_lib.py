@@ -33,6 +33,7 @@ SIGNATURES = {
     'gdml_train_upload': (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_int]),
     'gdml_assemble_K': (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64,
                                   C.c_int64, _vp, C.c_int64]),
+    'gdml_assemble_A': (C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.c_int64]),
     'gdml_K_shape': (C.c_int, [_vp, _ip, _ip, _ip]),
     'gdml_chol_set_rhs': (C.c_int, [_vp, _vp, C.c_int64]),
     'gdml_chol_factor': (C.c_int, [_vp, C.c_double, C.POINTER(C.c_int)]),
@@ -85,6 +86,13 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def device_count():
+    """Number of visible HIP devices (0 without a GPU)."""
+    n = C.c_int(0)
+    load().gdml_device_count(C.byref(n))
+    return n.value
 
 
 def _ptr(a):
@@ -278,8 +286,16 @@ class Context(object):
         self._train_fp = fp
         self.n_train, self.n_atoms = M, n_atoms
 
-    def assemble_K(self, sig, use_E_cstr=False, points=None, idx=None, alloc_extra_rows=0, to_host=False):
-        """Returns the host copy (rows+extra, cols) if to_host else None (matrix stays on the GPU)."""
+    def assemble_K(self, sig, use_E_cstr=False, points=None, idx=None, alloc_extra_rows=0, to_host=False,
+                   for_cholesky=None):
+        """Returns the host copy (rows+extra, cols) if to_host else None (matrix stays on the GPU).
+        for_cholesky=lam: all columns, device only, assembled as A = -K + lam I for chol_factor (gdml_assemble_A)."""
+        if for_cholesky is not None:
+            if points is not None or idx is not None or to_host:
+                raise ValueError('for_cholesky assembles the full device-resident system matrix')
+            self._check(self._lib.gdml_assemble_A(self._h, float(sig), float(for_cholesky), int(bool(use_E_cstr)),
+                                                  int(alloc_extra_rows)))
+            return None
         kind, a, b, ip, n_idx = COLS_ALL, 0, 0, None, 0
         if points is not None:
             kind, (a, b) = COLS_POINTS, points

@@ -550,9 +550,11 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   return GDML_OK;
 }
 
-extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind,
-                               int64_t col_a, int64_t col_b, const int64_t* idx, int64_t n_idx,
-                               int64_t alloc_extra_rows, double* K_host_out, int64_t ldk) {
+// as_A: assemble for the analytic solve (gdml_assemble_A): where the register-resident kernel applies the
+// matrix is produced directly as A = -K + lam I, blocks on/below the block diagonal only.
+static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind, int64_t col_a, int64_t col_b,
+                         const int64_t* idx, int64_t n_idx, int64_t alloc_extra_rows, double* K_host_out,
+                         int64_t ldk, int as_A, double lam) {
   if (!ctx) return GDML_ERR_INVALID;
   TrainSet& ts = ctx->ts;
   if (!ts.x) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_assemble_K: call gdml_train_upload first");
@@ -662,6 +664,10 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
   ctx->K_rhs_row = false;
   ctx->K_sig = sig;
   ctx->K_use_E = use_E_cstr;
+  const bool lower_A = as_A && col_kind == GDML_COLS_ALL && !use_E_cstr && !sharded && assemble_wave_applicable(ctx) &&
+                       ctx_opt_i(ctx, "asm.lower", 1) != 0;
+  ctx->K_is_A = lower_A;
+  if (lower_A) ctx->K_lam = lam;
 
   int32_t *d_jlist = nullptr, *d_colmap = nullptr, *d_ep = nullptr, *d_ec = nullptr;
   if (!dense && n_j > 0) {
@@ -693,7 +699,8 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
     if (i_end <= i_beg)
       rc = GDML_OK;
     else if (assemble_wave_applicable(ctx))
-      rc = assemble_wave_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, ctx->K, ld, i_beg, i_end);
+      rc = assemble_wave_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, ctx->K, ld, i_beg, i_end,
+                                lower_A ? 1 : 0, lam);
     else
       rc = assemble_dispatch(ctx, A, n_j);
   }
@@ -727,4 +734,15 @@ extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int co
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   return GDML_OK;
+}
+
+extern "C" int gdml_assemble_K(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind,
+                               int64_t col_a, int64_t col_b, const int64_t* idx, int64_t n_idx,
+                               int64_t alloc_extra_rows, double* K_host_out, int64_t ldk) {
+  return assemble_impl(ctx, sig, use_E_cstr, col_kind, col_a, col_b, idx, n_idx, alloc_extra_rows, K_host_out, ldk,
+                       0, 0.0);
+}
+
+extern "C" int gdml_assemble_A(gdml_ctx* ctx, double sig, double lam, int use_E_cstr, int64_t alloc_extra_rows) {
+  return assemble_impl(ctx, sig, use_E_cstr, GDML_COLS_ALL, 0, 0, nullptr, 0, alloc_extra_rows, nullptr, 0, 1, lam);
 }

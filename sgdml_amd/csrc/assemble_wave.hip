@@ -60,6 +60,8 @@ struct WaveArgs {
   int j_chunk;
   double* K;
   int64_t ld;
+  int lower;      // 1: only blocks j <= i (dense column range), values stored as -K, + lam on the diagonal:
+  double lam;     //    the matrix A = -K + lam I in the form the Cholesky factorisation reads (analytic.py:65,82)
 };
 
 template <int N>
@@ -72,8 +74,10 @@ __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
   const int b = c / 3, beta = c - 3 * b;
   const int64_t i = A.i_beg + blockIdx.x;
   const int64_t jb_beg = (int64_t)blockIdx.y * A.j_chunk;
-  const int64_t jb_end = (jb_beg + A.j_chunk < A.n_j) ? jb_beg + A.j_chunk : A.n_j;
+  int64_t jb_end = (jb_beg + A.j_chunk < A.n_j) ? jb_beg + A.j_chunk : A.n_j;
+  if (A.lower && jb_end > i - A.j0 + 1) jb_end = i - A.j0 + 1;  // blocks on/below the block diagonal only
   if (jb_beg >= jb_end) return;
+  const double sgn = A.lower ? -1.0 : 1.0;
 
   const double sig = A.sig, inv_sig = 1.0 / sig;
   const double sqrt5 = 2.23606797749978969641;
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
     const double nrm2 = wave_sum(act ? ss : 0.0) * (1.0 / 6.0);
     const double nrm = sqrt5 * sqrt(nrm2);
     const double ex = exp(-nrm * inv_sig);
-    const double bp = ex * base_div;
+    const double bp = sgn * ex * base_div;  // sign of the stored matrix folded into both coefficients
     const double cp = (sig * sig + sig * nrm) * bp;
     const double uc = 5.0 * bp * u;
     // exchange v through LDS (single wavefront: LDS operations are in order)
@@ -154,13 +158,18 @@ __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
           o0 = vsh[3 * a + 0] * uc - cp * g0;
           o1 = vsh[3 * a + 1] * uc - cp * g1;
           o2 = vsh[3 * a + 2] * uc - cp * g2;
+          if (A.lower && A.j0 + jb == i) {  // diagonal block: + lam on the matrix diagonal (row 3a+al == column c)
+            o0 += (beta == 0) ? A.lam : 0.0;
+            o1 += (beta == 1) ? A.lam : 0.0;
+            o2 += (beta == 2) ? A.lam : 0.0;
+          }
         }
         dst[0] = o0;
         dst[A.ld] = o1;
         dst[2 * A.ld] = o2;
         dst += 3 * A.ld;
       }
-      if (A.use_E) A.K[(A.M * N3 + i) * A.ld + outcol] = -e_fact * (nrm + sig) * ex * u;  // train.py:235-248
+      if (A.use_E) A.K[(A.M * N3 + i) * A.ld + outcol] = -e_fact * (nrm + sig) * ex * u;  // train.py:235-248 (never with lower)
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -191,13 +200,17 @@ bool assemble_wave_applicable(const gdml_ctx* ctx) {
 
 int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist,
                          const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld,
-                         int64_t i_beg, int64_t i_end) {
+                         int64_t i_beg, int64_t i_end, int lower, double lam) {
   TrainSet& ts = ctx->ts;
   GDML_TRY(build_dense_tables(ctx));
   WaveArgs A;
   A.XF = ts.XF; A.GD = ts.GD; A.M = ts.M; A.N = ts.N; A.sig = sig; A.use_E = use_E;
   A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.n_j = n_j; A.K = K; A.ld = ld;
   A.i_beg = i_beg;
+  A.lower = lower;
+  A.lam = lam;
+  if (lower && (d_jlist || d_colmap || use_E || j0 != 0 || i_beg != 0))
+    return gdml_fail(ctx, GDML_ERR_INVALID, "assemble_wave: lower form needs the dense full column range");
   const int64_t n_i = i_end - i_beg;
   if (n_i <= 0) return GDML_OK;
   int j_chunk = ctx_opt_i(ctx, "asm.j_chunk", 64);
@@ -212,7 +225,9 @@ int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
 #undef WC
     default: return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_wave: N out of range");
   }
-  ktime_end(ctx, slot, "assemble", 8.0 * (double)n_i * 3.0 * ts.N * (double)n_j * 3.0 * ts.N);
+  // algorithmic bytes: every requested element written once (lower form: the n_i (n_i + 1) / 2 blocks with j <= i)
+  const double blocks = lower ? 0.5 * (double)n_i * (double)(n_i + 1) : (double)n_i * (double)n_j;
+  ktime_end(ctx, slot, "assemble", 8.0 * blocks * 9.0 * ts.N * ts.N);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;

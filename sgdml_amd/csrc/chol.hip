@@ -670,6 +670,13 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
   }
   hipStream_t sm = ctx->stream, sp = ctx->stream2;
   hipEvent_t evA = ctx->ev_la[0], evB = ctx->ev_la[1];
+  // schedule experiments: another stream for the panel chain; the trailing SYRK split into chunks that
+  // alternate between the main stream and a second bulk stream
+  const int ps_idx = ctx_opt_i(ctx, "chol.panel_stream", -1);
+  if (ps_idx >= 0) GDML_TRY(ctx_pool_stream(ctx, ps_idx, &sp));
+  const int syrk_chunks = ctx_opt_i(ctx, "chol.syrk_chunks", 1);
+  hipStream_t sm2 = nullptr;
+  if (syrk_chunks > 1) GDML_TRY(ctx_pool_stream(ctx, ctx_opt_i(ctx, "chol.syrk_stream", 1), &sm2));
   // late phase: once fewer than mask_rows rows remain the panel chain is the critical path; from then
   // on the two streams are a CU-masked pair, so that the panel kernels never queue behind GEMM workgroups
   const int64_t mask_rows = (int64_t)ctx_opt(ctx, "chol.mask_rows", 0);
@@ -704,7 +711,17 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
     // (2) rest of the trailing matrix: C[t1:n, t1:n] -= P[t1:n] P[t1:n]^T  (lower)
     if (t1 < n) {
       const double* P1 = A + t1 * ld + k0;
-      GDML_TRY(launch_gemm_nt_sub(ctx, sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1));
+      if (syrk_chunks > 1 && lookahead && n - t1 > 8192 && n_rows == n) {
+        HIP_CHECK(ctx, hipStreamWaitEvent(sm2, evA, 0));
+        for (int c = 0; c < syrk_chunks; ++c)
+          GDML_TRY(launch_gemm_nt_sub_part(ctx, (c & 1) ? sm2 : sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, n - t1, n - t1, nb,
+                                           1, (double)c / syrk_chunks, (c + 1 == syrk_chunks) ? 1.0 : (double)(c + 1) / syrk_chunks,
+                                           true));
+        HIP_CHECK(ctx, hipEventRecord(ctx->ev_pool[0], sm2));
+        HIP_CHECK(ctx, hipStreamWaitEvent(sm, ctx->ev_pool[0], 0));
+      } else {
+        GDML_TRY(launch_gemm_nt_sub(ctx, sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1));
+      }
     }
     if (lookahead)
       HIP_CHECK(ctx, hipStreamWaitEvent(sm, evB, 0));
@@ -968,10 +985,15 @@ extern "C" int gdml_chol_factor(gdml_ctx* ctx, double lam, int* info) {
   if (ctx->K_factored) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_factor: already factored");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int64_t n = ctx->K_rows;
+  if (ctx->K_is_A && lam != ctx->K_lam)
+    return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_chol_factor: lam (%g) differs from the one gdml_assemble_A used (%g)",
+                     lam, ctx->K_lam);
   phase_begin(ctx);
-  hipLaunchKernelGGL(negate_shift_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->K, n,
-                     ctx->K_ld, lam);
-  ctx->launch_counter++;
+  if (!ctx->K_is_A) {  // un-negated K from gdml_assemble_K: A = -K + lam I on the lower triangle (analytic.py:65,82)
+    hipLaunchKernelGGL(negate_shift_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->K, n,
+                       ctx->K_ld, lam);
+    ctx->launch_counter++;
+  }
   int inf = 0;
   GDML_TRY(chol_factor_device(ctx, ctx->K, n, ctx->K_ld, &inf, ctx->K_rhs_row ? n + 1 : n));
   GDML_TRY(phase_end(ctx, "factor"));

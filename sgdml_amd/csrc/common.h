@@ -69,6 +69,8 @@ struct gdml_ctx {
   hipStream_t kt_stream = nullptr;                       // stream the per-kernel timers record on (default: stream)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_la[2] = {nullptr, nullptr};  // look-ahead hand-off between the two streams
+  hipStream_t pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // schedule experiments
+  hipEvent_t ev_pool[4] = {nullptr, nullptr, nullptr, nullptr};
   std::string err;
   std::map<std::string, double> opts;  // tuning / ablation options (gdml_set_option); absent key = built-in default
   int64_t held = 0;
@@ -91,6 +93,7 @@ struct gdml_ctx {
   double* K = nullptr;
   int64_t K_rows = 0, K_cols = 0, K_extra = 0, K_ld = 0, K_bytes = 0;
   bool K_factored = false;
+  bool K_is_A = false;      // the buffer already holds A = -K + lam I (lower blocks; gdml_assemble_A): factor skips the sign flip
   bool K_rhs_row = false;   // row K_rows of the buffer carries a right-hand side (gdml_chol_set_rhs)
   double* d_rhs = nullptr;  // device copy of that right-hand side (iterative refinement)
   double K_lam = 0, K_sig = 0;
@@ -149,6 +152,7 @@ int ctx_scratch(gdml_ctx* ctx, int64_t bytes, double** out);
 void phase_begin(gdml_ctx* ctx);
 // kernel timing (no-ops unless ctx->profiling)
 int ctx_masked_streams(gdml_ctx* ctx, int reserve_cus);  // creates stream_mm / stream_mp
+int ctx_pool_stream(gdml_ctx* ctx, int idx, hipStream_t* out);  // lazily created extra streams (0-3 normal, 4-7 high priority)
 int phase_resolve(gdml_ctx* ctx);  // reads a pending phase timer (waits for its end event)
 int ktime_begin(gdml_ctx* ctx);  // returns slot or -1
 void ktime_end(gdml_ctx* ctx, int slot, const char* name, double work);
@@ -198,4 +202,4 @@ static inline bool comm_active(const gdml_ctx* ctx) { return (ctx->comm || ctx->
 bool assemble_wave_applicable(const gdml_ctx* ctx);
 int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist,
                          const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld,
-                         int64_t i_beg, int64_t i_end);
+                         int64_t i_beg, int64_t i_end, int lower = 0, double lam = 0.0);

@@ -29,6 +29,7 @@ static const char* kKnownOptions[] = {
     "asm.wave", "asm.threads", "asm.ib", "asm.minw", "asm.gj_global", "asm.j_chunk", "asm.debug", "asm.lower",
     "gemm.debug", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.split", "chol.aux_cus",
     "chol.mask_rows", "chol.mask_cus", "chol.panel_a", "chol.panel_b", "chol.gemm_tf", "chol.panel_kernel",
+    "chol.panel_stream", "chol.syrk_chunks", "chol.syrk_stream",
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
     "lu.nb", "comm.force_collectives"};
 
@@ -144,6 +145,10 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
   if (ctx->h_coll) hipHostFree(ctx->h_coll);
+  for (int i = 0; i < 8; ++i)
+    if (ctx->pool[i]) hipStreamDestroy(ctx->pool[i]);
+  for (int i = 0; i < 4; ++i)
+    if (ctx->ev_pool[i]) hipEventDestroy(ctx->ev_pool[i]);
   if (ctx->stream_mm) hipStreamDestroy(ctx->stream_mm);
   if (ctx->stream_mp) hipStreamDestroy(ctx->stream_mp);
   delete ctx;
@@ -272,6 +277,20 @@ int ctx_masked_streams(gdml_ctx* ctx, int reserve_cus) {
   HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ctx->stream_mm, (uint32_t)mm.size(), mm.data()));
   HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ctx->stream_mp, (uint32_t)mp.size(), mp.data()));
   ctx->masked_cus = reserve_cus;
+  return GDML_OK;
+}
+
+// Extra streams for schedule experiments (option chol.panel_stream / chol.syrk_chunks): created in index order
+// on first use, so that index i always maps to the same hardware-queue slot of the process.
+int ctx_pool_stream(gdml_ctx* ctx, int idx, hipStream_t* out) {
+  if (idx < 0 || idx >= 8) return gdml_fail(ctx, GDML_ERR_INVALID, "stream pool index %d", idx);
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  for (int i = 0; i <= idx; ++i)
+    if (!ctx->pool[i]) HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->pool[i], hipStreamNonBlocking, i < 4 ? lo : hi));
+  for (int i = 0; i < 4; ++i)
+    if (!ctx->ev_pool[i]) HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_pool[i], hipEventDisableTiming));
+  *out = ctx->pool[idx];
   return GDML_OK;
 }
 

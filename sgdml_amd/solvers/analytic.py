@@ -34,10 +34,10 @@ class Analytic(object):
             cb = partial(cb, disp_str='Assembling kernel matrix')
             cb(0, 100)
         start = timeit.default_timer()
-        # un-negated K, device resident (analytic.py:65); one spare row: the right-hand side rides along
-        # through the factorisation, whose panel solves and trailing updates then perform the forward
-        # substitution of cho_solve (analytic.py:97)
-        ctx.assemble_K(sig, use_E_cstr, alloc_extra_rows=1)
+        # A = -K + lam I, device resident (analytic.py:65,82 fused into the assembly where the kernel allows it);
+        # one spare row: the right-hand side rides along through the factorisation, whose panel solves and
+        # trailing updates then perform the forward substitution of cho_solve (analytic.py:97)
+        ctx.assemble_K(sig, use_E_cstr, alloc_extra_rows=1, for_cholesky=lam)
         ctx.chol_set_rhs(y)
         if cb is not None:
             dur_s = timeit.default_timer() - start

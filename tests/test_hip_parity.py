@@ -756,3 +756,40 @@ def test_predict_mfma_randomised(ctx_factory, monkeypatch):
         assert np.abs(F1 - F0).max() <= 1e-11 * np.abs(F0).max(), (N, M, B, P, with_aE, sig)
         assert np.abs(E1 - E0).max() <= 1e-11 * np.abs(E0).max(), (N, M, B, P, with_aE, sig)
         c.close()
+
+
+@pytest.mark.parametrize('N,M', [(21, 40), (9, 70), (5, 33)])
+def test_assemble_A_lower_form(ctx_factory, N, M):
+    """gdml_assemble_A: A = -K + lam I written directly, blocks on/below the block diagonal only.  The written
+    part must equal -K + lam I of the oracle elementwise, and factor + solve must agree with the two-step path
+    (gdml_assemble_K, sign flip and shift inside gdml_chol_factor) to the conditioning of the system."""
+    ds = orc.synth_dataset(N, M, seed=5, jitter=0.3)
+    xo, go = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    sig, lam = 20.0, 1e-8
+    Ko = orc.assemble_K(xo, go, orc.tril_perms_lin_from_tril_perms(tp), sig)
+    n, N3 = Ko.shape[0], 3 * N
+    Ao = -Ko + lam * np.eye(n)
+    y = ds['F'].ravel() / np.std(ds['F'])
+    c = ctx_factory()
+    c.train_upload(xo, go, tp)
+    c.assemble_K(sig, False, alloc_extra_rows=1, for_cholesky=lam)
+    A = c.K_to_host()[:n]
+    blk_lower = np.kron(np.tril(np.ones((M, M))), np.ones((N3, N3))).astype(bool)
+    assert np.abs((A - Ao)[blk_lower]).max() <= 1e-12 * np.abs(Ko).max()
+    c.chol_set_rhs(y)
+    assert c.chol_factor(lam) == 0
+    a1 = c.chol_solve(None)
+    with pytest.raises(ValueError):  # a different lam than the assembly used
+        c.assemble_K(sig, False, for_cholesky=lam)
+        c.chol_factor(2 * lam)
+    c2 = ctx_factory()
+    c2.set_option('asm.lower', 0)  # same entry point, two-step form
+    c2.train_upload(xo, go, tp)
+    c2.assemble_K(sig, False, alloc_extra_rows=1, for_cholesky=lam)
+    c2.chol_set_rhs(y)
+    assert c2.chol_factor(lam) == 0
+    a2 = c2.chol_solve(None)
+    for a in (a1, a2):
+        assert np.linalg.norm(Ao @ (-a) - y) <= 1e-9 * np.linalg.norm(y)
+    assert np.abs(a1 - a2).max() <= 1e-6 * np.abs(a2).max()
