@@ -156,6 +156,14 @@ int gdml_K_shape(gdml_ctx* ctx, int64_t* n_rows, int64_t* n_cols, int64_t* extra
  *   substitution L z = y on the way (cho_solve's first triangular solve, analytic.py:97, for free);
  *   gdml_chol_solve(y = NULL) then only runs the backward substitution. */
 int gdml_chol_set_rhs(gdml_ctx* ctx, const double* y, int64_t n);
+/* LU branch of Analytic.solve (analytic.py:101-114: scipy.linalg.solve = LAPACK dgesv, taken when cho_factor
+ * raised LinAlgError): needs the FULL un-negated K of gdml_assemble_K(GDML_COLS_ALL) (assemble again after a
+ * failed gdml_chol_factor, which destroys the matrix), forms A = -K + lam I on both triangles, factors
+ * P A = L U with partial pivoting on the device (blocked, trailing updates on fp64 MFMA) and returns
+ * alphas = -(A^-1 y).  *info > 0: U(info,info) is exactly zero (dgetrf convention; scipy raises "Matrix is
+ * singular") and the function returns GDML_ERR_NOT_PD.  The matrix is consumed.
+ * The least-squares branch (analytic.py:138) only runs for a non-square K, which Analytic.solve never builds. */
+int gdml_lu_solve(gdml_ctx* ctx, double lam, const double* y, int64_t n, double* alphas_out, int* info);
 int gdml_chol_factor(gdml_ctx* ctx, double lam, int* info);
 int gdml_chol_solve(gdml_ctx* ctx, const double* y, int64_t n, int n_refine, double* alphas_out);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     'gdml_K_shape': (C.c_int, [_vp, _ip, _ip, _ip]),
     'gdml_chol_set_rhs': (C.c_int, [_vp, _vp, C.c_int64]),
     'gdml_chol_factor': (C.c_int, [_vp, C.c_double, C.POINTER(C.c_int)]),
+    'gdml_lu_solve': (C.c_int, [_vp, C.c_double, _vp, C.c_int64, _vp, C.POINTER(C.c_int)]),
     'gdml_chol_solve': (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp]),
     'gdml_predict_upload_model': (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_double, _vp]),
     'gdml_set_alphas': (C.c_int, [_vp, _vp, _vp]),
@@ -347,6 +348,15 @@ class Context(object):
         info = C.c_int(0)
         self._check(self._lib.gdml_chol_factor(self._h, float(lam), C.byref(info)))
         return info.value
+
+    def lu_solve(self, lam, y):
+        """alphas = -(A^-1 y), A = -K + lam I, by LU with partial pivoting (the full K of assemble_K must be
+        resident and is consumed).  Raises numpy.linalg.LinAlgError for an exactly singular matrix."""
+        y = f64(y).ravel()
+        out = np.empty_like(y)
+        info = C.c_int(0)
+        self._check(self._lib.gdml_lu_solve(self._h, float(lam), _ptr(y), y.size, _ptr(out), C.byref(info)))
+        return out
 
     def chol_set_rhs(self, y):
         """Hands y over before chol_factor (K must have been assembled with alloc_extra_rows >= 1): the

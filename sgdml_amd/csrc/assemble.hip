@@ -661,6 +661,7 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
   ctx->K_extra = alloc_extra_rows;
   ctx->K_ld = ld;
   ctx->K_factored = false;
+  ctx->K_destroyed = false;
   ctx->K_rhs_row = false;
   ctx->K_sig = sig;
   ctx->K_use_E = use_E_cstr;

@@ -983,6 +983,8 @@ extern "C" int gdml_chol_factor(gdml_ctx* ctx, double lam, int* info) {
     return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_factor: resident K is %lld x %lld, not square",
                      (long long)ctx->K_rows, (long long)ctx->K_cols);
   if (ctx->K_factored) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_factor: already factored");
+  if (ctx->K_destroyed)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_chol_factor: the resident matrix was consumed by a failed factorisation: assemble again");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int64_t n = ctx->K_rows;
   if (ctx->K_is_A && lam != ctx->K_lam)
@@ -1001,6 +1003,7 @@ extern "C" int gdml_chol_factor(gdml_ctx* ctx, double lam, int* info) {
   ctx->K_lam = lam;
   if (inf != 0) {
     ctx->K_factored = false;
+    ctx->K_destroyed = true;
     return gdml_fail(ctx, GDML_ERR_NOT_PD,
                      "%d-th leading minor of the array is not positive definite", inf);
   }

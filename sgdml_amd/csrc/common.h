@@ -93,6 +93,7 @@ struct gdml_ctx {
   double* K = nullptr;
   int64_t K_rows = 0, K_cols = 0, K_extra = 0, K_ld = 0, K_bytes = 0;
   bool K_factored = false;
+  bool K_destroyed = false; // a failed Cholesky or an LU consumed the buffer: assemble again before factoring
   bool K_is_A = false;      // the buffer already holds A = -K + lam I (lower blocks; gdml_assemble_A): factor skips the sign flip
   bool K_rhs_row = false;   // row K_rows of the buffer carries a right-hand side (gdml_chol_set_rhs)
   double* d_rhs = nullptr;  // device copy of that right-hand side (iterative refinement)
@@ -106,8 +107,8 @@ struct gdml_ctx {
   // scratch
   double* scratch = nullptr;
   int64_t scratch_bytes = 0;
-  double* slot[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // cached work buffers (ctx_slot)
-  int64_t slot_bytes[6] = {0, 0, 0, 0, 0, 0};
+  double* slot[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // cached work buffers (ctx_slot)
+  int64_t slot_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int* d_info = nullptr;
 
   // comm
@@ -186,6 +187,7 @@ int set_alphas_device(gdml_ctx* ctx, const double* d_alphas_F, const double* d_a
 int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, int64_t n,
                   double* d_out);
 int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info, int64_t n_rows = 0);
+int lu_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int64_t* d_piv, int* info_out);
 int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_b,
                       double* d_z, double* d_x);
 int operator_model_from_trainset(gdml_ctx* ctx, double sig);

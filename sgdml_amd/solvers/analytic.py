@@ -21,6 +21,7 @@ class Analytic(object):
         self.desc = desc
         self.callback = callback
         self.n_refine = 0  # iterative-refinement steps (0 = LAPACK cho_solve semantics)
+        self.used_lu = False  # set when the last solve went through the LU branch (analytic.py:101-114)
 
     def solve(self, task, R_desc, R_d_desc, tril_perms_lin, y):
         sig, lam, use_E_cstr = task['sig'], task['lam'], task['use_E_cstr']
@@ -46,11 +47,20 @@ class Analytic(object):
             cb(NOT_DONE)
 
         start = timeit.default_timer()
-        # A = -K + lam I, A = L L^T (analytic.py:65,82,94).  A non-PD matrix raises
-        # numpy.linalg.LinAlgError here; the reference would retry with a dense LU
-        # (analytic.py:101-114) -- there is deliberately no CPU fallback in this backend.
-        ctx.chol_factor(lam)
-        alphas = ctx.chol_solve(None, n_refine=self.n_refine)  # backward substitution; = -A^-1 y (analytic.py:97-99)
+        try:
+            # A = -K + lam I, A = L L^T (analytic.py:65,82,94)
+            ctx.chol_factor(lam)
+            alphas = ctx.chol_solve(None, n_refine=self.n_refine)  # backward substitution; = -A^-1 y (analytic.py:97-99)
+        except np.linalg.LinAlgError:  # "Try a solver that makes less assumptions" (analytic.py:101-114)
+            if self.callback is not None:
+                cb = partial(self.callback, disp_str='Solving linear system (LU factorization)      ')  # Keep whitespaces!
+                cb(NOT_DONE)
+            self.used_lu = True
+            # the failed Cholesky consumed the matrix (the reference keeps a second copy, overwrite_a=False): the
+            # LU needs both triangles, so the full K is assembled again (milliseconds) and factored with partial
+            # pivoting on the device
+            ctx.assemble_K(sig, use_E_cstr)
+            alphas = ctx.lu_solve(lam, y)
 
         if self.callback is not None:
             dur_s = timeit.default_timer() - start

@@ -228,3 +228,84 @@ def test_sharded_iterative_processes_share_one_gpu(tmp_path, world):
         assert np.abs(F[1] - F[0]).max() <= 5e-3 * np.abs(F[0]).max()
     finally:
         c.close()
+
+
+def _upload_as_K(ctx, A):
+    """Load an arbitrary square matrix as the resident 'K' (so that -K + lam I = A for lam = 0): assemble a dummy
+    two-atom problem of the right order and overwrite the buffer (pattern of test_cholesky_multi_panel)."""
+    import ctypes as C
+
+    n = A.shape[0]
+    assert n % 6 == 0
+    M = n // 6
+    ds = orc.synth_dataset(2, M, seed=1)
+    xo, go = orc.desc_from_R(ds['R'].reshape(M, -1))
+    ctx.train_upload(xo, go, np.zeros((1, 1), dtype=np.int64))
+    ctx.assemble_K(10.0, False)
+    assert ctx.K_shape()[0] == n
+    p, ld = C.c_void_p(), C.c_int64()
+    ctx._check(ctx._lib.gdml_K_dev(ctx._h, C.byref(p), C.byref(ld)))
+    buf = np.zeros((n, ld.value))
+    buf[:, :n] = -A
+    ctx._check(ctx._lib.gdml_memcpy_h2d(ctx._h, p, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+
+
+@pytest.mark.parametrize('n', [66, 258, 1026])
+def test_lu_solve_general_matrix_vs_lapack(ctx, n):
+    """gdml_lu_solve on non-symmetric, indefinite matrices (partial pivoting really permutes): solution vs
+    scipy.linalg.solve (dgesv), several panels, ragged last panel."""
+    import scipy.linalg as sla
+
+    rs = np.random.RandomState(n)
+    A = rs.normal(size=(n, n))
+    A[rs.randint(0, n, 5), :] *= 1e-3  # weak rows: pivoting matters
+    y = rs.normal(size=n)
+    _upload_as_K(ctx, A)
+    x = -ctx.lu_solve(0.0, y)
+    xr = sla.solve(A, y)
+    assert np.linalg.norm(A @ x - y) <= 1e-12 * np.linalg.norm(A, 2) * np.linalg.norm(x)
+    assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max()
+    with pytest.raises(Exception):  # the matrix was consumed
+        ctx.lu_solve(0.0, y)
+
+
+def test_lu_solve_singular_reports(ctx):
+    n = 66
+    A = np.eye(n)
+    A[:, 40] = 0.0
+    A[40, :] = 0.0
+    _upload_as_K(ctx, A)
+    with pytest.raises(np.linalg.LinAlgError, match='singular'):
+        ctx.lu_solve(0.0, np.ones(n))
+
+
+def test_lu_branch_matches_reference():
+    """The fixture on which the reference's Cholesky failed and its LU branch ran (analytic.py:101-114): our
+    Cholesky reports the failure too, Analytic.solve takes the device LU, and the model predicts like the
+    reference's."""
+    from sgdml_amd.predict import GDMLPredict
+    from sgdml_amd.solvers.analytic import Analytic
+    from sgdml_amd.train import GDMLTrain
+
+    g = load('lu_branch')
+    took = []
+    orig = Analytic.solve
+
+    def spy(self, *a, **kw):
+        out = orig(self, *a, **kw)
+        took.append(self.used_lu)
+        return out
+
+    Analytic.solve = spy
+    tr = GDMLTrain()
+    try:
+        model = tr.train(make_task(g, lam=float(g['lam'])))
+    finally:
+        Analytic.solve = orig
+        tr.__del__()
+    assert took == [True]
+    pred = GDMLPredict(model)
+    nt = len(g['R_test'])
+    E, F = pred.predict(g['R_test'].reshape(nt, -1))
+    assert np.abs(F - g['F_test']).max() <= 1e-6 * np.abs(g['F_test']).max()
+    assert np.abs(E - g['E_test']).max() <= 1e-6 * np.abs(g['E_test']).max()
