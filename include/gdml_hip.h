@@ -90,6 +90,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   predict.wave_only (0), predict.mfma (1), predict.mfma_wide (1), predict.fill   prediction kernel choice
  *   lu.nb (64)            panel width of the LU fallback
  *   comm.force_collectives (0)  issue collectives even for world == 1 without a communicator (tests)
+ *   nys.force_qr (0)      take the alternative (QR-equivalent) branch of the second Nystroem factorisation (tests)
  * Unknown keys return GDML_ERR_INVALID. */
 int gdml_set_option(gdml_ctx* ctx, const char* key, double value);
 int gdml_get_option(gdml_ctx* ctx, const char* key, double* value_out, int* is_set_out);
@@ -212,8 +213,9 @@ int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, const double* 
  *   L^-1 K_mn (m x n) with the jitter-escalation semantics of _cho_factor_stable, keeps it
  *   resident as the preconditioner, returns the leverage scores (column squared norms,
  *   iterative.py:107-109) in lev_scores_out (n) and optionally the factor in
- *   LinvKmn_host_out (m x n row-major, may be NULL).  *info: 0 ok, 1 = second Cholesky
- *   needed the QR fallback branch (not implemented: GDML_ERR_NOT_PD).
+ *   LinvKmn_host_out (m x n row-major, may be NULL).  *info: 0 ok, 1 = the second Cholesky failed and
+ *   the alternative branch ran (the reference's QR of [K_nm; sqrt(lam) I], iterative.py:313-324; here a
+ *   shifted CholeskyQR3 on fp64 MFMA with the same R^T R up to rounding).
  * gdml_precon_apply: out = (L^T L v - v)/lam  (iterative.py:120-140).
  * gdml_pcg: preconditioned CG for (-K + lam I) x = y with scipy.sparse.linalg.cg semantics
  *   (iterative.py:740-752: rtol*||y||, atol = 0, x0 optional).  cb(iter, resid, x_host, user)

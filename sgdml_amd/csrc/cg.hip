@@ -355,13 +355,58 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
     GDML_TRY(comm_allreduce_sum(ctx, S, m * ld));
     hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, S, ld, m, lam);
     GDML_TRY(cho_factor_stable_dev(ctx, S, m, ld, backup, false, -14, &ok));  // iterative.py:304-306
-    if (!ok) {
+    if (ok && ctx_opt_i(ctx, "nys.force_qr", 0)) ok = 0;  // test hook: take the alternative branch
+    if (ok) {
+      GDML_TRY(tall_trsm(ctx, S, X, n_loc, m, ld));  // iterative.py:335-345
+    } else {
+      // "QR fact. (alt.)" (iterative.py:313-324): R of the stacked matrix [K_nm; sqrt(lam) I], i.e. the Cholesky
+      // factor of K_nm^T K_nm + lam I obtained WITHOUT trusting the Gram matrix.  Here: shifted CholeskyQR3 -- three
+      // rounds of (Gram on fp64 MFMA, small Cholesky, tall triangular solve); the first Gram is shifted so that
+      // its factorisation cannot fail, the two repetitions remove the shift's error (R = R3 R2 R1 is never
+      // formed: the triangular solves apply R1^-1, R2^-1, R3^-1 to K_nm in turn).  Backward stable like
+      // Householder QR for cond([K_nm; sqrt(lam) I]) up to ~1/eps, and GEMM-shaped instead of panel-bound.
       if (info) *info = 1;
-      return gdml_fail(ctx, GDML_ERR_NOT_PD,
-                       "second Nystroem Cholesky failed (the reference falls back to QR here, "
-                       "iterative.py:313-324: not implemented)");
+      const double eps = 2.220446049250313e-16;
+      double* B = S;  // the stacked sqrt(lam) I block lives right below X: one Gram launch covers both
+      HIP_CHECK(ctx, hipMemsetAsync(B, 0, m * ld * 8, ctx->stream));
+      hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, B, ld, m, sqrt(lam));
+      void* gtmp = nullptr;
+      GDML_TRY(ctx_alloc(ctx, &gtmp, m * ld * 8));
+      double* G = (double*)gtmp;
+      int rcq = GDML_OK;
+      for (int pass = 0; pass < 3 && rcq == GDML_OK; ++pass) {
+        // the replicated block B enters the Gram sum once: on rank 0 (or when nothing is sharded)
+        const int64_t rows = n_loc + ((!ctx->K_sharded || ctx->rank == 0) ? m : 0);
+        const int tiles = (int)((m + TT - 1) / TT);
+        hipLaunchKernelGGL(syrk_tn_kernel, dim3((unsigned)(tiles * (tiles + 1) / 2)), dim3(256), 0, ctx->stream, X, ld,
+                           rows, m, G, ld, tiles);
+        rcq = comm_allreduce_sum(ctx, G, m * ld);
+        if (rcq != GDML_OK) break;
+        if (pass == 0) {
+          std::vector<double> diag((size_t)m);
+          hipError_t e = hipMemcpy2DAsync(diag.data(), 8, G, (ld + 1) * 8, 8, m, hipMemcpyDeviceToHost, ctx->stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+          if (e != hipSuccess) {
+            rcq = gdml_fail(ctx, GDML_ERR_HIP, "Gram diagonal: %s", hipGetErrorString(e));
+            break;
+          }
+          double tr = 0.0;
+          for (double d : diag) tr += d;  // ||A||_2^2 <= ||A||_F^2 = trace(A^T A)
+          const double rows_tot = (double)sg.n + (double)m;
+          const double shift = 11.0 * ((double)m * rows_tot + (double)m * ((double)m + 1.0)) * eps * tr;
+          hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, G, ld, m, shift);
+        }
+        int inf = 0;
+        rcq = chol_factor_device(ctx, G, m, ld, &inf);
+        if (rcq == GDML_OK && inf != 0)
+          rcq = gdml_fail(ctx, GDML_ERR_NOT_PD, "Nystroem factor: K_nm^T K_nm + lam I is singular to working precision "
+                                                "(shifted CholeskyQR pass %d failed at pivot %d)", pass + 1, inf);
+        if (rcq == GDML_OK) rcq = tall_trsm(ctx, G, X, n_loc + m, m, ld);  // X and B (every rank its own copy of B)
+      }
+      int rcf = ctx_free(ctx, gtmp);
+      GDML_TRY(rcq);
+      GDML_TRY(rcf);
     }
-    GDML_TRY(tall_trsm(ctx, S, X, n_loc, m, ld));  // iterative.py:335-345
     GDML_TRY(phase_end(ctx, "precon"));
     return GDML_OK;
   };

@@ -14,6 +14,8 @@ Cases (files next to this script; every array float64 / int64):
   cfg4_n60_p1    configs[4] shape: N=60 (D=1770), P=1, M=4: sampled K rows, solve, predictions
   pcg_n9_m400    Iterative.solve (iterative.py:473-825) with the inducing columns it drew: iteration
                  count, residual norm after every iteration, final alphas, predictions
+  nys_qr         Nystroem factor through the reference's QR branch (iterative.py:313-324, second Cholesky forced
+                 to fail) next to its Cholesky branch
   lu_branch      a near-singular system on which scipy's Cholesky fails and the reference takes its LU
                  branch (analytic.py:101-114): alphas, predictions
 
@@ -309,7 +311,42 @@ def case_lu_branch():
          model_c=np.float64(model['c']), model_std=np.float64(model['std']), R_test=Rt, E_test=E_test, F_test=F_test)
 
 
-CASES = dict(perm_c3=case_perm_c3, strat_sample=case_strat_sample, cfg0_n9_p6=case_cfg0_n9_p6,
+def case_nys_qr():
+    """Iterative._nystroem_cholesky_factor with the second Cholesky made to fail, so that the reference takes its
+    QR branch (iterative.py:313-324).  The branch is hard to reach with real data (scipy's Cholesky only gives up
+    on Gram matrices that are indefinite by more than the 1e-15 of jitter it is allowed), hence the forced failure."""
+    r = ref()
+    Desc, Iterative, gt = r['Desc'], r['Iterative'], r['train']
+    N, M, sig, lam = 6, 14, 10, 1e-10
+    ds = orc.synth_dataset(N, M, seed=51, jitter=0.3)
+    perms = np.arange(N)[None, :]
+    desc = Desc(N, max_processes=1)
+    tril_perms = np.array([Desc.perm(p) for p in perms])
+    tril_perms_lin = (tril_perms + np.arange(len(perms))[:, None] * desc.dim).flatten('F')
+    R_desc, R_d_desc = desc.from_R(ds['R'].reshape(M, -1))
+    n = M * 3 * N
+    col_idxs = np.sort(np.random.RandomState(2).choice(n, 40, replace=False))
+    it = Iterative(gt, desc, None, 1, False)
+    fac_chol = it._nystroem_cholesky_factor(R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr=False,
+                                            col_idxs=col_idxs).copy()
+    calls = []
+    orig = it._cho_factor_stable
+
+    def failing_second(Mat, pre_reg=False, eps_mag_max=1):
+        calls.append(1)
+        return None if len(calls) == 2 else orig(Mat, pre_reg=pre_reg, eps_mag_max=eps_mag_max)
+
+    it._cho_factor_stable = failing_second
+    fac_qr = it._nystroem_cholesky_factor(R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr=False,
+                                          col_idxs=col_idxs, callback=lambda *a, **k: None).copy()
+    assert len(calls) == 2
+    d = np.abs(fac_qr.T @ fac_qr - fac_chol.T @ fac_chol).max() / np.abs(fac_chol.T @ fac_chol).max()
+    print('  nys_qr: |P_qr - P_chol| rel %.2e' % d, flush=True)
+    save('nys_qr', R_train=ds['R'], perms=perms, sig=np.float64(sig), lam=np.float64(lam), col_idxs=col_idxs,
+         L_inv_K_mn_qr=fac_qr, L_inv_K_mn_chol=fac_chol)
+
+
+CASES = dict(nys_qr=case_nys_qr, perm_c3=case_perm_c3, strat_sample=case_strat_sample, cfg0_n9_p6=case_cfg0_n9_p6,
              cfg3_n42_p27=case_cfg3_n42_p27, cfg4_n60_p1=case_cfg4_n60_p1, pcg_n9_m400=case_pcg_n9_m400,
              lu_branch=case_lu_branch)
 

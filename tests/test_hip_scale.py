@@ -309,3 +309,31 @@ def test_lu_branch_matches_reference():
     E, F = pred.predict(g['R_test'].reshape(nt, -1))
     assert np.abs(F - g['F_test']).max() <= 1e-6 * np.abs(g['F_test']).max()
     assert np.abs(E - g['E_test']).max() <= 1e-6 * np.abs(g['E_test']).max()
+
+
+def test_nystroem_qr_branch_matches_reference(ctx):
+    """Second Nystroem factorisation through the alternative branch (reference: QR of [K_nm; sqrt(lam) I],
+    iterative.py:313-324; here shifted CholeskyQR3): the factor is unique up to row signs, so L^T L (what the
+    preconditioner applies) is compared with the reference's QR-branch output, and the leverage scores with its
+    column norms."""
+    g = load('nys_qr')
+    M, N = g['R_train'].shape[:2]
+    sig, lam, idx = float(g['sig']), float(g['lam']), g['col_idxs']
+    xd, gd = ctx.desc_from_R(g['R_train'].reshape(M, -1), N)
+    tp = orc.tril_perms_from_atom_perms(g['perms'])
+    ctx.train_upload(xd, gd, tp)
+    ref = g['L_inv_K_mn_qr']
+    P_ref = ref.T @ ref
+    out = {}
+    for force in (0, 1):
+        ctx.set_option('nys.force_qr', force)
+        ctx.assemble_K(sig, False, idx=idx, alloc_extra_rows=len(idx))
+        lev, fac, info = ctx.nystroem_factor(lam, idx, want_factor=True)
+        assert info == force
+        P = fac.T @ fac
+        assert np.abs(P - P_ref).max() <= 1e-9 * np.abs(P_ref).max(), force
+        np.testing.assert_allclose(lev, (ref**2).sum(0), rtol=1e-8)
+        v = np.random.RandomState(0).normal(size=P.shape[0])
+        out[force] = ctx.precon_apply(lam, v)
+        np.testing.assert_allclose(out[force], (P_ref @ v - v) / lam, rtol=1e-6, atol=1e-6 * np.abs(out[force]).max())
+    ctx.set_option('nys.force_qr', 0)
