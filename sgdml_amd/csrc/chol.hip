@@ -49,8 +49,15 @@ struct GemmArgs {
   int64_t s_begin;  // first super tile of this launch (a launch may cover a sub-range)
   int super_n;      // super-tile columns
   int aligned;      // A, B 16-byte aligned with even leading dimensions (vector loads legal)
+  // fused launch (gemm_nt_sub_diag_kernel): workgroup 0 factors the next panel's diagonal block meanwhile
+  double* diagA;    // top-left element of that nb x nb block (leading dimension ldc), or null
+  int diag_nbw;     // nb / 64
+  int64_t diag_off; // global index of its first row (LAPACK info)
+  int* diag_info;
   int dbg;          // option gemm.debug: ablation bits: 1 no epilogue, 2 no tile loads, 4 no LDS reads, 8 no barrier
 };
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g);
 
 template <bool FULL>
 __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int64_t ld,
@@ -212,11 +219,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   }
 }
 
+// block index -> tile (XCD-aware 8x8 super tiles: block b runs on XCD b % 8) and the tile's GEMM
 template <bool ABL>
-__global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
-  // ---- block -> tile mapping: XCD-aware 8x8 super tiles (block b runs on XCD b % 8)
-  const int64_t b = blockIdx.x;
+__device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][GT * GPITCH], int64_t b) {
   const int64_t xcd = b & 7, loc = b >> 3;
   const int64_t s = g.s_begin + (loc >> 6) * 8 + xcd;
   const int within = (int)(loc & 63);
@@ -243,15 +248,29 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
     gemm_tile_body<false, ABL>(g, lds, row0, col0);
 }
 
+template <bool ABL>
+__global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
+  gemm_block<ABL>(g, lds, blockIdx.x);
+}
+
 // f0, f1: the launch covers the super tiles [f0 * n_super, f1 * n_super) (whole update: 0, 1);
 // timed: bracket with the per-kernel timers (only launches on the timing stream)
+struct DiagJob {
+  double* A = nullptr;  // top-left of the next panel's diagonal block
+  int nbw = 0;
+  int64_t off = 0;
+};
+
 static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
                                    const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
-                                   int64_t N, int64_t K, int lower, double f0, double f1, bool timed) {
+                                   int64_t N, int64_t K, int lower, double f0, double f1, bool timed,
+                                   const DiagJob* diag = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return GDML_OK;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.lower = lower;
+  g.diagA = nullptr; g.diag_nbw = 0; g.diag_off = 0; g.diag_info = nullptr;
   g.dbg = ctx_opt_i(ctx, "gemm.debug", 0);
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
               (lda % 2 == 0) && (ldb % 2 == 0);
@@ -266,7 +285,10 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   int64_t groups = (g.n_super - g.s_begin + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
   int64_t blocks = groups * 512;
   const int slot = (timed && st == (ctx->kt_stream ? ctx->kt_stream : ctx->stream)) ? ktime_begin(ctx) : -1;
-  if (g.dbg)
+  if (diag && diag->A) {
+    g.diagA = diag->A; g.diag_nbw = diag->nbw; g.diag_off = diag->off; g.diag_info = ctx->d_info;
+    hipLaunchKernelGGL(gemm_nt_sub_diag_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, st, g);
+  } else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL(gemm_nt_sub_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
@@ -335,6 +357,152 @@ __device__ __forceinline__ int potrf64_wave(double* T, double* col, int lane) {
   for (int c = 0; c < 64; ++c) T[lane * 65 + c] = row[c];
   __builtin_amdgcn_s_waitcnt(0xc07f);
   return fail;
+}
+
+// ------------------------------------------------------------------------------------------
+// Diagonal block of a panel, factored by ONE workgroup (256 threads) inside the trailing-update launch.
+// The 64-wide step chain (potrf64, rows below by substitution, rank-64 update) of the nb x nb block is a
+// dependent sequence of tiny kernels that the hardware does not overlap with a pending GEMM grid from another
+// stream (profiles/r02_sched_probe.txt) and that ran ~650 us per panel exposed.  As workgroup 0 of the SYRK launch
+// of the PREVIOUS panel -- which never touches these columns -- it is dispatched first and its ~0.5 ms on one CU
+// disappear behind the other workgroups' tiles.  Phases talk through global memory (the block is L2 resident);
+// all of them are executed by the same workgroup, so __syncthreads() orders them (waves of a workgroup share the
+// CU's vector L1).
+//   D: top-left of the block (row-major, ld), nbw = nb / 64.  lds: >= 67 KB (aliased onto the GEMM tile buffers).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int potrf64_wave(double* T, double* col, int lane);
+
+// 64 x 64 Cholesky (lower, in place in the LDS tile T, pitch 65) by a whole workgroup of 256 threads with 16
+// doubles of state per thread (the one-wavefront version keeps a row of 64 per lane, too many registers next to
+// the GEMM role's budget): thread (row = tid / 4, q = tid % 4) holds the columns k = q (mod 4) of its row.
+// Right-looking; per step the current column goes through a double-buffered LDS vector: one barrier per step.
+// Returns 0 or the 1-based index of the first non-positive pivot (same value in every thread).
+__device__ __forceinline__ int potrf64_wg(double* T, double* colbuf /* 2 x 64 */, int tid) {
+  const int row = tid >> 2, q = tid & 3;
+  double a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = T[row * 65 + q + 4 * i];
+  int fail = 0;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const int qj = j & 3, ij = j >> 2;
+    double* col = colbuf + (j & 1) * 64;
+    if (q == qj) col[row] = a[ij];
+    __syncthreads();
+    const double d = col[j];
+    if (!(d > 0.0) && fail == 0) fail = j + 1;
+    double ri = __builtin_amdgcn_rsq(d);
+    ri = ri * (1.5 - 0.5 * d * ri * ri);
+    ri = ri * (1.5 - 0.5 * d * ri * ri);
+    const double lr = col[row] * ri;  // L[row][j] (meaningful for row > j)
+    if (q == qj) a[ij] = (row == j) ? d * ri : lr;
+#pragma unroll
+    for (int i = ij; i < 16; ++i) {
+      const int c = q + 4 * i;  // columns right of j only
+      const double lc = col[c < 64 ? c : 63] * ri;
+      if (i > ij || q > qj) a[i] -= lr * lc;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[row * 65 + q + 4 * i] = a[i];
+  return fail;
+}
+
+__device__ __forceinline__ void diag_block_role(double* __restrict__ D, int64_t ld, int nbw, int64_t global_off,
+                                             int* __restrict__ info, double* lds) {
+  double* T = lds;                   // 64 x 65 (potrf); afterwards reused as S: 32 x 66 row block of the substitution
+  double* Lt = lds + 64 * 65;        // L_jj^T, pitch 65
+  double* rinv = Lt + 64 * 65;       // 64
+  double* col = rinv + 64;           // 2 x 64
+  double* S = T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int srow = tid >> 3, sq = tid & 7;
+  const int nb = 64 * nbw;
+  for (int jj = 0; jj < nbw; ++jj) {
+    const int c0 = 64 * jj;
+    double* Ad = D + (int64_t)c0 * ld + c0;
+    for (int r = wave; r < 64; r += 4) T[r * 65 + lane] = Ad[(int64_t)r * ld + lane];
+    __syncthreads();
+    {
+      const int fail = potrf64_wg(T, col, tid);
+      if (fail != 0 && tid == 0) atomicCAS(info, 0, (int)(global_off + c0 + fail));
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      const double v = (c <= r) ? T[r * 65 + c] : 0.0;
+      Lt[c * 65 + r] = v;
+      if (c <= r) Ad[(int64_t)r * ld + c] = v;
+      if (c == r) rinv[r] = 1.0 / v;
+    }
+    __syncthreads();
+    // rows below inside the block: x <- x L_jj^-T by exact substitution, 32 rows per pass, 8 threads per row
+    // (thread q of a row holds its columns k = q mod 8; same scheme as panel_trsm_kernel)
+    const int mrows = nb - c0 - 64;
+    for (int base = 0; base < mrows; base += 32) {
+      double* xr = D + (int64_t)(c0 + 64 + base + srow) * ld + c0;
+      double t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = xr[sq + 8 * i];
+#pragma unroll
+      for (int c = 0; c < 64; ++c) {
+        const int qc = c & 7, ic = c >> 3;
+        const double mine = t[ic] * rinv[c];
+        const double x = __shfl(mine, (lane & ~7) | qc, 64);
+        if (sq == qc) t[ic] = x;
+#pragma unroll
+        for (int i = ic; i < 8; ++i) {
+          const double l = Lt[c * 65 + sq + 8 * i];
+          if (i > ic || sq > qc) t[i] -= x * l;
+        }
+        // keep the scheduler from hoisting all 288 L reads of the unrolled loop to its top (register pressure)
+        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xr[sq + 8 * i] = t[i];
+    }
+    __syncthreads();
+    // rank-64 update of the rest of the block (lower 16 x 16 tiles): C -= X_r X_c^T, X = columns [c0, c0+64)
+    const int nt = mrows / 16;
+    const int ntiles = nt * (nt + 1) / 2;
+    for (int t = wave; t < ntiles; t += 4) {
+      int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while (ti * (ti + 1) / 2 > t) --ti;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      const int tj = t - ti * (ti + 1) / 2;
+      const int r0 = c0 + 64 + 16 * ti, q0 = c0 + 64 + 16 * tj;
+      double* Cp = D + (int64_t)(r0 + lk) * ld + q0 + li;  // C layout: row = lk + 4 r, col = li
+      d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = Cp[(int64_t)(4 * r) * ld];
+      const double* Ap = D + (int64_t)(r0 + li) * ld + c0 + 4 * lk;
+      const double* Bp = D + (int64_t)(q0 + li) * ld + c0 + 4 * lk;
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        const d4 a = *reinterpret_cast<const d4*>(Ap + 16 * ch);
+        const d4 b = *reinterpret_cast<const d4*>(Bp + 16 * ch);
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[sidx], b[sidx], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cp[(int64_t)(4 * r) * ld] = acc[r];
+    }
+    __syncthreads();
+  }
+  (void)S;
+}
+
+// Trailing update + (workgroup 0) the next panel's diagonal block.
+__global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
+  static_assert(sizeof(double) * 2 * 2 * GT * GPITCH >= sizeof(double) * (2 * 64 * 65 + 64 + 128), "LDS of the diagonal role");
+  if (blockIdx.x == 0) {
+    diag_block_role(g.diagA, g.ldc, g.diag_nbw, g.diag_off, g.diag_info, &lds[0][0][0]);
+    return;
+  }
+  gemm_block<false>(g, lds, (int64_t)blockIdx.x - 1);
 }
 
 __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
@@ -497,6 +665,149 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Row-local panel solve:  X[r, 0:nb] <- X[r, 0:nb] * L^-T  for m rows, L = nb x nb lower (already factored
+// diagonal block of the panel), nb = 64 * nbw <= 512.  Replaces the 8 x (trsm64 + K=64 GEMM over the whole
+// panel strip) of the panel chain by ONE launch in which every workgroup finishes its own 32 rows: the strip
+// is read once and written once instead of eight read-modify-write passes, and the products run on the MFMA pipe.
+//
+// Workgroup = 32 rows, 4 wavefronts.  The 32 x nb strip lives in REGISTERS in MFMA C-layout: wavefront w owns
+// the 64-column blocks {w, 7 - w} (each block 2 x 4 tiles of 16 x 16) -- the right-looking update work of
+// block c is c block products, so every wavefront does 7.  Step jj:
+//   (1) the owner of block jj writes its (fully updated) block to LDS in row-major form;
+//   (2) exact substitution with the 64 x 64 diagonal block L_jj (no explicit inverse, cond(K) ~ 1/lam): 8 threads
+//       per row, thread q holds the columns k = q (mod 8); column by column the solved entry is broadcast inside
+//       the 8-lane group and the remaining entries are updated (right-looking: independent FMAs); L_jj^T from LDS;
+//   (3) the solved block goes to global memory and stays in LDS as the A operand of
+//   (4) acc_c -= X_jj * L[c, jj]^T for the blocks c > jj of every wavefront: v_mfma_f64_16x16x4_f64, B operand
+//       straight from global memory (L is 2 MB at most and L2 resident).  Both operands are fetched as 32-byte
+//       runs (4 consecutive k per lane): MFMA step s of a 16-deep chunk contracts k = 4 (lane >> 4) + s, the same
+//       bijection on both sides.
+// LDS 50 KB, ~200 VGPRs: two workgroups per CU, the second one covers the substitution phases of the first.
+// ------------------------------------------------------------------------------------------
+#define PT_ROWS 32
+#define PT_SP 66   // pitch of the row-major block in LDS (doubles): 16-byte aligned rows, 16-lane b128 reads conflict-free
+#define PT_LP 65   // pitch of L_jj^T
+
+__global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __restrict__ L, double* __restrict__ X,
+                                                            int64_t ld, int nbw, int64_t m) {
+  __shared__ __attribute__((aligned(16))) double S[PT_ROWS * PT_SP];
+  __shared__ __attribute__((aligned(16))) double Lt[64 * PT_LP];
+  __shared__ double rinv[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * PT_ROWS;
+
+  // ---- strip into registers (C layout: row = lk + 4 r + 16 i, col = li + 16 j); two separately named register
+  // blocks (an array indexed by the owner test would be demoted to scratch memory)
+  d4 accA[2][4], accB[2][4];
+  const int blkA = wave, blkB = 7 - wave;
+  auto load_block = [&](d4 (&acc)[2][4], int blk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        if (blk < nbw) {
+          // clamped row index + select instead of predicated loads (no divergent branches; rows past m read row m-1)
+          const int64_t gr = row0 + 16 * i + lk;
+          const double* pc = X + blk * 64 + 16 * j + li;
+          const int64_t r0 = gr < m ? gr : m - 1, r1 = gr + 4 < m ? gr + 4 : m - 1;
+          const int64_t r2 = gr + 8 < m ? gr + 8 : m - 1, r3 = gr + 12 < m ? gr + 12 : m - 1;
+          const double w0 = pc[r0 * ld], w1 = pc[r1 * ld], w2 = pc[r2 * ld], w3 = pc[r3 * ld];
+          v0 = gr < m ? w0 : 0.0;
+          v1 = gr + 4 < m ? w1 : 0.0;
+          v2 = gr + 8 < m ? w2 : 0.0;
+          v3 = gr + 12 < m ? w3 : 0.0;
+        }
+        acc[i][j] = (d4){v0, v1, v2, v3};
+      }
+  };
+  load_block(accA, blkA);
+  load_block(accB, blkB);
+
+  auto to_lds = [&](const d4 (&acc)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(16 * i + lk + 4 * r) * PT_SP + 16 * j + li] = acc[i][j][r];
+  };
+  auto update = [&](d4 (&acc)[2][4], int c, int jj) {
+    const double* Lc = L + (int64_t)(c * 64 + li) * ld + jj * 64 + 4 * lk;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {  // 16-deep chunks of the 64 contraction indices
+      d4 a[2], bb[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const d4*>(&S[(16 * i + li) * PT_SP + 16 * ch + 4 * lk]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const d4*>(Lc + (int64_t)(16 * j) * ld + 16 * ch);
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)  // acc -= a b^T  ==  acc += (-a) b^T
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[i][sidx], bb[j][sidx], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int srow = tid >> 3, sq = tid & 7;  // substitution: 8 threads per row
+  for (int jj = 0; jj < nbw; ++jj) {
+    // (1) owner's block -> LDS row-major; L_jj^T and reciprocal diagonal -> LDS
+    if (jj < 4) {
+      if (wave == jj) to_lds(accA);
+    } else {
+      if (wave == 7 - jj) to_lds(accB);
+    }
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;  // L_jj[r][c], c <= r
+      const double v = (c <= r) ? L[(int64_t)(jj * 64 + r) * ld + jj * 64 + c] : 0.0;
+      Lt[c * PT_LP + r] = v;
+      if (r == c) rinv[r] = 1.0 / v;
+    }
+    __syncthreads();
+    // (2) substitution: x_c = t_c / L[c][c];  t_k -= x_c L[k][c] for k > c
+    {
+      double t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = S[srow * PT_SP + sq + 8 * i];
+#pragma unroll
+      for (int c = 0; c < 64; ++c) {
+        const int qc = c & 7, ic = c >> 3;
+        const double mine = t[ic] * rinv[c];
+        const double x = __shfl(mine, (lane & ~7) | qc, 64);
+        if (sq == qc) t[ic] = x;
+#pragma unroll
+        for (int i = ic; i < 8; ++i) {
+          const double l = Lt[c * PT_LP + sq + 8 * i];
+          if (i > ic || sq > qc) t[i] -= x * l;
+        }
+      }
+      const int64_t gr = row0 + srow;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        S[srow * PT_SP + sq + 8 * i] = t[i];
+        if (gr < m) X[gr * ld + jj * 64 + sq + 8 * i] = t[i];
+      }
+    }
+    __syncthreads();
+    // (4) right-looking update of the blocks c > jj this wavefront owns
+    if (blkA > jj && blkA < nbw) update(accA, blkA, jj);
+    if (blkB > jj && blkB < nbw) update(accB, blkB, jj);
+    __syncthreads();  // S and Lt are rewritten by the next step
+  }
+}
+
+static int launch_panel_trsm(gdml_ctx* ctx, hipStream_t st, const double* L, double* X, int64_t ld, int nb, int64_t m) {
+  if (m <= 0) return GDML_OK;
+  hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, L, X, ld, nb / 64, m);
+  ctx->launch_counter++;
+  HIP_CHECK(ctx, hipGetLastError());
+  return GDML_OK;
+}
+
 // A <- -A + lam I on the lower triangle (analytic.py:65,82), tiled copy-free.
 __global__ void __launch_bounds__(256) negate_shift_kernel(double* __restrict__ A, int64_t n,
                                                            int64_t ld, double lam) {
@@ -519,8 +830,23 @@ int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, in
 }
 
 // Factor one panel: columns [k0, k0+nb), rows [k0, n), 64-wide sub-steps (potrf64 / trsm64 / K=64 gemm).
+static int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0, int64_t nb);
+
+// Panel = diagonal block (the 64-wide step chain, but only over the nb rows of the block) + ONE row-local solve of
+// all rows below (option chol.panel_kernel = 1, default); the step chain over the whole strip otherwise.
 static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0,
                         int64_t nb) {
+  const int64_t below = n - k0 - nb;
+  const bool aligned = (reinterpret_cast<uintptr_t>(A) & 31) == 0 && (ld % 4 == 0) && (k0 % 4 == 0);
+  if (ctx_opt_i(ctx, "chol.panel_kernel", 1) && nb % 64 == 0 && nb <= 512 && below > 0 && aligned) {
+    GDML_TRY(panel_factor_steps(ctx, st, A, k0 + nb, ld, k0, nb));
+    return launch_panel_trsm(ctx, st, A + k0 * ld + k0, A + (k0 + nb) * ld + k0, ld, (int)nb, below);
+  }
+  return panel_factor_steps(ctx, st, A, n, ld, k0, nb);
+}
+
+static int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0,
+                              int64_t nb) {
   const int fused = ctx_opt_i(ctx, "chol.panel_fused", 1);  // 0: separate potrf64 / trsm64 launches
   double* save = nullptr;  // two 64 x 64 slots for the deferred write-back of the diagonal blocks
   if (fused) GDML_TRY(ctx_slot(ctx, 5, 2 * 4096 * 8, &save));
@@ -667,6 +993,48 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
       if (info_out) *info_out = info;
       return GDML_OK;
     }
+  }
+  // ---- default schedule: ONE stream.  Per panel k:  GEMM1 (columns of panel k+1)  ->  SYRK of the rest, whose
+  // workgroup 0 factors the diagonal block of panel k+1 meanwhile  ->  row-local solve of panel k+1's rows.
+  // The 64-wide step chain of the diagonal block is hidden inside the SYRK launch; only the row-local solve
+  // (one launch) stays between two GEMM launches.  Near the end (SYRK shorter than the single-workgroup block
+  // factorisation) the block is factored by the multi-workgroup step chain instead.
+  if (ctx_opt_i(ctx, "chol.fused_diag", 1) && lookahead) {
+    hipStream_t st = ctx->stream;
+    const int64_t min_rows = (int64_t)ctx_opt(ctx, "chol.fused_min_rows", 12288);
+    GDML_TRY(panel_factor(ctx, st, A, n_rows, ld, 0, n < NB ? n : NB));
+    for (int64_t k0 = 0; k0 < n; k0 += NB) {
+      const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
+      const int64_t t0 = k0 + nb;
+      if (t0 >= n) break;
+      const int64_t nb2 = (n - t0 < NB) ? n - t0 : NB;
+      const int64_t t1 = t0 + nb2;
+      const double* P = A + t0 * ld + k0;
+      GDML_TRY(launch_gemm_nt_sub(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, nb2, nb, 0));
+      const bool fuse = (nb2 % 64 == 0) && (n - t1 >= min_rows) && (n_rows - t1 > 0);
+      if (fuse) {
+        DiagJob dj;
+        dj.A = A + t0 * ld + t0;
+        dj.nbw = (int)(nb2 / 64);
+        dj.off = t0;
+        const double* P1 = A + t1 * ld + k0;
+        GDML_TRY(launch_gemm_nt_sub_part(ctx, st, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1, 0.0,
+                                         1.0, true, &dj));
+        GDML_TRY(launch_panel_trsm(ctx, st, A + t0 * ld + t0, A + t1 * ld + t0, ld, (int)nb2, n_rows - t1));
+      } else {
+        GDML_TRY(panel_factor(ctx, st, A, n_rows, ld, t0, nb2));
+        if (t1 < n) {
+          const double* P1 = A + t1 * ld + k0;
+          GDML_TRY(launch_gemm_nt_sub(ctx, st, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1));
+        }
+      }
+    }
+    HIP_CHECK(ctx, hipGetLastError());
+    int info = 0;
+    HIP_CHECK(ctx, hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (info_out) *info_out = info;
+    return GDML_OK;
   }
   hipStream_t sm = ctx->stream, sp = ctx->stream2;
   hipEvent_t evA = ctx->ev_la[0], evB = ctx->ev_la[1];

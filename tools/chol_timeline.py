@@ -1,19 +1,19 @@
 #!/usr/bin/env python
-"""From a rocprofv3 rocpd database of one factorisation: how long is no GEMM kernel running
-(= exposed panel chain), and where in the factorisation.  Usage: chol_timeline.py <db> [n_steps_to_skip]"""
+"""From a rocprofv3 rocpd database of a run that factors the benchmark matrix: for the LAST factorisation,
+how long is no GEMM kernel running (= exposed panel chain), where in the factorisation, per-kernel sums, and a
+per-panel breakdown of the non-GEMM kernels for a few panels.  Usage: chol_timeline.py <db>"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
-tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='view' or type='table'")]
 rows = cur.execute("select name, start, end from kernels order by start").fetchall()
-# isolate the last factorisation: from the last negate_shift kernel to the first trsv after it
-idx = [i for i, r in enumerate(rows) if r[0].startswith('negate_shift')]
+short = lambda n: n.split('(')[0].replace('void ', '')
+# the last factorisation: from the last assembly kernel to the first triangular-solve kernel after it
+idx = [i for i, r in enumerate(rows) if 'assemble_wave_kernel' in r[0] or r[0].startswith('negate_shift')]
 i0 = idx[-1]
-i1 = next(i for i in range(i0, len(rows)) if rows[i][0].startswith('trsv_fwd'))
-seg = rows[i0 + 1:i1]
+i1 = next((i for i in range(i0, len(rows)) if short(rows[i][0]).startswith('trsv')), len(rows))
+seg = [r for r in rows[i0 + 1:i1] if not r[0].startswith('__amd_rocclr')]
 t0, t1 = seg[0][1], max(r[2] for r in seg)
-gem = sorted((r[1], r[2]) for r in seg if r[0].startswith('gemm_nt_sub'))
-# union of GEMM intervals
+gem = sorted((r[1], r[2]) for r in seg if 'gemm_nt_sub' in r[0])
 busy, gaps, cur_s, cur_e = 0, [], gem[0][0], gem[0][1]
 for s, e in gem[1:]:
     if s > cur_e:
@@ -26,18 +26,29 @@ busy += cur_e - cur_s
 tot = t1 - t0
 print('factorisation %.1f ms; some GEMM running %.1f ms; no GEMM running %.1f ms (%d gaps + head %.2f ms + tail %.2f ms)' % (
     tot / 1e6, busy / 1e6, (tot - busy) / 1e6, len(gaps), (gem[0][0] - t0) / 1e6, (t1 - cur_e) / 1e6))
-# gaps by position in time (deciles of the factorisation)
 dec = [0.0] * 10
 for s, g in gaps:
     dec[min(9, int(10 * (s - t0) / tot))] += g / 1e6
 print('gap ms per time decile:', ' '.join('%.1f' % d for d in dec))
-big = sorted(gaps, key=lambda x: -x[1])[:5]
-print('largest gaps (ms at t ms):', ', '.join('%.2f@%.0f' % (g / 1e6, (s - t0) / 1e6) for s, g in big))
-# per-kernel busy sums on the panel side
 agg = {}
 for n, s, e in seg:
-    k = n.split('(')[0]
-    a = agg.setdefault(k, [0, 0])
+    a = agg.setdefault(short(n), [0, 0])
     a[0] += 1; a[1] += e - s
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print('  %-28s %6d launches %10.1f ms summed' % (k[:28], a[0], a[1] / 1e6))
+    print('  %-34s %6d launches %10.1f ms summed %9.1f us avg' % (k[:34], a[0], a[1] / 1e6, a[1] / a[0] / 1e3))
+# K = 64 in-block GEMMs vs the big ones (by duration rank is unreliable: split by launch order inside a panel)
+# per-panel breakdown: a panel starts at each panel_trsm_kernel (new path) -- list what ran between big GEMMs
+pt = [i for i, r in enumerate(seg) if 'panel_trsm' in r[0]]
+if pt:
+    print('per-panel non-GEMM chain (sampled panels): wall from first chain kernel to end of panel_trsm; pieces summed')
+    for p in pt[::max(1, len(pt) // 8)]:
+        # walk back over the chain kernels of the diagonal block
+        j = p
+        while j > 0 and (seg[j - 1][2] - seg[j - 1][1]) < 3e5 and seg[p][1] - seg[j - 1][1] < 3e6:
+            j -= 1
+        chain = seg[j:p + 1]
+        parts = {}
+        for n, s, e in chain:
+            parts[short(n)] = parts.get(short(n), 0) + (e - s)
+        print('  t=%7.1f ms: wall %6.1f us | %s' % ((seg[p][1] - t0) / 1e6, (seg[p][2] - chain[0][1]) / 1e3,
+                                                  ', '.join('%s %.0f' % (k[:18], v / 1e3) for k, v in parts.items())))
