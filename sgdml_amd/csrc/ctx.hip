@@ -29,7 +29,7 @@ static const char* kKnownOptions[] = {
     "asm.wave", "asm.threads", "asm.ib", "asm.minw", "asm.gj_global", "asm.j_chunk", "asm.debug", "asm.lower",
     "gemm.debug", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.split", "chol.aux_cus",
     "chol.mask_rows", "chol.mask_cus", "chol.panel_a", "chol.panel_b", "chol.gemm_tf", "chol.panel_kernel",
-    "chol.panel_stream", "chol.syrk_chunks", "chol.syrk_stream", "chol.fused_diag", "chol.fused_min_rows",
+    "chol.panel_stream", "chol.syrk_chunks", "chol.syrk_stream", "chol.fused_diag", "chol.fused_min_rows", 
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
     "lu.nb", "comm.force_collectives", "nys.force_qr"};
 
