@@ -393,6 +393,7 @@ struct EColArgs {
   const int32_t* out_cols;  // output column for each
   double* K;
   int64_t ld;
+  int64_t i0;               // first row point of this launch
 };
 
 __global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
   const int tid = threadIdx.x, T = blockDim.x, nwaves = T >> 6;
   const int64_t jj = A.jj_list[blockIdx.x];
   const int64_t col = A.out_cols[blockIdx.x];
-  const int64_t i = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.y + A.i0;  // grid.y is tiled by the host (65535 limit)
   for (int k = tid; k < D; k += T) {
     xq[k] = A.x[jj * D + k];
     xi[k] = A.x[i * D + k];
@@ -715,9 +716,12 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
       size_t lds = (size_t)(6 * ts.D + 32) * 8;
       hipFuncSetAttribute((const void*)ecol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds);
-      hipLaunchKernelGGL(ecol_kernel, dim3((unsigned)e_pts.size(), (unsigned)M), dim3(256), lds,
-                         ctx->stream, E);
-      ctx->launch_counter++;
+      for (int64_t i0 = 0; i0 < M; i0 += 65535) {  // grid.y limit
+        E.i0 = i0;
+        const int64_t ny = (M - i0 < 65535) ? M - i0 : 65535;
+        hipLaunchKernelGGL(ecol_kernel, dim3((unsigned)e_pts.size(), (unsigned)ny), dim3(256), lds, ctx->stream, E);
+        ctx->launch_counter++;
+      }
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "ecol launch: %s", hipGetErrorString(e));
     }

@@ -1231,9 +1231,11 @@ static int chol_fwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld
 // owned cyclically (from the bottom) by one workgroup per CU, all resident at once; availability is a
 // single counter `done` (= number of finished blocks from the bottom) in global memory, advanced with a
 // release after the solution block has been written, read with an acquire by the consumers (x crosses
-// XCDs, i.e. L2s).  A workgroup only ever waits for blocks owned by workgroups with a lower index, which
-// are dispatched first, so the schedule cannot deadlock; spins are bounded anyway and report through
-// `err` instead of hanging the GPU.
+// XCDs, i.e. L2s).  Blocks are dealt round-robin, so a workgroup also waits for blocks of workgroups with a HIGHER
+// index (workgroup 0 at round 2 needs the last workgroup's block of round 1): all min(nbk, CUs) workgroups must
+// be resident at once.  One workgroup per CU on an otherwise idle stream satisfies that; where it does not (GPU
+// shared with another process) the bounded spins give up, `err` is set and the host falls back to the
+// per-block launches below.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) trsv_bwd_persist_kernel(const double* __restrict__ L, int64_t ld,
                                                                int64_t n, int nbk, const double* __restrict__ z,
@@ -1301,8 +1303,9 @@ static int chol_bwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld
     int h_err = 0;
     HIP_CHECK(ctx, hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_err != 0) return gdml_fail(ctx, GDML_ERR_HIP, "backward substitution: a workgroup waited too long");
-    return GDML_OK;
+    if (h_err == 0) return GDML_OK;
+    // a workgroup gave up waiting (the persistent launch needs all its workgroups co-resident: not guaranteed when
+    // the GPU is shared): d_z was only read so far, redo the substitution with one launch per block
   }
   int64_t last = ((n - 1) / 64) * 64;
   for (int64_t c0 = last; c0 >= 0; c0 -= 64) {
