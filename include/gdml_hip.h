@@ -90,6 +90,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   predict.wave_only (0), predict.mfma (1), predict.mfma_wide (1), predict.fill   prediction kernel choice
  *   lu.nb (64)            panel width of the LU fallback
  *   comm.force_collectives (0)  issue collectives even for world == 1 without a communicator (tests)
+ *   dist.nb (512)         row-block size of the distributed Cholesky (multiple of 128)
  *   nys.force_qr (0)      take the alternative (QR-equivalent) branch of the second Nystroem factorisation (tests)
  * Unknown keys return GDML_ERR_INVALID. */
 int gdml_set_option(gdml_ctx* ctx, const char* key, double value);
@@ -243,6 +244,16 @@ int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const d
 int gdml_comm_unique_id(void* id128_out);
 int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world);
 int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out);
+
+/* Distributed analytic solve (new; Analytic.solve, analytic.py:65-99, for systems beyond one GPU -- BASELINE.json
+ * configs[3], [4]): the system matrix A = -K + lam I is assembled block-ROW-cyclic over the ranks of the communicator
+ * (512-row blocks, every rank only its own rows: n^2 * 8 / world bytes per GPU), factored by a right-looking blocked
+ * Cholesky (diagonal block broadcast, row-local panel solve, panel all-gather over RCCL, local fp64-MFMA trailing
+ * update) with the right-hand side carried as a replicated extra row, and solved back; every rank receives
+ * alphas = -(A^-1 y).  Needs gdml_train_upload (P = 1, N <= 21) and a communicator (gdml_comm_init /
+ * gdml_comm_init_host; without one it runs on a single GPU).  *info as gdml_chol_factor. */
+int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const double* y, int64_t n, double* alphas_out,
+                         int* info);
 
 /* Host-staged collectives: the same sharded algorithms with the two collectives delegated to the caller
  * (e.g. torch.distributed's gloo backend).  The library copies the device buffer to pinned host memory,

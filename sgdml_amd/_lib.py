@@ -49,6 +49,7 @@ SIGNATURES = {
     'gdml_precon_apply': (C.c_int, [_vp, C.c_double, _vp, C.c_int64, _vp]),
     'gdml_pcg': (C.c_int, [_vp, C.c_double, C.c_int, _vp, _vp, C.c_int64, C.c_double, C.c_int64, C.c_int,
                            PCG_CB, C.c_int64, _vp, _vp, _ip, _dp, C.POINTER(C.c_int)]),
+    'gdml_dist_chol_solve': (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int64, _vp, C.POINTER(C.c_int)]),
     'gdml_comm_unique_id': (C.c_int, [_vp]),
     'gdml_comm_init': (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     'gdml_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -356,6 +357,16 @@ class Context(object):
         out = np.empty_like(y)
         info = C.c_int(0)
         self._check(self._lib.gdml_lu_solve(self._h, float(lam), _ptr(y), y.size, _ptr(out), C.byref(info)))
+        return out
+
+    def dist_chol_solve(self, sig, lam, y):
+        """Distributed analytic solve over the ranks of this context's communicator (gdml_dist_chol_solve):
+        alphas = -(A^-1 y), A = -K + lam I, on every rank."""
+        y = f64(y).ravel()
+        out = np.empty_like(y)
+        info = C.c_int(0)
+        self._check(self._lib.gdml_dist_chol_solve(self._h, float(sig), float(lam), _ptr(y), y.size, _ptr(out),
+                                                   C.byref(info)))
         return out
 
     def chol_set_rhs(self, y):

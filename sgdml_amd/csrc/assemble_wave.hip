@@ -62,9 +62,12 @@ struct WaveArgs {
   int64_t ld;
   int lower;      // 1: only blocks j <= i (dense column range), values stored as -K, + lam on the diagonal:
   double lam;     //    the matrix A = -K + lam I in the form the Cholesky factorisation reads (analytic.py:65,82)
+  // distributed Cholesky (CYC instantiation): K is this rank's share of a block-row-cyclic layout -- global row
+  // block b (cyc_nb rows) lives on rank b % cyc_W as local row block b / cyc_W; rows of other ranks are not stored
+  int cyc_W, cyc_rank, cyc_nb;
 };
 
-template <int N>
+template <int N, bool CYC = false>
 __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
   constexpr int N3 = 3 * N;
   __shared__ double vsh[64];
@@ -78,6 +81,18 @@ __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
   if (A.lower && jb_end > i - A.j0 + 1) jb_end = i - A.j0 + 1;  // blocks on/below the block diagonal only
   if (jb_beg >= jb_end) return;
   const double sgn = A.lower ? -1.0 : 1.0;
+  // CYC: the 3N rows of point i fall into at most two row blocks; local row of block-relative row r is
+  // base0 + r (r < rb) or base1 + (r - rb); base < 0 = not this rank's block
+  int64_t base0 = 0, base1 = 0;
+  int rb = N3;
+  if (CYC) {
+    const int64_t g0 = i * N3, b0 = g0 / A.cyc_nb;
+    const int64_t rest = (b0 + 1) * A.cyc_nb - g0;
+    rb = rest < N3 ? (int)rest : N3;
+    base0 = (b0 % A.cyc_W == A.cyc_rank) ? (b0 / A.cyc_W) * A.cyc_nb + g0 % A.cyc_nb : -1;
+    base1 = ((b0 + 1) % A.cyc_W == A.cyc_rank) ? ((b0 + 1) / A.cyc_W) * A.cyc_nb : -1;
+    if (base0 < 0 && (base1 < 0 || rb == N3)) return;
+  }
 
   const double sig = A.sig, inv_sig = 1.0 / sig;
   const double sqrt5 = 2.23606797749978969641;
@@ -164,10 +179,20 @@ __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
             o2 += (beta == 2) ? A.lam : 0.0;
           }
         }
-        dst[0] = o0;
-        dst[A.ld] = o1;
-        dst[2 * A.ld] = o2;
-        dst += 3 * A.ld;
+        if (CYC) {
+          const double o[3] = {o0, o1, o2};
+#pragma unroll
+          for (int al = 0; al < 3; ++al) {
+            const int r = 3 * a + al;
+            const int64_t lr = r < rb ? (base0 < 0 ? -1 : base0 + r) : (base1 < 0 ? -1 : base1 + (r - rb));
+            if (lr >= 0) A.K[lr * A.ld + outcol] = o[al];
+          }
+        } else {
+          dst[0] = o0;
+          dst[A.ld] = o1;
+          dst[2 * A.ld] = o2;
+          dst += 3 * A.ld;
+        }
       }
       if (A.use_E) A.K[(A.M * N3 + i) * A.ld + outcol] = -e_fact * (nrm + sig) * ex * u;  // train.py:235-248 (never with lower)
     }
@@ -200,7 +225,7 @@ bool assemble_wave_applicable(const gdml_ctx* ctx) {
 
 int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist,
                          const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld,
-                         int64_t i_beg, int64_t i_end, int lower, double lam) {
+                         int64_t i_beg, int64_t i_end, int lower, double lam, int cyc_W, int cyc_rank, int cyc_nb) {
   TrainSet& ts = ctx->ts;
   GDML_TRY(build_dense_tables(ctx));
   WaveArgs A;
@@ -209,6 +234,8 @@ int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   A.i_beg = i_beg;
   A.lower = lower;
   A.lam = lam;
+  A.cyc_W = cyc_W; A.cyc_rank = cyc_rank; A.cyc_nb = cyc_nb;
+  if (cyc_W > 0 && !lower) return gdml_fail(ctx, GDML_ERR_INVALID, "assemble_wave: the row-cyclic layout is only built in the lower form");
   if (lower && (d_jlist || d_colmap || use_E || j0 != 0 || i_beg != 0))
     return gdml_fail(ctx, GDML_ERR_INVALID, "assemble_wave: lower form needs the dense full column range");
   const int64_t n_i = i_end - i_beg;
@@ -219,7 +246,11 @@ int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   dim3 grid((unsigned)n_i, (unsigned)((n_j + j_chunk - 1) / j_chunk));
   const int slot = ktime_begin(ctx);
   switch (ts.N) {
-#define WC(v) case v: hipLaunchKernelGGL(assemble_wave_kernel<v>, grid, dim3(64), 0, ctx->stream, A); break;
+#define WC(v)                                                                                          \
+  case v:                                                                                              \
+    if (cyc_W > 0) hipLaunchKernelGGL((assemble_wave_kernel<v, true>), grid, dim3(64), 0, ctx->stream, A); \
+    else hipLaunchKernelGGL((assemble_wave_kernel<v, false>), grid, dim3(64), 0, ctx->stream, A);          \
+    break;
     WC(2) WC(3) WC(4) WC(5) WC(6) WC(7) WC(8) WC(9) WC(10) WC(11) WC(12) WC(13) WC(14) WC(15) WC(16)
     WC(17) WC(18) WC(19) WC(20) WC(21)
 #undef WC

@@ -49,6 +49,11 @@ struct GemmArgs {
   int64_t s_begin;  // first super tile of this launch (a launch may cover a sub-range)
   int super_n;      // super-tile columns
   int aligned;      // A, B 16-byte aligned with even leading dimensions (vector loads legal)
+  // block-row-cyclic lower structure (distributed Cholesky): C rows are LOCAL rows, local row block lb (cyc_nb rows)
+  // is global block (cyc_lb0 + lb) * cyc_W + cyc_rank; a tile is computed iff its first column (cyc_col0 + col0,
+  // global) is not right of its last global row; local rows >= cyc_block_rows (carried right-hand side) take all
+  int cyc_W, cyc_rank;
+  int64_t cyc_lb0, cyc_nb, cyc_col0, cyc_block_rows;
   // fused launch (gemm_nt_sub_diag_kernel): workgroup 0 factors the next panel's diagonal block meanwhile
   double* diagA;    // top-left element of that nb x nb block (leading dimension ldc), or null
   int diag_nbw;     // nb / 64
@@ -241,6 +246,11 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
   if (ti >= g.tiles_m || tj >= g.tiles_n) return;
   if (g.lower && tj > ti) return;
   const int64_t row0 = ti * GT, col0 = tj * GT;
+  if (g.cyc_W > 0 && row0 + GT <= g.cyc_block_rows) {  // tiles that reach into the carried rhs row take all columns
+    const int64_t gb = (g.cyc_lb0 + row0 / g.cyc_nb) * g.cyc_W + g.cyc_rank;  // (tiles never straddle blocks: nb % GT == 0)
+    const int64_t grow_last = gb * g.cyc_nb + (row0 + GT - 1) % g.cyc_nb;
+    if (g.cyc_col0 + col0 > grow_last) return;
+  }
   const bool full = (row0 + GT <= g.M) && (col0 + GT <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
   if (full)
     gemm_tile_body<true, ABL>(g, lds, row0, col0);
@@ -265,12 +275,14 @@ struct DiagJob {
 static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
                                    const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
                                    int64_t N, int64_t K, int lower, double f0, double f1, bool timed,
-                                   const DiagJob* diag = nullptr) {
+                                   const DiagJob* diag = nullptr, const CyclicLower* cyc = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return GDML_OK;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.lower = lower;
   g.diagA = nullptr; g.diag_nbw = 0; g.diag_off = 0; g.diag_info = nullptr;
+  g.cyc_W = 0; g.cyc_rank = 0; g.cyc_lb0 = 0; g.cyc_nb = 0; g.cyc_col0 = 0; g.cyc_block_rows = 0;
+  if (cyc) { g.cyc_W = cyc->W; g.cyc_rank = cyc->rank; g.cyc_lb0 = cyc->lb0; g.cyc_nb = cyc->nb; g.cyc_col0 = cyc->col0; g.cyc_block_rows = cyc->block_rows; }
   g.dbg = ctx_opt_i(ctx, "gemm.debug", 0);
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
               (lda % 2 == 0) && (ldb % 2 == 0);
@@ -303,6 +315,11 @@ int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t l
                               const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
                               int64_t N, int64_t K, int lower) {
   return launch_gemm_nt_sub_part(ctx, st, A, lda, B, ldb, C, ldc, M, N, K, lower, 0.0, 1.0, true);
+}
+
+int launch_gemm_nt_sub_cyclic(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
+                              double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const CyclicLower& cyc) {
+  return launch_gemm_nt_sub_part(ctx, st, A, lda, B, ldb, C, ldc, M, N, K, 0, 0.0, 1.0, true, nullptr, &cyc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -616,13 +633,13 @@ __global__ void __launch_bounds__(256) writeback_block_kernel(const double* __re
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ Ld,
                                                      double* __restrict__ X, int64_t ld, int w,
-                                                     int64_t m) {
+                                                     int64_t m, int64_t ldl) {
   __shared__ __attribute__((aligned(16))) double Ls[64 * 64];
   const int tid = threadIdx.x;
   for (int e = tid; e < 64 * 64; e += 256) {
     int r = e >> 6, c = e & 63;
     double v = (r == c) ? 1.0 : 0.0;  // identity padding for w < 64
-    if (r < w && c < w && c <= r) v = Ld[r * ld + c];
+    if (r < w && c < w && c <= r) v = Ld[r * ldl + c];
     Ls[e] = v;
   }
   __syncthreads();
@@ -689,8 +706,8 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
 #define PT_SP 66   // pitch of the row-major block in LDS (doubles): 16-byte aligned rows, 16-lane b128 reads conflict-free
 #define PT_LP 65   // pitch of L_jj^T
 
-__global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __restrict__ L, double* __restrict__ X,
-                                                            int64_t ld, int nbw, int64_t m) {
+__global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __restrict__ L, int64_t ldl,
+                                                            double* __restrict__ X, int64_t ld, int nbw, int64_t m) {
   __shared__ __attribute__((aligned(16))) double S[PT_ROWS * PT_SP];
   __shared__ __attribute__((aligned(16))) double Lt[64 * PT_LP];
   __shared__ double rinv[64];
@@ -735,14 +752,14 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
         for (int r = 0; r < 4; ++r) S[(16 * i + lk + 4 * r) * PT_SP + 16 * j + li] = acc[i][j][r];
   };
   auto update = [&](d4 (&acc)[2][4], int c, int jj) {
-    const double* Lc = L + (int64_t)(c * 64 + li) * ld + jj * 64 + 4 * lk;
+    const double* Lc = L + (int64_t)(c * 64 + li) * ldl + jj * 64 + 4 * lk;
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {  // 16-deep chunks of the 64 contraction indices
       d4 a[2], bb[4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const d4*>(&S[(16 * i + li) * PT_SP + 16 * ch + 4 * lk]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const d4*>(Lc + (int64_t)(16 * j) * ld + 16 * ch);
+      for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const d4*>(Lc + (int64_t)(16 * j) * ldl + 16 * ch);
 #pragma unroll
       for (int sidx = 0; sidx < 4; ++sidx)
 #pragma unroll
@@ -763,7 +780,7 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
     }
     for (int e = tid; e < 64 * 64; e += 256) {
       const int r = e >> 6, c = e & 63;  // L_jj[r][c], c <= r
-      const double v = (c <= r) ? L[(int64_t)(jj * 64 + r) * ld + jj * 64 + c] : 0.0;
+      const double v = (c <= r) ? L[(int64_t)(jj * 64 + r) * ldl + jj * 64 + c] : 0.0;
       Lt[c * PT_LP + r] = v;
       if (r == c) rinv[r] = 1.0 / v;
     }
@@ -800,9 +817,12 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
   }
 }
 
-static int launch_panel_trsm(gdml_ctx* ctx, hipStream_t st, const double* L, double* X, int64_t ld, int nb, int64_t m) {
+// L: nb x nb lower block (leading dimension ldl; 0 = the same matrix as X), X: m rows of leading dimension ld
+int launch_panel_trsm(gdml_ctx* ctx, hipStream_t st, const double* L, double* X, int64_t ld, int nb, int64_t m,
+                      int64_t ldl) {
   if (m <= 0) return GDML_OK;
-  hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, L, X, ld, nb / 64, m);
+  hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, L, ldl > 0 ? ldl : ld, X, ld,
+                     nb / 64, m);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;
@@ -821,16 +841,16 @@ __global__ void __launch_bounds__(256) negate_shift_kernel(double* __restrict__ 
 }
 
 int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, int64_t ld, int w,
-                  int64_t m) {
+                  int64_t m, int64_t ldl) {
   if (m <= 0) return GDML_OK;
-  hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ld, X, ld, w, m);
+  hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ld, X, ld, w, m, ldl > 0 ? ldl : ld);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;
 }
 
 // Factor one panel: columns [k0, k0+nb), rows [k0, n), 64-wide sub-steps (potrf64 / trsm64 / K=64 gemm).
-static int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0, int64_t nb);
+int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0, int64_t nb);
 
 // Panel = diagonal block (the 64-wide step chain, but only over the nb rows of the block) + ONE row-local solve of
 // all rows below (option chol.panel_kernel = 1, default); the step chain over the whole strip otherwise.
@@ -845,8 +865,8 @@ static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int
   return panel_factor_steps(ctx, st, A, n, ld, k0, nb);
 }
 
-static int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0,
-                              int64_t nb) {
+int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0,
+                       int64_t nb) {
   const int fused = ctx_opt_i(ctx, "chol.panel_fused", 1);  // 0: separate potrf64 / trsm64 launches
   double* save = nullptr;  // two 64 x 64 slots for the deferred write-back of the diagonal blocks
   if (fused) GDML_TRY(ctx_slot(ctx, 5, 2 * 4096 * 8, &save));
@@ -879,7 +899,7 @@ static int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t 
       if (m > 0) {
         double* X = A + (c0 + w) * ld + c0;
         hipLaunchKernelGGL(trsm64_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, Ad, X, ld,
-                           w, m);
+                           w, m, ld);
         ctx->launch_counter++;
       }
     }
@@ -1289,7 +1309,7 @@ __global__ void __launch_bounds__(256) trsv_bwd_persist_kernel(const double* __r
 }
 
 // d_z is destroyed
-static int chol_bwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_z, double* d_x) {
+int chol_bwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_z, double* d_x) {
   const int persist = ctx_opt_i(ctx, "trsv.persist", 1);
   if (persist && n >= 2048) {
     const int nbk = (int)((n + 63) / 64);

@@ -193,8 +193,19 @@ int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, dou
 int operator_model_from_trainset(gdml_ctx* ctx, double sig);
 int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B,
                        int64_t ldb, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int lower);
+// lower structure of a block-row-cyclic local matrix (see GemmArgs in chol.hip)
+struct CyclicLower {
+  int W = 0, rank = 0;
+  int64_t lb0 = 0, nb = 0, col0 = 0, block_rows = 0;
+};
+int launch_gemm_nt_sub_cyclic(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
+                              double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const CyclicLower& cyc);
 int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, int64_t ld, int w,
-                  int64_t m);
+                  int64_t m, int64_t ldl = 0);
+int launch_panel_trsm(gdml_ctx* ctx, hipStream_t st, const double* L, double* X, int64_t ld, int nb, int64_t m,
+                      int64_t ldl = 0);
+int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0, int64_t nb);
+int chol_bwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_z, double* d_x);
 int ctx_slot(gdml_ctx* ctx, int slot, int64_t bytes, double** out);
 void shard_points(const gdml_ctx* ctx, int64_t M, int64_t* p0, int64_t* p1, int64_t* pts_per);
 int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk);
@@ -204,4 +215,5 @@ static inline bool comm_active(const gdml_ctx* ctx) { return (ctx->comm || ctx->
 bool assemble_wave_applicable(const gdml_ctx* ctx);
 int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist,
                          const int32_t* d_colmap, int64_t j0, int64_t n_j, double* K, int64_t ld,
-                         int64_t i_beg, int64_t i_end, int lower = 0, double lam = 0.0);
+                         int64_t i_beg, int64_t i_end, int lower = 0, double lam = 0.0, int cyc_W = 0,
+                         int cyc_rank = 0, int cyc_nb = 0);

@@ -31,7 +31,7 @@ static const char* kKnownOptions[] = {
     "chol.mask_rows", "chol.mask_cus", "chol.panel_a", "chol.panel_b", "chol.gemm_tf", "chol.panel_kernel",
     "chol.panel_stream", "chol.syrk_chunks", "chol.syrk_stream", "chol.fused_diag", "chol.fused_min_rows", 
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
-    "lu.nb", "comm.force_collectives", "nys.force_qr"};
+    "lu.nb", "comm.force_collectives", "nys.force_qr", "dist.nb"};
 
 double ctx_opt(const gdml_ctx* ctx, const char* key, double dflt) {
   auto it = ctx->opts.find(key);

@@ -30,6 +30,20 @@ class Analytic(object):
         ctx = self.gdml_train._context()
         ctx.train_upload(R_desc, R_d_desc, _lib.tril_perms_from_lin(tril_perms_lin, dim_d))
 
+        if ctx.comm_info()[1] > 1:
+            # GDMLTrain.init_distributed: the system matrix is partitioned block-row-cyclic over the ranks and
+            # factored by the distributed Cholesky (csrc/dist_chol.hip); every rank gets the coefficients
+            if self.callback is not None:
+                cb = partial(self.callback, disp_str='Solving linear system (distributed Cholesky factorization)')
+                cb(NOT_DONE)
+            start = timeit.default_timer()
+            alphas = ctx.dist_chol_solve(sig, lam, y)
+            if self.callback is not None:
+                dur_s = timeit.default_timer() - start
+                self.callback(DONE, disp_str='Training on {:,} points'.format(n_train),
+                              sec_disp_str='took {:.1f} s'.format(dur_s) if dur_s >= 0.1 else '')
+            return alphas
+
         cb = self.callback
         if cb is not None:
             cb = partial(cb, disp_str='Assembling kernel matrix')

@@ -309,6 +309,11 @@ class GDMLTrain(object):
         # here the matrix lives in HBM and is factored in place, so the test is n^2 8 bytes vs HBM.
         budget = self._device_budget_bytes()
         est_analytic = Analytic.est_device_memory(n_train, n_atoms, task['use_E_cstr'])
+        world = self._context().comm_info()[1]
+        if world > 1 and not task['use_E_cstr'] and n_perms == 1 and n_atoms <= 21:
+            # distributed Cholesky: every rank holds 1/world of the matrix plus panel buffers
+            n_sys = n_train * 3 * n_atoms
+            est_analytic = est_analytic / world + (2 * n_sys + 600000) * 512 * 8
         use_analytic_solver = est_analytic < 0.95 * budget
         if self._force_solver is not None:
             use_analytic_solver = self._force_solver == 'analytic'
