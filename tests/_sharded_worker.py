@@ -1,6 +1,6 @@
 """Worker of tests/test_hip_scale.py::test_sharded_iterative_two_processes_one_gpu (launched with
 torch.distributed.run, world_size ranks sharing GPU 0): trains the pcg_n9_m400 fixture through
-GDMLTrain with the iterative solver SHARDED over the ranks -- csrc/cg.hip, predict.hip and comm.hip
+GDMLTrain with the iterative solver SHARDED over the ranks (or, solver 'analytic', the distributed Cholesky) -- csrc/cg.hip, predict.hip and comm.hip
 with host-staged (gloo) collectives -- and writes rank 0's result next to the output path."""
 import os
 import sys
@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out_path, backend = sys.argv[1], sys.argv[2]
+    solver = sys.argv[3] if len(sys.argv) > 3 else 'cg'
     import torch.distributed as dist
 
     dist.init_process_group('gloo')
@@ -34,16 +35,18 @@ def main():
     k = len(g['inducing_pts_idxs']) // (3 * N)
     np.random.seed(100 + rank)  # deliberately different per rank: every draw has to come from rank 0
     tr = GDMLTrain()
-    tr._force_solver = 'cg'
+    tr._force_solver = solver
     tr._force_n_inducing_pts = k
     r, w = tr.init_distributed(backend=backend)
     assert (r, w) == (rank, world)
     model = tr.train(task)
     calls, nbytes = tr._context().comm_stats()
-    if rank == 0:
+    if rank == 0 and solver == 'cg':
         np.savez(out_path, alphas=model['alphas_F'], iters=model['solver_iters'], resid=model['solver_resid'],
                  c=model['c'], inducing=model['inducing_pts_idxs'], coll_calls=calls, coll_bytes=nbytes,
                  norm_y=model['norm_y_train'])
+    elif rank == 0:
+        np.savez(out_path, alphas=model['alphas_F'], c=model['c'], coll_calls=calls, solver=model['solver_name'])
     # a second, restart-free property: all ranks hold the same coefficients
     chk = [None] * world
     dist.all_gather_object(chk, float(np.abs(model['alphas_F']).sum()))

@@ -386,3 +386,29 @@ def test_distributed_cholesky_processes_share_one_gpu(tmp_path, ctx, world, N, M
     n = 3 * N * M
     nblk = -(-n // nb)
     assert int(r['coll_calls']) >= 2 * nblk  # per panel: block broadcast + panel gather (+ backward substitution)
+
+
+def test_dropin_train_distributed_analytic(tmp_path):
+    """GDMLTrain.train in distributed mode with the analytic solver: Analytic.solve goes through the distributed
+    Cholesky (2 processes, one GPU, host-staged collectives) and the model equals the single-process one."""
+    from sgdml_amd.train import GDMLTrain
+
+    g = load('pcg_n9_m400')
+    out = str(tmp_path / 'dtrain.npz')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+    port = 29950 + (os.getpid() % 40)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', '_sharded_worker.py'), out, 'host', 'analytic']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r = dict(np.load(out))
+    assert str(r['solver']) == 'analytic' and int(r['coll_calls']) > 0
+    tr = GDMLTrain()
+    try:
+        tr._force_solver = 'analytic'
+        model = tr.train(make_task(g))
+    finally:
+        tr.__del__()
+    assert np.abs(r['alphas'] - model['alphas_F']).max() <= 1e-5 * np.abs(model['alphas_F']).max()
+    assert abs(float(r['c']) - model['c']) <= 1e-6 * max(1.0, abs(model['c']))
