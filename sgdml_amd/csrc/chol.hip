@@ -62,7 +62,6 @@ struct GemmArgs {
   int dbg;          // option gemm.debug: ablation bits: 1 no epilogue, 2 no tile loads, 4 no LDS reads, 8 no barrier
 };
 
-template <int VAR>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g);
 
 template <bool FULL>
@@ -225,120 +224,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Interior tiles, variant 2: operand tiles go global -> LDS directly (global_load_lds_dwordx4, no staging
-// registers, no ds_write pass), two LDS buffers, the DMA of tile kt+1 is issued before the MFMAs of tile kt and
-// retired by the vmcnt(0) of the closing __syncthreads().
-// LDS image of an operand tile: 128 rows x 16 doubles, unpadded (the DMA writes lane-linearly: one wave-load = 8
-// rows of 128 bytes); the 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7).  The permutation is
-// applied on the SOURCE address of the DMA and on the read address (same involution both sides).  Operand reads
-// are two ds_read_b128 per 16 x 16 tile row and k-tile: lane (i = l & 15, q = l >> 4) fetches k = 4q .. 4q+3 of
-// its row, MFMA step s contracts k = 4q + s on both operands.  With this layout the 16 lanes of a q group hit 16
-// different 16-byte bank groups (rows of equal (r >> 1) & 7 differ in r & 1): no bank conflicts, where the
-// ds_read2_b64 pairs of the padded layout conflict 2-way.
-// ------------------------------------------------------------------------------------------
-#define GLDS_TILE (GT * GBK)  // doubles per operand tile
-
-__device__ __forceinline__ void glds16(const double* g, double* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-__device__ __forceinline__ void gemm_tile_body_glds(const GemmArgs& g, double* lds, int64_t row0, int64_t col0) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 15, lk = lane >> 4;
-  // lds: [buf][operand][GLDS_TILE]
-  d4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  // loader: wave w fills rows [32 w, 32 w + 32) of both operand tiles, 8 rows per DMA instruction
-  const int lrow = lane >> 3, slot = lane & 7;
-  const double* ga[4];
-  const double* gb[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = wave * 32 + q * 8 + lrow;
-    const int chunk = slot ^ ((row >> 1) & 7);
-    ga[q] = g.A + (row0 + row) * g.lda + 2 * chunk;
-    gb[q] = g.B + (col0 + row) * g.ldb + 2 * chunk;
-  }
-  auto issue = [&](int64_t kt, int buf) {
-    double* la = lds + (buf * 2 + 0) * GLDS_TILE + wave * 32 * GBK;
-    double* lb = lds + (buf * 2 + 1) * GLDS_TILE + wave * 32 * GBK;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      glds16(ga[q] + kt * GBK, la + q * 8 * GBK);
-      glds16(gb[q] + kt * GBK, lb + q * 8 * GBK);
-    }
-  };
-  // reader: chunk positions of k = 4 lk .. 4 lk + 3 for this lane's rows ((r >> 1) & 7 = li >> 1 for every tile row)
-  const int sw = li >> 1;
-  const int off_lo = ((2 * lk) ^ sw) * 2, off_hi = ((2 * lk + 1) ^ sw) * 2;
-  const int arow = (wm * 64 + li) * GBK, brow = (wn * 64 + li) * GBK;
-
-  const int64_t nk = g.K / GBK;
-  issue(0, 0);
-  __syncthreads();
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    const double* As = lds + (cur * 2 + 0) * GLDS_TILE + arow;
-    const double* Bs = lds + (cur * 2 + 1) * GLDS_TILE + brow;
-    d2 alo[4], ahi[4], blo[4], bhi[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      alo[i] = *reinterpret_cast<const d2*>(As + i * 16 * GBK + off_lo);
-      ahi[i] = *reinterpret_cast<const d2*>(As + i * 16 * GBK + off_hi);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      blo[j] = *reinterpret_cast<const d2*>(Bs + j * 16 * GBK + off_lo);
-      bhi[j] = *reinterpret_cast<const d2*>(Bs + j * 16 * GBK + off_hi);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(alo[i].x, blo[j].x, acc[i][j], 0, 0, 0);
-    // the DMA of the next tile is issued behind the first 16 MFMAs (1024 cycles of pipe time queued): the operand
-    // reads and the first MFMAs start right after the barrier
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(alo[i].y, blo[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ahi[i].x, bhi[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ahi[i].y, bhi[j].y, acc[i][j], 0, 0, 0);
-    __syncthreads();  // retires this wave's DMA (vmcnt(0)) and everybody's reads of `cur`
-  }
-  // epilogue: C -= acc (C/D layout: col = lane & 15, row = (lane >> 4) + 4 r)
-  double* Cw = g.C + (row0 + wm * 64 + lk) * g.ldc + col0 + wn * 64 + li;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    double cv[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cv[i][r] = Cw[(i * 16 + 4 * r) * g.ldc + j * 16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[i][r] - acc[i][j][r];
-  }
-}
-
 // block index -> tile (XCD-aware 8x8 super tiles: block b runs on XCD b % 8) and the tile's GEMM
-template <bool ABL, int VAR = 0>
+template <bool ABL>
 __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][GT * GPITCH], int64_t b) {
   const int64_t xcd = b & 7, loc = b >> 3;
   const int64_t s = g.s_begin + (loc >> 6) * 8 + xcd;
@@ -365,14 +252,10 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
     if (g.cyc_col0 + col0 > grow_last) return;
   }
   const bool full = (row0 + GT <= g.M) && (col0 + GT <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
-  if (full) {
-    if (VAR == 1)
-      gemm_tile_body_glds(g, &lds[0][0][0], row0, col0);
-    else
-      gemm_tile_body<true, ABL>(g, lds, row0, col0);
-  } else {
+  if (full)
+    gemm_tile_body<true, ABL>(g, lds, row0, col0);
+  else
     gemm_tile_body<false, ABL>(g, lds, row0, col0);
-  }
 }
 
 template <bool ABL>
@@ -381,10 +264,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   gemm_block<ABL>(g, lds, blockIdx.x);
 }
 
-__global__ void __launch_bounds__(256, 2) gemm_nt_sub_v2_kernel(GemmArgs g) {  // interior tiles through LDS-DMA
-  __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
-  gemm_block<false, 1>(g, lds, blockIdx.x);
-}
 
 // f0, f1: the launch covers the super tiles [f0 * n_super, f1 * n_super) (whole update: 0, 1);
 // timed: bracket with the per-kernel timers (only launches on the timing stream)
@@ -419,16 +298,10 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   int64_t groups = (g.n_super - g.s_begin + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
   int64_t blocks = groups * 512;
   const int slot = (timed && st == (ctx->kt_stream ? ctx->kt_stream : ctx->stream)) ? ktime_begin(ctx) : -1;
-  const int glds = ctx_opt_i(ctx, "gemm.glds", 0);
   if (diag && diag->A) {
     g.diagA = diag->A; g.diag_nbw = diag->nbw; g.diag_off = diag->off; g.diag_info = ctx->d_info;
-    if (glds)
-      hipLaunchKernelGGL(gemm_nt_sub_diag_kernel<1>, dim3((unsigned)blocks + 1), dim3(256), 0, st, g);
-    else
-      hipLaunchKernelGGL(gemm_nt_sub_diag_kernel<0>, dim3((unsigned)blocks + 1), dim3(256), 0, st, g);
-  } else if (glds && !g.dbg)
-    hipLaunchKernelGGL(gemm_nt_sub_v2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
-  else if (g.dbg)
+    hipLaunchKernelGGL(gemm_nt_sub_diag_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, st, g);
+  } else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL(gemm_nt_sub_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
@@ -640,7 +513,6 @@ __device__ __forceinline__ void diag_block_role(double* __restrict__ D, int64_t 
 }
 
 // Trailing update + (workgroup 0) the next panel's diagonal block.
-template <int VAR>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
   static_assert(sizeof(double) * 2 * 2 * GT * GPITCH >= sizeof(double) * (2 * 64 * 65 + 64 + 128), "LDS of the diagonal role");
@@ -648,7 +520,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
     diag_block_role(g.diagA, g.ldc, g.diag_nbw, g.diag_off, g.diag_info, &lds[0][0][0]);
     return;
   }
-  gemm_block<false, VAR>(g, lds, (int64_t)blockIdx.x - 1);
+  gemm_block<false>(g, lds, (int64_t)blockIdx.x - 1);
 }
 
 __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,

@@ -27,7 +27,7 @@ extern "C" int gdml_abi_version(void) { return 2; }
 // a context is created (lab convenience for the probes under tools/).
 static const char* kKnownOptions[] = {
     "asm.wave", "asm.threads", "asm.ib", "asm.minw", "asm.gj_global", "asm.j_chunk", "asm.debug", "asm.lower",
-    "gemm.debug", "gemm.glds", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.split", "chol.aux_cus",
+    "gemm.debug", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.split", "chol.aux_cus",
     "chol.mask_rows", "chol.mask_cus", "chol.panel_a", "chol.panel_b", "chol.gemm_tf", "chol.panel_kernel",
     "chol.panel_stream", "chol.syrk_chunks", "chol.syrk_stream", "chol.fused_diag", "chol.fused_min_rows", 
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
