@@ -250,7 +250,7 @@ int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out);
  * (512-row blocks, every rank only its own rows: n^2 * 8 / world bytes per GPU), factored by a right-looking blocked
  * Cholesky (diagonal block broadcast, row-local panel solve, panel all-gather over RCCL, local fp64-MFMA trailing
  * update) with the right-hand side carried as a replicated extra row, and solved back; every rank receives
- * alphas = -(A^-1 y).  Needs gdml_train_upload (P = 1, N <= 21) and a communicator (gdml_comm_init /
+ * alphas = -(A^-1 y).  Needs gdml_train_upload (any P; no energy constraints) and a communicator (gdml_comm_init /
  * gdml_comm_init_host; without one it runs on a single GPU).  *info as gdml_chol_factor. */
 int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const double* y, int64_t n, double* alphas_out,
                          int* info);

@@ -43,6 +43,11 @@ struct AsmArgs {
   int dbg;  // GDML_ASM_DEBUG ablation bits: 1 skip stores, 2 skip phase A2, 4 skip phase B
   double* K;
   int64_t ld;
+  // distributed Cholesky: K = this rank's share of the block-row-cyclic layout (global row block b of cyc_nb rows
+  // lives on rank b % cyc_W as local block b / cyc_W); values stored as -K, + cyc_lam on the matrix diagonal; only
+  // column points j <= the last row point of the workgroup are walked (lower blocks)
+  int cyc_W, cyc_rank, cyc_nb;
+  double cyc_lam;
 };
 
 __device__ __forceinline__ double block_sum(double v, double* red, int tid, int nwaves) {
@@ -97,7 +102,16 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
   const int64_t i0 = A.i_beg + (int64_t)blockIdx.x * IB;
   const int nb = (A.i_end - i0 < IB) ? (int)(A.i_end - i0) : IB;
   const int64_t jb_beg = (int64_t)blockIdx.y * A.i_chunk;
-  const int64_t jb_end = (jb_beg + A.i_chunk < A.n_j) ? jb_beg + A.i_chunk : A.n_j;
+  int64_t jb_end = (jb_beg + A.i_chunk < A.n_j) ? jb_beg + A.i_chunk : A.n_j;
+  if (A.cyc_W > 0) {  // lower blocks only (dense columns: j = jb), and only row points with a row on this rank
+    const int64_t i_last = i0 + nb - 1;
+    if (jb_end > i_last + 1) jb_end = i_last + 1;
+    if (jb_beg >= jb_end) return;
+    const int64_t b_first = (i0 * (3 * N)) / A.cyc_nb, b_last = ((i_last + 1) * (3 * N) - 1) / A.cyc_nb;
+    bool mine = false;
+    for (int64_t bb = b_first; bb <= b_last; ++bb) mine = mine || (bb % A.cyc_W == A.cyc_rank);
+    if (!mine) return;
+  }
 
   const int n_chunks = (N + AC - 1) / AC;
   const int item = tid;
@@ -363,10 +377,20 @@ __global__ void __launch_bounds__(512, MINW) assemble_kernel(AsmArgs A) {
             for (int aa = 0; aa < AC; ++aa) {
               const int a = chunk * AC + aa;
               if (a < N) {
-                double* dst = A.K + ((int64_t)(i - A.i_beg) * N3 + 3 * a) * A.ld + outcol;
-                dst[0] = acc[ib][aa][0];
-                dst[A.ld] = acc[ib][aa][1];
-                dst[2 * A.ld] = acc[ib][aa][2];
+                if (A.cyc_W > 0) {
+#pragma unroll
+                  for (int al = 0; al < 3; ++al) {
+                    const int64_t grow = i * N3 + 3 * a + al, gb = grow / A.cyc_nb;
+                    if (gb % A.cyc_W == A.cyc_rank)
+                      A.K[((gb / A.cyc_W) * A.cyc_nb + grow % A.cyc_nb) * A.ld + outcol] =
+                          -acc[ib][aa][al] + (grow == outcol ? A.cyc_lam : 0.0);
+                  }
+                } else {
+                  double* dst = A.K + ((int64_t)(i - A.i_beg) * N3 + 3 * a) * A.ld + outcol;
+                  dst[0] = acc[ib][aa][0];
+                  dst[A.ld] = acc[ib][aa][1];
+                  dst[2 * A.ld] = acc[ib][aa][2];
+                }
               }
             }
             if (A.use_E && chunk == 0) A.K[(A.M * N3 + i) * A.ld + outcol] = erow[ib];
@@ -551,6 +575,24 @@ static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   return GDML_OK;
 }
 
+// Rows of A = -K + lam I owned by this rank in the block-row-cyclic layout of the distributed Cholesky (any P,
+// N <= 64): full column range, lower blocks.  K: the rank's local matrix.
+int assemble_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int64_t ld, int cyc_W, int cyc_rank,
+                           int cyc_nb) {
+  TrainSet& ts = ctx->ts;
+  if (assemble_wave_applicable(ctx))
+    return assemble_wave_launch(ctx, sig, 0, nullptr, nullptr, 0, ts.M, K, ld, 0, ts.M, 1, lam, cyc_W, cyc_rank, cyc_nb);
+  AsmArgs A;
+  A.x = ts.x; A.g = ts.g; A.tp = ts.tp; A.perm = ts.perm; A.pinv = ts.pinv;
+  A.M = ts.M; A.N = ts.N; A.D = ts.D; A.P = ts.P; A.sig = sig; A.use_E = 0;
+  A.jlist = nullptr; A.colmap = nullptr; A.j0 = 0; A.col0 = 0; A.i_chunk = 8;
+  A.dbg = 0;
+  A.K = K; A.ld = ld;
+  A.i_beg = 0; A.i_end = ts.M;
+  A.cyc_W = cyc_W; A.cyc_rank = cyc_rank; A.cyc_nb = cyc_nb; A.cyc_lam = lam;
+  return assemble_dispatch(ctx, A, ts.M);
+}
+
 // as_A: assemble for the analytic solve (gdml_assemble_A): where the register-resident kernel applies the
 // matrix is produced directly as A = -K + lam I, blocks on/below the block diagonal only.
 static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind, int64_t col_a, int64_t col_b,
@@ -697,6 +739,7 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
     A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.col0 = 0; A.i_chunk = 8;
     A.dbg = ctx_opt_i(ctx, "asm.debug", 0);
     A.K = ctx->K; A.ld = ld;
+    A.cyc_W = 0; A.cyc_rank = 0; A.cyc_nb = 0; A.cyc_lam = 0.0;
     A.i_beg = i_beg; A.i_end = i_end;
     if (i_end <= i_beg)
       rc = GDML_OK;

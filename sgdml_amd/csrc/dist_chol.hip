@@ -8,7 +8,8 @@
 // Layout: block-ROW cyclic.  The matrix is row-major and the factorisation works on rows (the panel solve is row
 // local, the trailing update of a row needs the panel rows of the columns left of its diagonal), so global row
 // block b (NB = 512 rows, full width) lives on rank b % W as local row block b / W.  Every rank assembles only its
-// own rows (A = -K + lam I, lower blocks: assemble_wave_kernel<N, CYC>), so the matrix never exists in one place:
+// own rows (A = -K + lam I, lower blocks: assemble_wave_kernel<N, CYC> for P = 1, N <= 21, the LDS kernel in its
+// row-cyclic mode for everything else), so the matrix never exists in one place:
 // n^2 * 8 / W bytes per GPU.  Cyclic ownership balances the lower-triangular work (row b has b blocks).
 //
 // Per panel k (right-looking):
@@ -107,9 +108,6 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
   if (info_out) *info_out = 0;
   TrainSet& ts = ctx->ts;
   if (!ts.x) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_dist_chol_solve: call gdml_train_upload first");
-  if (!assemble_wave_applicable(ctx))
-    return gdml_fail(ctx, GDML_ERR_UNSUPPORTED,
-                     "gdml_dist_chol_solve: the row-cyclic assembly exists for P = 1, N <= 21 (register-resident kernel)");
   if (ctx->virtual_rank) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_dist_chol_solve needs a real communicator");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int64_t N3 = 3 * (int64_t)ts.N, n = ts.M * N3;
@@ -158,7 +156,7 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
   auto body = [&]() -> int {
     // ---- assembly of my rows (lower blocks of A = -K + lam I) and the right-hand side
     phase_begin(ctx);
-    GDML_TRY(assemble_wave_launch(ctx, sig, 0, nullptr, nullptr, 0, ts.M, A, ld, 0, ts.M, 1, lam, c.W, c.rank, (int)nb));
+    GDML_TRY(assemble_cyclic_launch(ctx, sig, lam, A, ld, c.W, c.rank, (int)nb));
     GDML_TRY(phase_end(ctx, "assemble"));
     HIP_CHECK(ctx, hipMemcpyAsync(A + Lr * ld, y, n * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(ctx, hipStreamSynchronize(st));  // y is the caller's pageable array

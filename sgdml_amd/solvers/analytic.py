@@ -31,6 +31,8 @@ class Analytic(object):
         ctx.train_upload(R_desc, R_d_desc, _lib.tril_perms_from_lin(tril_perms_lin, dim_d))
 
         if ctx.comm_info()[1] > 1:
+            if use_E_cstr:
+                raise NotImplementedError('the distributed analytic solver does not support energy constraints')
             # GDMLTrain.init_distributed: the system matrix is partitioned block-row-cyclic over the ranks and
             # factored by the distributed Cholesky (csrc/dist_chol.hip); every rank gets the coefficients
             if self.callback is not None:

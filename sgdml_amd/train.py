@@ -310,7 +310,7 @@ class GDMLTrain(object):
         budget = self._device_budget_bytes()
         est_analytic = Analytic.est_device_memory(n_train, n_atoms, task['use_E_cstr'])
         world = self._context().comm_info()[1]
-        if world > 1 and not task['use_E_cstr'] and n_perms == 1 and n_atoms <= 21:
+        if world > 1 and not task['use_E_cstr']:
             # distributed Cholesky: every rank holds 1/world of the matrix plus panel buffers
             n_sys = n_train * 3 * n_atoms
             est_analytic = est_analytic / world + (2 * n_sys + 600000) * 512 * 8

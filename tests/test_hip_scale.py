@@ -339,10 +339,10 @@ def test_nystroem_qr_branch_matches_reference(ctx):
     ctx.set_option('nys.force_qr', 0)
 
 
-def _reference_solve(ctx, R, y, N, sig, lam):
+def _reference_solve(ctx, R, y, N, sig, lam, perms=None):
     M = R.shape[0]
     xd, gd = ctx.desc_from_R(R.reshape(M, -1), N)
-    tp = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
+    tp = np.arange(N * (N - 1) // 2, dtype=np.int64)[None] if perms is None else orc.tril_perms_from_atom_perms(perms)
     ctx.train_upload(xd, gd, tp)
     ctx.assemble_K(sig, False, alloc_extra_rows=1, for_cholesky=lam)
     ctx.chol_set_rhs(y)
@@ -352,13 +352,19 @@ def _reference_solve(ctx, R, y, N, sig, lam):
     return a, (lambda v: ctx.kernel_matvec(lam, False, v))
 
 
-@pytest.mark.parametrize('N,M,nb', [(21, 30, 128), (9, 100, 256), (21, 70, 512)])
-def test_distributed_cholesky_single_rank(ctx, N, M, nb):
-    """gdml_dist_chol_solve with one rank (no communicator): row-cyclic assembly, broadcast-buffer panel solve,
-    cyclic-lower trailing update, blocked backward substitution -- vs the single-GPU factorisation."""
+_P6 = np.array([[0, 1, 2, 3, 4, 5, 6, 7, 8], [1, 2, 0, 3, 4, 5, 6, 7, 8], [2, 0, 1, 3, 4, 5, 6, 7, 8],
+                [0, 1, 2, 4, 3, 5, 6, 7, 8], [1, 2, 0, 4, 3, 5, 6, 7, 8], [2, 0, 1, 4, 3, 5, 6, 7, 8]])
+
+
+@pytest.mark.parametrize('N,M,nb,perms', [(21, 30, 128, None), (9, 100, 256, None), (21, 70, 512, None),
+                                          (9, 60, 256, _P6), (26, 20, 128, None)])
+def test_distributed_cholesky_single_rank(ctx, N, M, nb, perms):
+    """gdml_dist_chol_solve with one rank (no communicator): row-cyclic assembly (register-resident kernel for
+    P = 1, N <= 21; the LDS kernel's cyclic mode for permutation groups and larger molecules), broadcast-buffer panel
+    solve, cyclic-lower trailing update, blocked backward substitution -- vs the single-GPU factorisation."""
     ds = orc.synth_dataset(N, M, seed=9, jitter=0.3)
     y = ds['F'].ravel() / np.std(ds['F'])
-    a_ref, Kop = _reference_solve(ctx, ds['R'], y, N, 20.0, 1e-10)
+    a_ref, Kop = _reference_solve(ctx, ds['R'], y, N, 20.0, 1e-10, perms)
     ctx.set_option('dist.nb', nb)
     a = ctx.dist_chol_solve(20.0, 1e-10, y)
     r = Kop(-a) + y  # y - A x with A x = -(K x - lam x)
