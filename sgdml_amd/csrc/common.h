@@ -183,6 +183,7 @@ int desc_device(gdml_ctx* ctx, const double* d_R, int64_t M, int N, const double
                 const double* lat_inv, double* d_x, double* d_g);
 int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_t B, double* d_E,
                    double* d_F);
+int predict_wide_device(gdml_ctx* ctx, const double* d_xq, int64_t B, double* part_F, double* part_E);
 int set_alphas_device(gdml_ctx* ctx, const double* d_alphas_F, const double* d_alphas_E);
 int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, int64_t n,
                   double* d_out);

@@ -700,6 +700,23 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   int KPL = 1;
   while (KPL * 64 < D) KPL <<= 1;
   if (KPL > 32) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "predict kernel supports D <= 2048");
+  // below ~1e9 (row, query, descriptor) triples the seven launches of the pipeline cost more than the wave kernel
+  // (tools/predict_wide_probe.py); option predict.mfma_wide = 2 forces it (tests)
+  const int wide_opt = ctx_opt_i(ctx, "predict.mfma_wide", 1);
+  const bool wide = (B >= 256) && (D > 256) && !ctx_opt_i(ctx, "predict.wave_only", 0) &&
+                    (wide_opt == 2 || (wide_opt == 1 && (double)MP * (double)B * (double)D >= 1.0e9));
+  if (wide) {  // large molecules: the contractions as tiled fp64-MFMA GEMMs (predict_wide.hip)
+    double* part;
+    GDML_TRY(ctx_slot(ctx, 0, (B * (int64_t)D + B) * 8, &part));
+    const int slot = ktime_begin(ctx);
+    GDML_TRY(predict_wide_device(ctx, d_xq, B, part, part + B * (int64_t)D));
+    ktime_end(ctx, slot, "predict", 10.0 * (double)D * (double)B * (double)MP);
+    hipLaunchKernelGGL(predict_epilogue_kernel, dim3((unsigned)B), dim3(256), (size_t)D * 8, ctx->stream, part,
+                       part + B * (int64_t)D, d_gq, B, N, D, 1, d_E, d_F);
+    ctx->launch_counter++;
+    HIP_CHECK(ctx, hipGetLastError());
+    return GDML_OK;
+  }
   const bool bulk = (B >= 256) && (D <= 256) && !ctx_opt_i(ctx, "predict.wave_only", 0);
   const bool mfma = bulk && ctx_opt_i(ctx, "predict.mfma", 1);
   int QB = max_qb_for(KPL);

@@ -793,3 +793,36 @@ def test_assemble_A_lower_form(ctx_factory, N, M):
     for a in (a1, a2):
         assert np.linalg.norm(Ao @ (-a) - y) <= 1e-9 * np.linalg.norm(y)
     assert np.abs(a1 - a2).max() <= 1e-6 * np.abs(a2).max()
+
+
+@pytest.mark.parametrize('n_atoms,n_train,n_query,n_perms,with_aE', [
+    (24, 40, 300, 1, False),   # D = 276: first size past the register-resident MFMA kernel
+    (26, 30, 257, 2, True),    # odd D (325), permutations, energy-constraint terms, ragged query tile
+    (42, 12, 256, 1, False),   # D = 861 (BASELINE configs[3] molecule size)
+    (60, 5, 300, 1, True),     # D = 1770 (configs[4])
+])
+def test_predict_wide_mfma(ctx_factory, n_atoms, n_train, n_query, n_perms, with_aE):
+    """Large molecules (D > 256): the GEMM-pipeline prediction path (predict_wide.hip) against the wave kernel on
+    the same model, incl. training-set style coincident points (queries 0..M-1 ARE the training geometries)."""
+    rs = np.random.RandomState(n_atoms)
+    N, M, B = n_atoms, n_train, n_query
+    ds = orc.synth_dataset(N, M + B, seed=4, jitter=0.3)
+    Rf = ds['R'].reshape(M + B, -1)
+    perms = np.arange(N)[None]
+    if n_perms == 2:
+        p2 = np.arange(N)
+        p2[[0, 1]] = p2[[1, 0]]
+        perms = np.vstack([perms, p2])
+    tp = orc.tril_perms_from_atom_perms(perms)
+    xd, gd = orc.desc_from_R(Rf[:M])
+    ja = rs.normal(size=xd.shape)
+    aE = rs.normal(size=M) if with_aE else None
+    Rq = np.vstack([Rf[:M], Rf[M:M + B - M]])  # first M queries coincide with the training points
+    c = ctx_factory()
+    c.predict_upload_model(xd, ja, tp, 25.0, aE)
+    c.set_option('predict.mfma_wide', 2)  # force the pipeline at test sizes
+    E1, F1 = c.predict(Rq)
+    c.set_option('predict.wave_only', 1)
+    E0, F0 = c.predict(Rq)
+    assert np.abs(F1 - F0).max() <= 1e-11 * np.abs(F0).max()
+    assert np.abs(E1 - E0).max() <= 1e-11 * np.abs(E0).max()
