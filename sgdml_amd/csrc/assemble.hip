@@ -708,8 +708,9 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
   ctx->K_rhs_row = false;
   ctx->K_sig = sig;
   ctx->K_use_E = use_E_cstr;
-  const bool lower_A = as_A && col_kind == GDML_COLS_ALL && !use_E_cstr && !sharded && assemble_wave_applicable(ctx) &&
-                       ctx_opt_i(ctx, "asm.lower", 1) != 0;
+  // fused form for the analytic solve: the register-resident kernel (P = 1, N <= 21) or, for permutation groups and
+  // larger molecules, the LDS kernel in its lower / negated mode (= its row-cyclic mode with one rank)
+  const bool lower_A = as_A && col_kind == GDML_COLS_ALL && !use_E_cstr && !sharded && ctx_opt_i(ctx, "asm.lower", 1) != 0;
   ctx->K_is_A = lower_A;
   if (lower_A) ctx->K_lam = lam;
 
@@ -743,6 +744,8 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
     A.i_beg = i_beg; A.i_end = i_end;
     if (i_end <= i_beg)
       rc = GDML_OK;
+    else if (lower_A && !assemble_wave_applicable(ctx))
+      rc = assemble_cyclic_launch(ctx, sig, lam, ctx->K, ld, 1, 0, 512);
     else if (assemble_wave_applicable(ctx))
       rc = assemble_wave_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, ctx->K, ld, i_beg, i_end,
                                 lower_A ? 1 : 0, lam);

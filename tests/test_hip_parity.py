@@ -758,14 +758,18 @@ def test_predict_mfma_randomised(ctx_factory, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize('N,M', [(21, 40), (9, 70), (5, 33)])
-def test_assemble_A_lower_form(ctx_factory, N, M):
+_P6_9 = np.array([[0, 1, 2, 3, 4, 5, 6, 7, 8], [1, 2, 0, 3, 4, 5, 6, 7, 8], [2, 0, 1, 3, 4, 5, 6, 7, 8],
+                  [0, 1, 2, 4, 3, 5, 6, 7, 8], [1, 2, 0, 4, 3, 5, 6, 7, 8], [2, 0, 1, 4, 3, 5, 6, 7, 8]])
+
+
+@pytest.mark.parametrize('N,M,perms', [(21, 40, None), (9, 70, None), (5, 33, None), (9, 30, _P6_9), (24, 14, None)])
+def test_assemble_A_lower_form(ctx_factory, N, M, perms):
     """gdml_assemble_A: A = -K + lam I written directly, blocks on/below the block diagonal only.  The written
     part must equal -K + lam I of the oracle elementwise, and factor + solve must agree with the two-step path
     (gdml_assemble_K, sign flip and shift inside gdml_chol_factor) to the conditioning of the system."""
     ds = orc.synth_dataset(N, M, seed=5, jitter=0.3)
     xo, go = orc.desc_from_R(ds['R'].reshape(M, -1))
-    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None] if perms is None else perms)
     sig, lam = 20.0, 1e-8
     Ko = orc.assemble_K(xo, go, orc.tril_perms_lin_from_tril_perms(tp), sig)
     n, N3 = Ko.shape[0], 3 * N
