@@ -499,7 +499,8 @@ static size_t asm_lds_bytes(int N, int D, int IB, bool gjg = false) {
 static int assemble_dispatch(gdml_ctx* ctx, AsmArgs& A, int64_t n_j) {
   const int N = A.N, D = A.D;
   static const int acs[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
-  const int t_target = ctx_opt_i(ctx, "asm.threads", 256);
+  // threads per workgroup: measured optimum by molecule size (profiles/r02_assemble_lds_sweep.txt)
+  const int t_target = ctx_opt_i(ctx, "asm.threads", N >= 22 ? 512 : (N >= 12 && N <= 16 ? 128 : 256));
   int AC = 32;
   for (int v : acs) {
     int items = ((N + v - 1) / v) * 3 * N;
