@@ -240,7 +240,9 @@ int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
     return gdml_fail(ctx, GDML_ERR_INVALID, "assemble_wave: lower form needs the dense full column range");
   const int64_t n_i = i_end - i_beg;
   if (n_i <= 0) return GDML_OK;
-  int j_chunk = ctx_opt_i(ctx, "asm.j_chunk", 64);
+  // column points walked by one wavefront: 64 for full rows; 32 in the lower form (measured 3.90 vs 4.06-4.22 ms at the
+  // benchmark size, tools/asm_lower_probe.py: shorter walks balance the triangular rows better)
+  int j_chunk = ctx_opt_i(ctx, "asm.j_chunk", lower ? 32 : 64);
   while (j_chunk > 8 && n_i * ((n_j + j_chunk - 1) / j_chunk) < 8192) j_chunk >>= 1;
   A.j_chunk = j_chunk;
   dim3 grid((unsigned)n_i, (unsigned)((n_j + j_chunk - 1) / j_chunk));
