@@ -37,11 +37,13 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 0, 0])
     print('%-40s %8d %16.3f %16.3f %14.4f' % (k[:40], n, rd / 1e9, wr / 1e9, (rd + wr) / max(1, n) / 1e9))
     out[k] = {'launches': n, 'read_bytes': rd, 'written_bytes': wr, 'hbm_bytes_per_launch': (rd + wr) / max(1, n)}
 res = {}
-for key, pat in (('gemm_nt_sub', 'gemm_nt_sub_kernel'), ('assemble', 'assemble_wave_kernel')):
-    for k, v in out.items():
-        if k.startswith(pat):
-            res[key] = {'hbm_bytes_per_launch': v['hbm_bytes_per_launch'], 'read_bytes_per_launch': v['read_bytes'] / v['launches'],
-                        'written_bytes_per_launch': v['written_bytes'] / v['launches'], 'launches': v['launches'],
-                        'source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950 half-count) + WRITE_SIZE, separate passes of '
-                                  'bench.py --steps 1 (tools/profile_round.sh); memory-side requests incl. Infinity-Cache hits'}
+for key, pat in (('gemm_nt_sub', 'gemm_nt_sub'), ('assemble', 'assemble_wave_kernel')):
+    sel = [v for k, v in out.items() if k.startswith(pat)]  # all instantiations (plain + fused diagonal-block launch)
+    if sel:
+        n = sum(v['launches'] for v in sel)
+        rd, wr = sum(v['read_bytes'] for v in sel), sum(v['written_bytes'] for v in sel)
+        res[key] = {'hbm_bytes_per_launch': (rd + wr) / n, 'read_bytes_per_launch': rd / n, 'written_bytes_per_launch': wr / n,
+                    'launches': n,
+                    'source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950 half-count) + WRITE_SIZE, separate passes of '
+                              'bench.py --steps 1 (tools/profile_round.sh); memory-side requests incl. Infinity-Cache hits'}
 json.dump(res, open(sys.argv[3], 'w'), indent=1)
