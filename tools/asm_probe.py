@@ -11,7 +11,7 @@ def run(N, M, P=1, reps=3):
     D = N * (N - 1) // 2
     from oracle import gdml_oracle as orc
     perms = [list(range(N))]
-    for q in range(1, P):
+    for q in range(1, P):  # P - 1 transpositions of disjoint atom pairs (not a group: the kernel does not care)
         p2 = list(range(N)); p2[2*q-2], p2[2*q-1] = p2[2*q-1], p2[2*q-2]; perms.append(p2)
     tp = orc.tril_perms_from_atom_perms(np.array(perms))
     xd, gd = ctx.desc_from_R(R.reshape(M, -1), N)
@@ -21,7 +21,7 @@ def run(N, M, P=1, reps=3):
         ctx.assemble_K(20.0, False)
         ts.append(ctx.phase_ms('assemble')[0])
     n = M * 3 * N
-    print('N=%d M=%d P=%d dbg=%s: %.2f ms  -> %.0f GB/s' % (N, M, P, os.environ.get('GDML_ASM_DEBUG', '0'), min(ts), 8.0 * n * n / min(ts) / 1e6), flush=True)
+    print('N=%d M=%d P=%d dbg=%s: %.2f ms  -> %.0f GB/s' % (N, M, P, os.environ.get('GDML_OPTIONS', '-'), min(ts), 8.0 * n * n / min(ts) / 1e6), flush=True)
     ctx.close()
 
 if __name__ == '__main__':

@@ -1,4 +1,4 @@
-"""GEMM ablation probe: factor the benchmark matrix once per GDML_GEMM_DEBUG mask and report the
+"""GEMM ablation probe: factor the benchmark matrix under GDML_OPTIONS="gemm.debug=<mask>" and report the
 aggregated gemm_nt_sub rate (numerically meaningless masks are fine: NOT_PD is caught)."""
 import os, sys
 import numpy as np
@@ -23,4 +23,4 @@ for rep in range(2):
         pass
     ms, n, w = ctx.kernel_stat('gemm_nt_sub')
     print('dbg=%s rep %d: gemm %.1f TF (%.1f ms in %d launches), factor %.1f ms' % (
-        os.environ.get('GDML_GEMM_DEBUG', '0'), rep, w / ms / 1e9, ms, n, ctx.phase_ms('factor')[0]), flush=True)
+        os.environ.get('GDML_OPTIONS', '-'), rep, w / ms / 1e9, ms, n, ctx.phase_ms('factor')[0]), flush=True)

@@ -15,13 +15,12 @@ def run(N, M, B, seed=0):
     rs = np.random.RandomState(seed)
     ctx.predict_upload_model(xd, rs.normal(size=xd.shape), tp, 20.0, None)
     out = {}
-    for name, env in (('mfma', {}), ('bulk', {'GDML_PREDICT_NO_MFMA': '1'}), ('wave', {'GDML_PREDICT_V1': '1'})):
-        for k in ('GDML_PREDICT_NO_MFMA', 'GDML_PREDICT_V1'):
-            os.environ.pop(k, None)
-        os.environ.update(env)
+    for name, opts in (('mfma', {}), ('bulk', {'predict.mfma': 0}), ('wave', {'predict.wave_only': 1})):
+        ctx.set_option('predict.mfma', 1)
+        ctx.set_option('predict.wave_only', 0)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
         out[name] = ctx.predict(Rf[M:])
-    for k in ('GDML_PREDICT_NO_MFMA', 'GDML_PREDICT_V1'):
-        os.environ.pop(k, None)
     Fw = out['wave'][1]; Ew = out['wave'][0]
     sc = np.abs(Fw).max()
     for name in ('mfma', 'bulk'):

@@ -28,11 +28,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     ja = rs.normal(size=xd.shape) * 10.0 ** rs.uniform(-2, 4)
     aE = rs.normal(size=M) if with_aE else None
     ctx.predict_upload_model(xd, ja, tp, sig, aE)
-    os.environ.pop('GDML_PREDICT_V1', None)
     E1, F1 = ctx.predict(Rf[M:])
-    os.environ['GDML_PREDICT_V1'] = '1'
+    ctx.set_option('predict.wave_only', 1)
     E0, F0 = ctx.predict(Rf[M:])
-    os.environ.pop('GDML_PREDICT_V1', None)
     dF = np.abs(F1 - F0).max() / np.abs(F0).max(); dE = np.abs(E1 - E0).max() / np.abs(E0).max()
     worst = max(worst, dF, dE)
     flag = '' if max(dF, dE) < 1e-11 else '   <-- CHECK'

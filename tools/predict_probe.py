@@ -29,7 +29,7 @@ def run(N, M, B, reps=5):
         ts.append(ctx.phase_ms('predict')[0])
     kms, kn, kw = ctx.kernel_stat('predict')
     print('N=%d M=%d B=%d v1=%s: phase %.3f ms, kernel %.3f ms -> %.2e geoms/s, %.1f TF alg' % (
-        N, M, B, os.environ.get('GDML_PREDICT_V1', '0'), min(ts), kms / kn, B / (min(ts) * 1e-3), kw / kms / 1e9), flush=True)
+        N, M, B, os.environ.get('GDML_OPTIONS', '-'), min(ts), kms / kn, B / (min(ts) * 1e-3), kw / kms / 1e9), flush=True)
     ctx.close()
 
 if __name__ == '__main__':
