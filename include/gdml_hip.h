@@ -234,13 +234,16 @@ int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const d
 
 /* ---- multi-GPU (new: the reference has no collective) ----------------------
  * One process per GPU.  Rank 0 calls gdml_comm_unique_id (128 bytes) and ships it to the
- * other ranks by any host channel (bench.py uses torch.distributed's store); every rank then
+ * other ranks by any host channel (sgdml_amd/dist.py uses torch.distributed's store); every rank then
  * calls gdml_comm_init (id128 = NULL: "virtual rank" without a communicator, shard arithmetic only --
- * tests).  After that the iterative path is sharded over the training points (contiguous row shards):
- * gdml_assemble_K(GDML_COLS_INDEX, ..., alloc_extra_rows > 0) assembles the rank's rows of K_nm,
- * gdml_nystroem_factor / gdml_precon_apply / gdml_kernel_matvec / gdml_pcg use RCCL all-reduce and
- * all-gather of m- and n-vectors over xGMI.  The analytic path (gdml_chol_*) is per GPU: a matrix must fit
- * one device (a distributed Cholesky is not part of this library yet). */
+ * tests).  After that
+ *   - the iterative path is sharded over the training points (contiguous row shards):
+ *     gdml_assemble_K(GDML_COLS_INDEX, ..., alloc_extra_rows > 0) assembles the rank's rows of K_nm,
+ *     gdml_nystroem_factor / gdml_precon_apply / gdml_kernel_matvec / gdml_pcg exchange m- and n-vectors with
+ *     RCCL all-reduce / all-gather over xGMI;
+ *   - the analytic path is gdml_dist_chol_solve (block-row-cyclic matrix, below).
+ * The collectives are issued for every communicator size, including one rank.  gdml_chol_* / gdml_lu_solve stay
+ * single-GPU entry points. */
 int gdml_comm_unique_id(void* id128_out);
 int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world);
 int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out);

@@ -7,14 +7,18 @@
 // Storage: row-major, LOWER triangle referenced (A = L L^T, L overwrites the lower triangle; the
 // strict upper triangle is scratch and may be overwritten with garbage).
 //
-// Right-looking blocked algorithm, outer panel width NB (512), inner width 64:
-//   for each panel:   for each 64-wide sub-block:  potrf_trsm64 (diagonal block factored by one wavefront per
-//                                                               workgroup, then the rows below by substitution)
-//                                                  gemm_nt (K=64 update of the rest of the panel)
-//                     syrk: trailing -= P P^T with gemm_nt (K=NB) on v_mfma_f64_16x16x4_f64
-//   one panel of look-ahead on a second stream; a right-hand side stored as an extra row is carried through
-//   (forward substitution for free); the backward substitution is one persistent launch.
-// n^3/3 of the flops are in gemm_nt; everything else is O(n^2 NB).
+// Right-looking blocked algorithm, panel width NB (512), ONE stream.  Per panel k:
+//   gemm_nt_sub            columns of panel k+1:  C[t0:n, t0:t1] -= P P^T                     (K = NB)
+//   gemm_nt_sub_diag       the rest of the trailing matrix (SYRK, lower tiles); workgroup 0 of this launch factors
+//                          the NB x NB diagonal block of panel k+1 meanwhile (diag_block_role: potrf64_wg, substitution,
+//                          MFMA rank-64 updates) -- the dependent step chain is hidden inside the big launch
+//   panel_trsm             row-local solve of the rows below that block, one launch (strip in registers, MFMA updates)
+// Near the end (SYRK shorter than the single-workgroup block factorisation) and for the first / ragged panels the
+// block is factored by the multi-workgroup 64-wide step chain (potrf_trsm64 + K = 64 GEMM) instead.
+// A right-hand side stored as an extra row is carried through (forward substitution for free); the backward
+// substitution is one persistent launch with a per-block fallback.  n^3/3 of the flops are in gemm_nt_sub.
+// The round-1 schedule (step chain on a second stream with one panel of look-ahead, CU-masked variants) is still
+// selectable with option chol.fused_diag = 0; profiles/r02_panel_fusion_ab.txt has the comparison.
 #include "common.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
