@@ -84,8 +84,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   asm.lower (1)         analytic path: assemble only blocks on/below the diagonal, as -K + lam I
  *   asm.threads, asm.ib, asm.minw, asm.gj_global, asm.j_chunk, asm.debug   LDS-kernel shape / ablations
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
- *   chol.nb (512), chol.lookahead (1), chol.panel_fused (1), chol.panel_kernel, chol.split (0), chol.aux_cus,
- *   chol.mask_rows, chol.mask_cus, chol.panel_a, chol.panel_b, chol.gemm_tf     factorisation schedule
+ *   chol.nb (512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),
+ *   chol.lookahead (1)    factorisation schedule (fused_diag = 0: the round-1 second-stream look-ahead schedule)
  *   trsv.persist (1)      backward substitution as one persistent launch
  *   predict.wave_only (0), predict.mfma (1), predict.mfma_wide (1), predict.fill   prediction kernel choice
  *   lu.nb (64)            panel width of the LU fallback

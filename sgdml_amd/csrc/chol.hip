@@ -17,8 +17,9 @@
 // block is factored by the multi-workgroup 64-wide step chain (potrf_trsm64 + K = 64 GEMM) instead.
 // A right-hand side stored as an extra row is carried through (forward substitution for free); the backward
 // substitution is one persistent launch with a per-block fallback.  n^3/3 of the flops are in gemm_nt_sub.
-// The round-1 schedule (step chain on a second stream with one panel of look-ahead, CU-masked variants) is still
-// selectable with option chol.fused_diag = 0; profiles/r02_panel_fusion_ab.txt has the comparison.
+// The round-1 schedule (step chain on a second stream with one panel of look-ahead) is still selectable with option
+// chol.fused_diag = 0; profiles/r02_panel_fusion_ab.txt has the comparison.  The CU-masked / split-stream / chunked
+// variants measured in rounds 1-2 (profiles/r01_chol_timeline_split.txt, r02_sched_probe.txt) are gone.
 #include "common.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -925,80 +926,6 @@ int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int6
   return GDML_OK;
 }
 
-// Right-looking blocked Cholesky with one panel of look-ahead: after panel k is factored, the
-// compute stream first updates only the columns of panel k+1, then (a) the panel stream factors
-// panel k+1 (latency-bound 64-wide steps) while (b) the compute stream applies the big SYRK to
-// the rest of the trailing matrix.  The two touch disjoint columns.
-// Split-stream schedule (option chol.split, off by default): the panel kernels need a CU with a free GEMM slot
-// (a GEMM workgroup takes half the registers and LDS of a CU), and while the SYRK grid has workgroups
-// pending the dispatcher refills every slot with the next GEMM workgroup -- so with plain look-ahead the
-// panel only makes progress once the SYRK has drained and ends up exposed in every step (timeline:
-// 136 ms of 1.63 s without any GEMM running).  Here the two streams carry complementary CU masks for the
-// whole factorisation: the auxiliary stream owns `aux_cus` compute units, runs panel k+1 there right away
-// and then takes a share of SYRK k sized so that both streams finish together; the main stream does the
-// rest of SYRK k on the other CUs.
-static int chol_factor_split(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int64_t NB, int aux_cus) {
-  GDML_TRY(ctx_masked_streams(ctx, aux_cus));
-  hipStream_t sm = ctx->stream_mm, sa = ctx->stream_mp;
-  hipEvent_t evA = ctx->ev_la[0], evB = ctx->ev_la[1];
-  // panel time on the auxiliary CUs: t_p(m) = pa + pb * m  [ms];  full-chip SYRK: t_s(m) = m^2 nb / rate
-  const double pa = ctx_opt(ctx, "chol.panel_a", 0.5);
-  const double pb = ctx_opt(ctx, "chol.panel_b", 2.7e-3 / (double)aux_cus);  // ms per row per CU^-1
-  const double rate = ctx_opt(ctx, "chol.gemm_tf", 57.0);
-  const double fa = (double)aux_cus / (double)ctx->num_cus;  // capacity share of the auxiliary stream
-  HIP_CHECK(ctx, hipEventRecord(evA, ctx->stream));
-  HIP_CHECK(ctx, hipStreamWaitEvent(sm, evA, 0));
-  ctx->kt_stream = sm;
-  GDML_TRY(panel_factor(ctx, sm, A, n, ld, 0, n < NB ? n : NB));
-  for (int64_t k0 = 0; k0 < n; k0 += NB) {
-    const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
-    const int64_t t0 = k0 + nb;
-    if (t0 >= n) break;
-    const int64_t nb2 = (n - t0 < NB) ? n - t0 : NB;
-    const int64_t t1 = t0 + nb2;
-    const double* P = A + t0 * ld + k0;
-    // (1) next panel's columns on the main CUs
-    GDML_TRY(launch_gemm_nt_sub(ctx, sm, P, ld, P, ld, A + t0 * ld + t0, ld, n - t0, nb2, nb, 0));
-    HIP_CHECK(ctx, hipEventRecord(evA, sm));
-    HIP_CHECK(ctx, hipStreamWaitEvent(sa, evA, 0));
-    // (2) panel k+1 on the auxiliary CUs, then its share of the trailing update
-    GDML_TRY(panel_factor(ctx, sa, A, n, ld, t0, nb2));
-    const int64_t m = n - t1;
-    double f_aux = 0.0;
-    if (m > 0) {
-      const double t_s = (double)m * (double)m * (double)nb / (rate * 1e9);  // ms on the whole chip
-      const double t_p = pa + pb * (double)(n - t0);
-      // t_p + f t_s / fa = (1 - f) t_s / (1 - fa)
-      f_aux = (t_s / (1.0 - fa) - t_p) / (t_s / fa + t_s / (1.0 - fa));
-      if (f_aux < 0.0) f_aux = 0.0;
-      if (f_aux > fa) f_aux = fa;
-      const int64_t tiles = (m + GT - 1) / GT, sup = (tiles + 7) / 8;
-      if (sup * (sup + 1) / 2 < 64) f_aux = 0.0;  // too few super tiles to split
-      const double* P1 = A + t1 * ld + k0;
-      const int slot = ktime_begin(ctx);
-      if (f_aux > 0.0)
-        GDML_TRY(launch_gemm_nt_sub_part(ctx, sa, P1, ld, P1, ld, A + t1 * ld + t1, ld, m, m, nb, 1, 1.0 - f_aux,
-                                         1.0, false));
-      HIP_CHECK(ctx, hipEventRecord(evB, sa));
-      GDML_TRY(launch_gemm_nt_sub_part(ctx, sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, m, m, nb, 1, 0.0,
-                                       1.0 - f_aux, false));
-      HIP_CHECK(ctx, hipStreamWaitEvent(sm, evB, 0));
-      ktime_end(ctx, slot, "gemm_nt_sub", (double)m * (double)(m + 1) * (double)nb);  // both parts, to the join
-    } else {
-      HIP_CHECK(ctx, hipEventRecord(evB, sa));
-      HIP_CHECK(ctx, hipStreamWaitEvent(sm, evB, 0));
-    }
-  }
-  if (ctx->profiling) {
-    HIP_CHECK(ctx, hipStreamSynchronize(sm));
-    GDML_TRY(ktime_collect(ctx));
-  }
-  ctx->kt_stream = nullptr;
-  HIP_CHECK(ctx, hipEventRecord(evA, sm));
-  HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, evA, 0));
-  return GDML_OK;
-}
-
 // n: order of the matrix; n_rows >= n: rows n..n_rows-1 are carried along (right-hand sides stored as extra
 // rows: they go through the panel solves and trailing updates, i.e. through the forward substitution)
 int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out, int64_t n_rows) {
@@ -1007,18 +934,6 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
   int64_t NB = (int64_t)ctx_opt(ctx, "chol.nb", 512);  // outer panel width (multiple of 64)
   if (NB < 64 || NB % 64) NB = 512;
   const bool lookahead = ctx_opt_i(ctx, "chol.lookahead", 1) != 0;
-  {
-    const int split = ctx_opt_i(ctx, "chol.split", 0), aux_cus = ctx_opt_i(ctx, "chol.aux_cus", 32);
-    if (split && n_rows == n && n > 4 * NB && lookahead) {
-      GDML_TRY(chol_factor_split(ctx, A, n, ld, NB, aux_cus));
-      HIP_CHECK(ctx, hipGetLastError());
-      int info = 0;
-      HIP_CHECK(ctx, hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-      if (info_out) *info_out = info;
-      return GDML_OK;
-    }
-  }
   // ---- default schedule: ONE stream.  Per panel k:  GEMM1 (columns of panel k+1)  ->  SYRK of the rest, whose
   // workgroup 0 factors the diagonal block of panel k+1 meanwhile  ->  row-local solve of panel k+1's rows.
   // The 64-wide step chain of the diagonal block is hidden inside the SYRK launch; only the row-local solve
@@ -1061,35 +976,16 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
     if (info_out) *info_out = info;
     return GDML_OK;
   }
+  // ---- round-1 schedule (option chol.fused_diag = 0; A/B reference): the step chain of panel k+1 on a second
+  // stream with one panel of look-ahead (the hardware hardly overlaps it: profiles/r02_sched_probe.txt), or fully
+  // sequential on one stream with chol.lookahead = 0
   hipStream_t sm = ctx->stream, sp = ctx->stream2;
   hipEvent_t evA = ctx->ev_la[0], evB = ctx->ev_la[1];
-  // schedule experiments: another stream for the panel chain; the trailing SYRK split into chunks that
-  // alternate between the main stream and a second bulk stream
-  const int ps_idx = ctx_opt_i(ctx, "chol.panel_stream", -1);
-  if (ps_idx >= 0) GDML_TRY(ctx_pool_stream(ctx, ps_idx, &sp));
-  const int syrk_chunks = ctx_opt_i(ctx, "chol.syrk_chunks", 1);
-  hipStream_t sm2 = nullptr;
-  if (syrk_chunks > 1) GDML_TRY(ctx_pool_stream(ctx, ctx_opt_i(ctx, "chol.syrk_stream", 1), &sm2));
-  // late phase: once fewer than mask_rows rows remain the panel chain is the critical path; from then
-  // on the two streams are a CU-masked pair, so that the panel kernels never queue behind GEMM workgroups
-  const int64_t mask_rows = (int64_t)ctx_opt(ctx, "chol.mask_rows", 0);
-  const int mask_cus = ctx_opt_i(ctx, "chol.mask_cus", 32);
-  bool masked = false;
   GDML_TRY(panel_factor(ctx, sm, A, n_rows, ld, 0, n < NB ? n : NB));
   for (int64_t k0 = 0; k0 < n; k0 += NB) {
     const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
     const int64_t t0 = k0 + nb;
-    if (t0 >= n_rows) break;
     if (t0 >= n) break;
-    if (lookahead && !masked && mask_rows > 0 && n - t0 < mask_rows) {
-      GDML_TRY(ctx_masked_streams(ctx, mask_cus));
-      HIP_CHECK(ctx, hipEventRecord(evA, sm));  // everything issued so far is on sm (sp has been joined)
-      HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_mm, evA, 0));
-      sm = ctx->stream_mm;
-      sp = ctx->stream_mp;
-      ctx->kt_stream = sm;
-      masked = true;
-    }
     const int64_t nb2 = (n - t0 < NB) ? n - t0 : NB;
     const int64_t t1 = t0 + nb2;
     const double* P = A + t0 * ld + k0;  // rows t0.. of panel k
@@ -1104,31 +1000,12 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
     // (2) rest of the trailing matrix: C[t1:n, t1:n] -= P[t1:n] P[t1:n]^T  (lower)
     if (t1 < n) {
       const double* P1 = A + t1 * ld + k0;
-      if (syrk_chunks > 1 && lookahead && n - t1 > 8192 && n_rows == n) {
-        HIP_CHECK(ctx, hipStreamWaitEvent(sm2, evA, 0));
-        for (int c = 0; c < syrk_chunks; ++c)
-          GDML_TRY(launch_gemm_nt_sub_part(ctx, (c & 1) ? sm2 : sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, n - t1, n - t1, nb,
-                                           1, (double)c / syrk_chunks, (c + 1 == syrk_chunks) ? 1.0 : (double)(c + 1) / syrk_chunks,
-                                           true));
-        HIP_CHECK(ctx, hipEventRecord(ctx->ev_pool[0], sm2));
-        HIP_CHECK(ctx, hipStreamWaitEvent(sm, ctx->ev_pool[0], 0));
-      } else {
-        GDML_TRY(launch_gemm_nt_sub(ctx, sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1));
-      }
+      GDML_TRY(launch_gemm_nt_sub(ctx, sm, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1));
     }
     if (lookahead)
       HIP_CHECK(ctx, hipStreamWaitEvent(sm, evB, 0));
     else
       GDML_TRY(panel_factor(ctx, sm, A, n_rows, ld, t0, nb2));
-  }
-  if (masked) {  // join the masked pair back into the context's main stream
-    if (ctx->profiling) {
-      HIP_CHECK(ctx, hipStreamSynchronize(sm));  // the timers of the late GEMMs were recorded on sm
-      GDML_TRY(ktime_collect(ctx));
-    }
-    ctx->kt_stream = nullptr;
-    HIP_CHECK(ctx, hipEventRecord(evA, sm));
-    HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, evA, 0));
   }
   HIP_CHECK(ctx, hipGetLastError());
   int info = 0;

@@ -64,13 +64,9 @@ struct gdml_ctx {
   int num_cus = 256;  // compute units of the device (grid sizing)
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;
-  hipStream_t stream_mm = nullptr, stream_mp = nullptr;  // CU-masked pair (late Cholesky panels), lazily created
-  int masked_cus = 0;                                    // CUs reserved for stream_mp
   hipStream_t kt_stream = nullptr;                       // stream the per-kernel timers record on (default: stream)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_la[2] = {nullptr, nullptr};  // look-ahead hand-off between the two streams
-  hipStream_t pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // schedule experiments
-  hipEvent_t ev_pool[4] = {nullptr, nullptr, nullptr, nullptr};
   std::string err;
   std::map<std::string, double> opts;  // tuning / ablation options (gdml_set_option); absent key = built-in default
   int64_t held = 0;
@@ -152,8 +148,6 @@ int ctx_free(gdml_ctx* ctx, void* p);
 int ctx_scratch(gdml_ctx* ctx, int64_t bytes, double** out);
 void phase_begin(gdml_ctx* ctx);
 // kernel timing (no-ops unless ctx->profiling)
-int ctx_masked_streams(gdml_ctx* ctx, int reserve_cus);  // creates stream_mm / stream_mp
-int ctx_pool_stream(gdml_ctx* ctx, int idx, hipStream_t* out);  // lazily created extra streams (0-3 normal, 4-7 high priority)
 int phase_resolve(gdml_ctx* ctx);  // reads a pending phase timer (waits for its end event)
 int ktime_begin(gdml_ctx* ctx);  // returns slot or -1
 void ktime_end(gdml_ctx* ctx, int slot, const char* name, double work);

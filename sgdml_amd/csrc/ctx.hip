@@ -27,9 +27,8 @@ extern "C" int gdml_abi_version(void) { return 2; }
 // a context is created (lab convenience for the probes under tools/).
 static const char* kKnownOptions[] = {
     "asm.wave", "asm.threads", "asm.ib", "asm.minw", "asm.gj_global", "asm.j_chunk", "asm.debug", "asm.lower",
-    "gemm.debug", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.split", "chol.aux_cus",
-    "chol.mask_rows", "chol.mask_cus", "chol.panel_a", "chol.panel_b", "chol.gemm_tf", "chol.panel_kernel",
-    "chol.panel_stream", "chol.syrk_chunks", "chol.syrk_stream", "chol.fused_diag", "chol.fused_min_rows", 
+    "gemm.debug", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
+    "chol.fused_min_rows",
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
     "lu.nb", "comm.force_collectives", "nys.force_qr", "dist.nb"};
 
@@ -145,12 +144,6 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
   if (ctx->h_coll) hipHostFree(ctx->h_coll);
-  for (int i = 0; i < 8; ++i)
-    if (ctx->pool[i]) hipStreamDestroy(ctx->pool[i]);
-  for (int i = 0; i < 4; ++i)
-    if (ctx->ev_pool[i]) hipEventDestroy(ctx->ev_pool[i]);
-  if (ctx->stream_mm) hipStreamDestroy(ctx->stream_mm);
-  if (ctx->stream_mp) hipStreamDestroy(ctx->stream_mp);
   delete ctx;
   return GDML_OK;
 }
@@ -256,41 +249,6 @@ int phase_end(gdml_ctx* ctx, const char* name) {
   HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->phase_pending = name;
   ctx->phase_pending_launches = ctx->launch_counter;
-  return GDML_OK;
-}
-
-// A pair of streams with complementary CU masks: stream_mp owns `reserve_cus` compute units (mask bits
-// are dealt round-robin over the XCDs, so the first bits are spread evenly), stream_mm the rest.  Used
-// for the late panels of the Cholesky factorisation, where the panel chain is the critical path and
-// its small kernels would otherwise queue behind a full grid of GEMM workgroups.
-int ctx_masked_streams(gdml_ctx* ctx, int reserve_cus) {
-  if (ctx->stream_mm && ctx->masked_cus == reserve_cus) return GDML_OK;
-  if (ctx->stream_mm) {
-    (void)hipStreamDestroy(ctx->stream_mm);
-    (void)hipStreamDestroy(ctx->stream_mp);
-    ctx->stream_mm = ctx->stream_mp = nullptr;
-  }
-  const int ncu = ctx->num_cus;
-  if (reserve_cus <= 0 || reserve_cus >= ncu) return gdml_fail(ctx, GDML_ERR_INVALID, "bad CU reservation");
-  std::vector<uint32_t> mm((ncu + 31) / 32, 0u), mp((ncu + 31) / 32, 0u);
-  for (int c = 0; c < ncu; ++c) (c < reserve_cus ? mp : mm)[c / 32] |= 1u << (c % 32);
-  HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ctx->stream_mm, (uint32_t)mm.size(), mm.data()));
-  HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ctx->stream_mp, (uint32_t)mp.size(), mp.data()));
-  ctx->masked_cus = reserve_cus;
-  return GDML_OK;
-}
-
-// Extra streams for schedule experiments (option chol.panel_stream / chol.syrk_chunks): created in index order
-// on first use, so that index i always maps to the same hardware-queue slot of the process.
-int ctx_pool_stream(gdml_ctx* ctx, int idx, hipStream_t* out) {
-  if (idx < 0 || idx >= 8) return gdml_fail(ctx, GDML_ERR_INVALID, "stream pool index %d", idx);
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  for (int i = 0; i <= idx; ++i)
-    if (!ctx->pool[i]) HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->pool[i], hipStreamNonBlocking, i < 4 ? lo : hi));
-  for (int i = 0; i < 4; ++i)
-    if (!ctx->ev_pool[i]) HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_pool[i], hipEventDisableTiming));
-  *out = ctx->pool[idx];
   return GDML_OK;
 }
 
