@@ -111,6 +111,23 @@ def _worker(rank, world, port, case, rtol, out_dir):
         stub = StubCtx()
         r, w = init_comm_from_torch_distributed(stub)
         assert (r, w) == (rank, world) and stub.args == (bytes([7]) * 128, rank, world)
+        # host-staged backend: the callbacks handed to gdml_comm_init_host complete the collectives in place
+        class HostStub:
+            def comm_init_host(self, r_, w_, allreduce, allgather):
+                self.r, self.w, self.allreduce, self.allgather = r_, w_, allreduce, allgather
+
+        hs = HostStub()
+        r, w = init_comm_from_torch_distributed(hs, backend='host')
+        assert (r, w, hs.r, hs.w) == (rank, world, rank, world)
+        buf = np.arange(6, dtype=np.float64) + 10.0 * rank
+        hs.allreduce(buf)
+        np.testing.assert_array_equal(buf, world * np.arange(6) + 10.0 * sum(range(world)))
+        chunk = 4
+        g_buf = np.full(chunk * world, -1.0)
+        g_buf[rank * chunk:(rank + 1) * chunk] = rank + 0.25 * np.arange(chunk)
+        hs.allgather(g_buf, chunk)
+        np.testing.assert_array_equal(g_buf, np.concatenate([q + 0.25 * np.arange(chunk) for q in range(world)]))
+        np.testing.assert_array_equal(hs._bcast(np.arange(5) + 100 * rank), np.arange(5))  # rank 0's draw everywhere
         np.savez(os.path.join(out_dir, 'r%d.npz' % rank), x=x, info=info, iters=iters, lev=lev)
     finally:
         dist.destroy_process_group()
@@ -148,3 +165,76 @@ def test_shard_range_covers_points():
                 assert 0 <= a <= b <= M and b - a <= per
                 seen += list(range(a, b))
             assert seen == list(range(M))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Distributed Cholesky (csrc/dist_chol.hip): the block-row-cyclic algorithm with real multi-process collectives,
+# NumPy standing in for the per-rank kernels.
+
+
+def _dist_chol_worker(rank, world, port, case, nb, out_dir):
+    import scipy.linalg as sla
+
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = dict(np.load(os.path.join(GOLDEN, case + '.npz')))
+        lam = float(g['lam'])
+        n = g['K'].shape[0] - (g['R_train'].shape[0] if bool(g['use_E_cstr']) else 0)
+        A_full = -g['K'][:n, :n] + lam * np.eye(n)
+        y = g['y'][:n]
+        nblk = -(-n // nb)
+        rows_of = lambda b: min(nb, n - b * nb)
+        mine = [b for b in range(nblk) if b % world == rank]
+        # local share: my row blocks (lower part only is ever read) + the replicated right-hand-side row
+        Aloc = {b: np.tril(A_full)[b * nb:b * nb + rows_of(b)].copy() for b in mine}
+        rhs = y.copy()
+        for k in range(nblk):
+            k0, w = k * nb, rows_of(k)
+            Lkk = np.zeros((nb, nb))
+            if k % world == rank:
+                Lkk[:w, :w] = np.linalg.cholesky(np.tril(Aloc[k][:, k0:k0 + w]) + np.tril(Aloc[k][:, k0:k0 + w], -1).T)
+                Aloc[k][:, k0:k0 + w] = Lkk[:w, :w]
+            Lkk = _allreduce(Lkk)[:w, :w]  # broadcast of the factored block
+            below = [b for b in mine if b > k]
+            for b in below:  # row-local solve
+                Aloc[b][:, k0:k0 + w] = sla.solve_triangular(Lkk, Aloc[b][:, k0:k0 + w].T, lower=True).T
+            rhs[k0:k0 + w] = sla.solve_triangular(Lkk, rhs[k0:k0 + w], lower=True)
+            t0 = k0 + w
+            if t0 >= n:
+                break
+            # gather the panel rows of all ranks in global order
+            P = np.zeros((n - t0, w))
+            for b in below:
+                P[b * nb - t0:b * nb - t0 + rows_of(b)] = Aloc[b][:, k0:k0 + w]
+            P = _allreduce(P)  # (the library all-gathers equal chunks and unpacks; the sum of disjoint rows is the same)
+            for b in below:  # trailing update of my rows: columns t0 .. end of the block's diagonal
+                hi = b * nb + rows_of(b)
+                Aloc[b][:, t0:hi] -= Aloc[b][:, k0:k0 + w] @ P[:hi - t0].T
+            rhs[t0:] -= P @ rhs[k0:k0 + w]
+        # backward substitution
+        acc, x = np.zeros(n), np.zeros(n)
+        for k in range(nblk - 1, -1, -1):
+            k0, w = k * nb, rows_of(k)
+            s_blk = _allreduce(acc[k0:k0 + w].copy())
+            if k % world == rank:
+                Lkk = np.tril(Aloc[k][:, k0:k0 + w])
+                x[k0:k0 + w] = sla.solve_triangular(Lkk, rhs[k0:k0 + w] - s_blk, lower=True, trans='T')
+                acc[:k0] += Aloc[k][:, :k0].T @ x[k0:k0 + w]
+        x = _allreduce(x)
+        np.savez(os.path.join(out_dir, 'c%d.npz' % rank), x=x)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case,world,nb', [('n6_p1', 2, 32), ('n9_p1', 3, 64), ('n5_p4', 2, 48)])
+def test_block_row_cyclic_cholesky_matches_direct_solve(tmp_path, case, world, nb):
+    mp.spawn(_dist_chol_worker, args=(world, _free_port(), case, nb, str(tmp_path)), nprocs=world, join=True)
+    g = dict(np.load(os.path.join(GOLDEN, case + '.npz')))
+    lam = float(g['lam'])
+    n = g['K'].shape[0]
+    A = -g['K'] + lam * np.eye(n)
+    for r in range(world):
+        x = np.load(os.path.join(str(tmp_path), 'c%d.npz' % r))['x']
+        assert np.linalg.norm(A @ x - g['y']) <= 1e-9 * np.linalg.norm(g['y'])
