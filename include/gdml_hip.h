@@ -82,6 +82,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  * library reads no environment variables except GDML_OPTIONS="key=value,..." (applied at gdml_ctx_create).
  *   asm.wave (1)          register-resident assembly kernel for P = 1, N <= 21 (0: LDS kernel)
  *   asm.lower (1)         analytic path: assemble only blocks on/below the diagonal, as -K + lam I
+ *   asm.strip (1)         64-column-strip assembly kernel (full-line stores) for P = 1, 11 <= N <= 21, all columns
+ *   asm.i_chunk (32)      row points walked by one wavefront of the strip kernel
  *   asm.threads, asm.ib, asm.minw, asm.gj_global, asm.j_chunk, asm.debug   LDS-kernel shape / ablations
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
  *   chol.nb (512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),

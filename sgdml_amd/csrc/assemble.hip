@@ -747,6 +747,8 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
       rc = GDML_OK;
     else if (lower_A && !assemble_wave_applicable(ctx))
       rc = assemble_cyclic_launch(ctx, sig, lam, ctx->K, ld, 1, 0, 512);
+    else if (dense && !use_E_cstr && i_beg == 0 && i_end == M && assemble_strip_applicable(ctx))
+      rc = assemble_strip_launch(ctx, sig, ctx->K, ld, lower_A ? 1 : 0, lam);
     else if (assemble_wave_applicable(ctx))
       rc = assemble_wave_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, ctx->K, ld, i_beg, i_end,
                                 lower_A ? 1 : 0, lam);

@@ -43,6 +43,7 @@ struct TrainSet {
   int32_t* pinv = nullptr;   // (P,N)    inverse atom permutations
   double* XF = nullptr;      // (M,N,N)   dense x[pair(b,m)] table, m-major (assemble_wave.hip)
   double* GD = nullptr;      // (M,N,N,3) dense G(b,m) table, m-major
+  double* TS = nullptr;      // (M,pitch) packed per-point image [GD | XF | x | 0-pad] staged by assemble_strip.hip
   std::vector<int32_t> h_tp, h_perm, h_pinv;
 };
 
@@ -208,6 +209,8 @@ int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count);
 void comm_destroy(gdml_ctx* ctx);
 static inline bool comm_active(const gdml_ctx* ctx) { return (ctx->comm || ctx->host_allreduce) && !ctx->virtual_rank; }
 bool assemble_wave_applicable(const gdml_ctx* ctx);
+bool assemble_strip_applicable(const gdml_ctx* ctx);
+int assemble_strip_launch(gdml_ctx* ctx, double sig, double* K, int64_t ld, int lower, double lam);
 int assemble_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int64_t ld, int cyc_W, int cyc_rank,
                            int cyc_nb);
 int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist,

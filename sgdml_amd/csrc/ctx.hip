@@ -26,7 +26,7 @@ extern "C" int gdml_abi_version(void) { return 2; }
 // environment variable the library looks at is GDML_OPTIONS="key=value,key=value", applied once when
 // a context is created (lab convenience for the probes under tools/).
 static const char* kKnownOptions[] = {
-    "asm.wave", "asm.threads", "asm.ib", "asm.minw", "asm.gj_global", "asm.j_chunk", "asm.debug", "asm.lower",
+    "asm.wave", "asm.threads", "asm.ib", "asm.minw", "asm.gj_global", "asm.j_chunk", "asm.debug", "asm.lower", "asm.strip", "asm.i_chunk",
     "gemm.debug", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
     "chol.fused_min_rows",
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",

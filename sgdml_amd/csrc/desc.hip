@@ -175,7 +175,8 @@ extern "C" int gdml_train_upload(gdml_ctx* ctx, const double* R_desc, const doub
   GDML_TRY(ctx_free(ctx, ts.pinv));
   GDML_TRY(ctx_free(ctx, ts.XF));
   GDML_TRY(ctx_free(ctx, ts.GD));
-  ts.XF = ts.GD = nullptr;
+  GDML_TRY(ctx_free(ctx, ts.TS));
+  ts.XF = ts.GD = ts.TS = nullptr;
   ts.x = ts.g = nullptr;
   ts.tp = ts.perm = ts.pinv = nullptr;
   ts.M = M; ts.N = N; ts.D = D; ts.P = P;

@@ -799,6 +799,34 @@ def test_assemble_A_lower_form(ctx_factory, N, M, perms):
     assert np.abs(a1 - a2).max() <= 1e-6 * np.abs(a2).max()
 
 
+@pytest.mark.parametrize('N,M', [(21, 37), (20, 13), (16, 19), (12, 30), (11, 29)])
+def test_assemble_strip_kernel(ctx_factory, N, M):
+    """assemble_strip.hip (64-column strips, 11 <= N <= 21, identity permutation): the full K and the lower form of A
+    against the oracle, and against the block-per-wavefront kernel (asm.strip = 0).  The sizes give strips that
+    straddle two (N = 21) and three column blocks, a ragged last strip and more than one row chunk."""
+    ds = orc.synth_dataset(N, M, seed=3 * N + M, jitter=0.25)
+    xo, go = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    sig, lam = 17.0, 1e-7
+    Ko = orc.assemble_K(xo, go, orc.tril_perms_lin_from_tril_perms(tp), sig)
+    n, N3 = Ko.shape[0], 3 * N
+    res = {}
+    for strip in (1, 0):
+        c = ctx_factory()
+        c.set_option('asm.strip', strip)
+        c.set_option('asm.i_chunk', 8)
+        c.train_upload(xo, go, tp)
+        res[strip, 'K'] = c.assemble_K(sig, False, to_host=True)
+        c.assemble_K(sig, False, alloc_extra_rows=1, for_cholesky=lam)
+        res[strip, 'A'] = c.K_to_host()[:n]
+    scale = np.abs(Ko).max()
+    blk_lower = np.kron(np.tril(np.ones((M, M))), np.ones((N3, N3))).astype(bool)
+    assert np.abs(res[1, 'K'] - Ko).max() <= 1e-12 * scale
+    assert np.abs((res[1, 'A'] - (-Ko + lam * np.eye(n)))[blk_lower]).max() <= 1e-12 * scale
+    assert np.abs(res[1, 'K'] - res[0, 'K']).max() <= 1e-13 * scale
+    assert np.abs((res[1, 'A'] - res[0, 'A'])[blk_lower]).max() <= 1e-13 * scale
+
+
 @pytest.mark.parametrize('n_atoms,n_train,n_query,n_perms,with_aE', [
     (24, 40, 300, 1, False),   # D = 276: first size past the register-resident MFMA kernel
     (26, 30, 257, 2, True),    # odd D (325), permutations, energy-constraint terms, ragged query tile

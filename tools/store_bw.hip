@@ -76,6 +76,26 @@ __global__ void row8_kernel(double* K, int64_t ld, int64_t n) {
   int64_t r = blockIdx.x; double* row = K + r * ld;
   for (int64_t c = threadIdx.x; c < n; c += blockDim.x) row[c] = 1.0;
 }
+// mode 5 (round 2): 64-column STRIPS.  Wavefront = 64 (or 128 with 16-byte stores) consecutive global columns, walks
+// ichunk row points x N3 rows; W wavefronts of a workgroup own adjacent strips (W*512 contiguous bytes per matrix row),
+// optionally in lockstep per row point; xcd = 1 places consecutive workgroups of a row chunk on one XCD.
+template <int VW>
+__global__ void strip_kernel(double* K, int64_t ld, int64_t n, int N3, int M, int ichunk, int sync, int xcd, int64_t nsg) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+  int64_t b = blockIdx.x, sg, iy;
+  if (xcd) { int64_t x = b & 7, l = b >> 3; int64_t per = (nsg + 7) / 8; sg = x * per + (l % per); iy = l / per; if (sg >= nsg) return; }
+  else { sg = b % nsg; iy = b / nsg; }
+  int64_t c = ((sg * W + wave) * 64 + lane) * VW;
+  int64_t i0 = iy * ichunk;
+  for (int64_t i = i0; i < i0 + ichunk && i < M; ++i) {
+    double* dst = K + (i * N3) * ld + c;
+    if (c < n)
+      for (int r = 0; r < N3; ++r, dst += ld) {
+        if (VW == 1) *dst = (double)lane; else { d2 v = {1.0, 2.0}; *reinterpret_cast<d2*>(dst) = v; }
+      }
+    if (sync) __syncthreads();
+  }
+}
 #define T(name, call) do { hipEventRecord(a); call; hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b); printf("%-28s: %.2f ms  %.0f GB/s\n", name, ms, gb / ms * 1e3); } while (0)
 int main() {
   int N3 = 63, M = 1000; int64_t n = (int64_t)N3 * M, ld = (n + 15) / 16 * 16;
@@ -95,6 +115,15 @@ int main() {
       char nm[64]; int jchunk = 64; int64_t nch = (M + jchunk - 1) / jchunk;
       snprintf(nm, 64, "WG/i, wave/j, W=%d sync=%d", W, sy);
       T(nm, (seg_wavecols_kernel<<<dim3((unsigned)(nch * M)), 64 * W>>>(K, ld, N3, M, jchunk, sy)));
+    }
+    for (int vw = 1; vw <= 2; ++vw) for (int W = 1; W <= 16; W *= 2) for (int sy = 0; sy < 2; ++sy) for (int xc = 0; xc < 2; ++xc) {
+      if (W == 1 && sy) continue;
+      if (rep == 0) continue;
+      char nm[64]; int64_t nsg = (n + 64 * vw * W - 1) / (64 * vw * W); int64_t per = (nsg + 7) / 8;
+      int64_t nb = xc ? per * 8 * ny : nsg * ny;
+      snprintf(nm, 64, "strip %dB W=%d sync=%d xcd=%d", 8 * vw, W, sy, xc);
+      if (vw == 1) T(nm, (strip_kernel<1><<<dim3((unsigned)nb), 64 * W>>>(K, ld, n, N3, M, ic, sy, xc, nsg)));
+      else T(nm, (strip_kernel<2><<<dim3((unsigned)nb), 64 * W>>>(K, ld, n, N3, M, ic, sy, xc, nsg)));
     }
     for (int J = 1; J <= 8; J *= 2) {
       char nm[64]; int jchunk = 40; int64_t nch = (M + jchunk - 1) / jchunk;
