@@ -88,9 +88,10 @@ __global__ void __launch_bounds__(64 * STRIP_W, 2) assemble_strip_kernel(StripAr
   const int a_r = lane < N3 ? lane / 3 : 0;  // row-role atom (lane = 3 a + al)
   const int q0 = (int)(j0 - jw0);            // wave-uniform index of the strip's first column point in XFj / xjs
 
-  int64_t i_lo = (int64_t)blockIdx.y * A.i_chunk;
+  // row chunks are counted from the workgroup's diagonal point in the lower form: every live workgroup walks a full
+  // chunk, and the dispatch order (chunk-major) leaves the sparsely populated chunk rows for the end of the launch
+  const int64_t i_lo = (A.lower ? jw0 : 0) + (int64_t)blockIdx.y * A.i_chunk;
   const int64_t i_hi = (i_lo + A.i_chunk < A.M) ? i_lo + A.i_chunk : A.M;
-  if (A.lower && i_lo < jw0) i_lo = jw0;
   if (i_lo >= i_hi) return;
 
   const double sig = A.sig, inv_sig = 1.0 / sig;

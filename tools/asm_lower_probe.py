@@ -13,15 +13,20 @@ for spec in (sys.argv[1:] or ['-']):
     ctx = _lib.Context(0)
     xd, gd = ctx.desc_from_R(R.reshape(M, -1), N)
     ctx.train_upload(xd, gd, tp)
+    full = False
     if spec != '-':
         for kv in spec.split(','):
             k, v = kv.split('=')
-            ctx.set_option(k, float(v))
+            if k == 'full':   # pseudo-option: the full un-negated K (gdml_assemble_K) instead of the lower form
+                full = bool(int(v))
+            else:
+                ctx.set_option(k, float(v))
     ts = []
-    for rep in range(6):
-        ctx.assemble_K(20.0, False, alloc_extra_rows=1, for_cholesky=1e-10)
+    for rep in range(14):
+        ctx.assemble_K(20.0, False, alloc_extra_rows=1, for_cholesky=None if full else 1e-10)
         ts.append(ctx.phase_ms('assemble')[0])
     n = M * 3 * N
-    by = 8.0 * 0.5 * M * (M + 1) * (3 * N) ** 2
-    print('%-28s assemble %s ms -> best %.0f GB/s (%.3f of 8 TB/s)' % (spec, ' '.join('%.2f' % t for t in ts), by / min(ts) / 1e6, by / min(ts) / 1e6 / 8000), flush=True)
+    by = 8.0 * (M * M if full else 0.5 * M * (M + 1)) * (3 * N) ** 2
+    med = float(np.median(ts[6:]))
+    print('%-28s assemble %s ms -> median of last 8 %.2f ms = %.0f GB/s (%.3f of 8 TB/s)' % (spec, ' '.join('%.2f' % t for t in ts), med, by / med / 1e6, by / med / 1e6 / 8000), flush=True)
     ctx.close()
