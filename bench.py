@@ -453,7 +453,7 @@ def run_analytic(args):
         if a_ms > 0:
             ach = a_by / (a_ms * 1e-3) / 1e9
             tr = traffic.get('assemble', {})
-            extra['roofline_assemble'] = {'kernel': 'assemble_wave_kernel (-K + lam I, blocks on/below the diagonal)',
+            extra['roofline_assemble'] = {'kernel': 'assemble_strip_kernel (-K + lam I, blocks on/below the diagonal, 64-column strips)',
                                           'bound': 'hbm', 'achieved': ach,
                                           'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                                           'traffic': tr.get('hbm_bytes_per_launch'), 'traffic_source': tr.get('source'),

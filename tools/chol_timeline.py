@@ -8,7 +8,7 @@ cur = db.cursor()
 rows = cur.execute("select name, start, end from kernels order by start").fetchall()
 short = lambda n: n.split('(')[0].replace('void ', '')
 # the last factorisation: from the last assembly kernel to the first triangular-solve kernel after it
-idx = [i for i, r in enumerate(rows) if 'assemble_wave_kernel' in r[0] or r[0].startswith('negate_shift')]
+idx = [i for i, r in enumerate(rows) if 'assemble_wave_kernel' in r[0] or 'assemble_strip_kernel' in r[0] or r[0].startswith('negate_shift')]
 i0 = idx[-1]
 i1 = next((i for i in range(i0, len(rows)) if short(rows[i][0]).startswith('trsv')), len(rows))
 seg = [r for r in rows[i0 + 1:i1] if not r[0].startswith('__amd_rocclr')]

@@ -37,8 +37,8 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 0, 0])
     print('%-40s %8d %16.3f %16.3f %14.4f' % (k[:40], n, rd / 1e9, wr / 1e9, (rd + wr) / max(1, n) / 1e9))
     out[k] = {'launches': n, 'read_bytes': rd, 'written_bytes': wr, 'hbm_bytes_per_launch': (rd + wr) / max(1, n)}
 res = {}
-for key, pat in (('gemm_nt_sub', 'gemm_nt_sub'), ('assemble', 'assemble_wave_kernel')):
-    sel = [v for k, v in out.items() if k.startswith(pat)]  # all instantiations (plain + fused diagonal-block launch)
+for key, pat in (('gemm_nt_sub', 'gemm_nt_sub'), ('assemble', 'assemble_strip_kernel')):
+    sel = [v for k, v in out.items() if pat in k]  # all instantiations (plain + fused diagonal-block launch)
     if sel:
         n = sum(v['launches'] for v in sel)
         rd, wr = sum(v['read_bytes'] for v in sel), sum(v['written_bytes'] for v in sel)
