@@ -1130,61 +1130,82 @@ static int chol_fwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld
 // restores the per-block launches).  Left-looking: the workgroup that owns 64-block k accumulates
 //   s = sum_{c > k} L[c,k]^T x_c      (rows below the block, 512-byte row segments, 4 wavefronts over the blocks c)
 // as the x_c become available, then solves the transposed diagonal block and publishes x_k.  Blocks are
-// owned cyclically (from the bottom) by one workgroup per CU, all resident at once; availability is a
-// single counter `done` (= number of finished blocks from the bottom) in global memory, advanced with a
-// release after the solution block has been written, read with an acquire by the consumers (x crosses
+// owned cyclically (from the bottom) by one workgroup per CU, all resident at once.  The solution vector itself is the
+// availability signal: it is pre-filled with a NaN sentinel, x_k is published with relaxed agent-scope 8-byte stores and
+// the consumers poll the elements they need (x crosses
 // XCDs, i.e. L2s).  Blocks are dealt round-robin, so a workgroup also waits for blocks of workgroups with a HIGHER
 // index (workgroup 0 at round 2 needs the last workgroup's block of round 1): all min(nbk, CUs) workgroups must
 // be resident at once.  One workgroup per CU on an otherwise idle stream satisfies that; where it does not (GPU
 // shared with another process) the bounded spins give up, `err` is set and the host falls back to the
 // per-block launches below.
 // ------------------------------------------------------------------------------------------
+// Sentinel of "not yet solved" in the solution vector of the persistent backward substitution: a quiet NaN with a
+// payload no arithmetic produces (hardware NaNs are 0x7FF8000000000000 / 0xFFF8...).
+#define TRSV_PENDING 0x7FF8A5A5C3C30001ull
+
+__global__ void __launch_bounds__(256) trsv_fill_pending_kernel(unsigned long long* __restrict__ x, int64_t n) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) x[t] = TRSV_PENDING;
+}
+
 __global__ void __launch_bounds__(256) trsv_bwd_persist_kernel(const double* __restrict__ L, int64_t ld,
                                                                int64_t n, int nbk, const double* __restrict__ z,
-                                                               double* x, int* done, int* err) {
+                                                               double* x, int* err) {
   __shared__ __attribute__((aligned(16))) double Ls[64 * 65];
   __shared__ double part[4][64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned long long* xb = reinterpret_cast<unsigned long long*>(x);
   for (int kk = blockIdx.x; kk < nbk; kk += gridDim.x) {  // kk counts blocks from the bottom
     const int k = nbk - 1 - kk;
     const int64_t c0 = (int64_t)k * 64;
     const int wk = (int)((n - c0 < 64) ? n - c0 : 64);
     load_block64(L, ld, c0, wk, Ls, tid, 256);  // diagonal block (independent of x): overlaps the waiting
+    __syncthreads();
+    const double rdiag = 1.0 / Ls[lane * 65 + lane];  // reciprocal pivots off the critical path (identity on padding)
     double acc = 0.0;
     for (int cc = wv; cc < kk; cc += 4) {  // blocks below, bottom first; this wavefront takes every 4th
       const int c = nbk - 1 - cc;
+      const int64_t r0 = (int64_t)c * 64;
+      const int rows = (int)((n - r0 < 64) ? n - r0 : 64);
+      // the L block does not depend on x: its 64 row segments are in flight while the wavefront waits for x_c
+      const double* Lp = L + r0 * ld + c0 + (lane < wk ? lane : 0);
+      double lreg[64];
+#pragma unroll
+      for (int i = 0; i < 64; ++i) lreg[i] = (i < rows) ? Lp[(int64_t)i * ld] : 0.0;
+      // x_c is published element by element (relaxed agent-scope stores of the 8-byte values over the sentinel): the
+      // consumer polls the data itself -- one memory round trip, no separate flag, no fences
+      unsigned long long xv = 0;
       int spins = 0;
-      while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= cc) {
-        __builtin_amdgcn_s_sleep(2);
+      for (;;) {
+        xv = (lane < rows) ? __hip_atomic_load(xb + r0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        if (!__any(xv == TRSV_PENDING)) break;
+        __builtin_amdgcn_s_sleep(1);
         if (++spins > (1 << 26)) {  // ~1 min: only reachable if the GPU is shared with another process for that long
           if (lane == 0) atomicExch(err, 1);
+          xv = 0;
           break;
         }
       }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);  // agent scope: x_c written by another XCD is visible now
-      const int64_t r0 = (int64_t)c * 64;
-      const int rows = (int)((n - r0 < 64) ? n - r0 : 64);
-      const double xv = (lane < rows) ? __hip_atomic_load(x + r0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      const double* Lp = L + r0 * ld + c0 + lane;
-      if (rows == 64 && lane < wk) {
-#pragma unroll 16
-        for (int i = 0; i < 64; ++i) acc += Lp[(int64_t)i * ld] * __shfl(xv, i, 64);
-      } else {
-        for (int i = 0; i < rows; ++i) {
-          const double xr = __shfl(xv, i, 64);
-          if (lane < wk) acc += Lp[(int64_t)i * ld] * xr;
-        }
-      }
+      const double xd = __longlong_as_double((long long)xv);
+#pragma unroll
+      for (int i = 0; i < 64; ++i) acc += lreg[i] * __shfl(xd, i, 64);
     }
-    part[wv][lane] = acc;
+    part[wv][lane] = (lane < wk) ? acc : 0.0;
     __syncthreads();
     if (wv == 0) {
       const double s = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-      const double bi = lane < wk ? z[c0 + lane] - s : 0.0;
-      const double xi = tri_solve64_wave<true>(Ls, bi, lane);
-      if (lane < wk) __hip_atomic_store(x + c0 + lane, xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __atomic_thread_fence(__ATOMIC_RELEASE);
-      if (lane == 0) __hip_atomic_store(done, kk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      double bi = lane < wk ? z[c0 + lane] - s : 0.0;
+      // transposed 64 x 64 solve, row r of L broadcast from lane r: x_r = b_r / L_rr; b_c -= L_rc x_r (c < r)
+      double sol = 0.0;
+#pragma unroll
+      for (int r = 63; r >= 0; --r) {
+        const double xr = __shfl(bi * rdiag, r, 64);
+        if (lane == r) sol = xr;
+        bi -= Ls[r * 65 + lane] * xr;
+      }
+      if (lane < wk)
+        __hip_atomic_store(xb + c0 + lane, (unsigned long long)__double_as_longlong(sol), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
@@ -1195,12 +1216,12 @@ int chol_bwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, doubl
   const int persist = ctx_opt_i(ctx, "trsv.persist", 1);
   if (persist && n >= 2048) {
     const int nbk = (int)((n + 63) / 64);
-    int* done = ctx->d_info + 4;
     int* err = ctx->d_info + 5;
-    HIP_CHECK(ctx, hipMemsetAsync(done, 0, 2 * sizeof(int), ctx->stream));
+    HIP_CHECK(ctx, hipMemsetAsync(err, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(trsv_fill_pending_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<unsigned long long*>(d_x), n);
     const int grid = nbk < ctx->num_cus ? nbk : ctx->num_cus;  // one workgroup per CU, all resident
-    hipLaunchKernelGGL(trsv_bwd_persist_kernel, dim3(grid), dim3(256), 0, ctx->stream, L, ld, n, nbk, d_z, d_x,
-                       done, err);
+    hipLaunchKernelGGL(trsv_bwd_persist_kernel, dim3(grid), dim3(256), 0, ctx->stream, L, ld, n, nbk, d_z, d_x, err);
     ctx->launch_counter++;
     int h_err = 0;
     HIP_CHECK(ctx, hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
