@@ -299,19 +299,24 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   const int64_t n_super_all = lower ? sm * (sm + 1) / 2 : sm * sn;
   g.s_begin = (int64_t)(f0 * (double)n_super_all);
   g.n_super = (f1 >= 1.0) ? n_super_all : (int64_t)(f1 * (double)n_super_all);
-  if (g.n_super <= g.s_begin) return GDML_OK;
+  const bool has_diag = diag && diag->A;
+  if (g.n_super <= g.s_begin) {
+    if (!has_diag) return GDML_OK;
+    g.n_super = g.s_begin;  // empty tile range: the launch still carries the diagonal-block workgroup
+  }
   int64_t groups = (g.n_super - g.s_begin + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
   int64_t blocks = groups * 512;
   const int slot = (timed && st == (ctx->kt_stream ? ctx->kt_stream : ctx->stream)) ? ktime_begin(ctx) : -1;
-  if (diag && diag->A) {
+  if (has_diag) {
     g.diagA = diag->A; g.diag_nbw = diag->nbw; g.diag_off = diag->off; g.diag_info = ctx->d_info;
     hipLaunchKernelGGL(gemm_nt_sub_diag_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, st, g);
   } else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL(gemm_nt_sub_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+  const double part = (double)(g.n_super - g.s_begin) / (double)n_super_all;  // share of the tile list in this launch
   ktime_end(ctx, slot, "gemm_nt_sub",
-            lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K);
+            part * (lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K));
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;
@@ -942,17 +947,46 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
   if (ctx_opt_i(ctx, "chol.fused_diag", 1) && lookahead) {
     hipStream_t st = ctx->stream;
     const int64_t min_rows = (int64_t)ctx_opt(ctx, "chol.fused_min_rows", 12288);
-    GDML_TRY(panel_factor(ctx, st, A, n_rows, ld, 0, n < NB ? n : NB));
-    for (int64_t k0 = 0; k0 < n; k0 += NB) {
-      const int64_t nb = (n - k0 < NB) ? n - k0 : NB;
+    // Panel PAIRS: while the trailing matrix is large, two NB-wide panels a | b form an outer panel of OB = 2 NB columns
+    // and the bulk of the trailing update runs with K = OB, which halves the C read-modify-write traffic per flop of the
+    // SYRK (its epilogue is ~6 % of the launch at K = 512).  The bulk launch is split in two halves of its tile list so
+    // that each of the two NB x NB diagonal blocks still has a long launch to hide behind:
+    //   GEMM1 (columns of a | b, K = OB)  ->  bulk half 1 + [block a]  ->  solve rows below a  ->  K = NB GEMM onto b's columns
+    //   ->  bulk half 2 + [block b]  ->  solve rows below b.
+    // Once the bulk gets too short (n - t1 < chol.outer_min_rows) new panels are single NB-wide ones again.
+    int64_t OB = (int64_t)ctx_opt(ctx, "chol.outer", 1024);
+    if (OB != 2 * NB) OB = NB;
+    const int64_t outer_min_rows = (int64_t)ctx_opt(ctx, "chol.outer_min_rows", 16384);
+    auto width_at = [&](int64_t c0) -> int64_t {  // width of the panel that starts at column c0
+      const int64_t w = (OB > NB && n - (c0 + OB) >= outer_min_rows) ? OB : NB;
+      return (n - c0 < w) ? n - c0 : w;
+    };
+    // first panel: always one level (nothing to hide its diagonal block behind)
+    int64_t k0 = 0, nb = (n < NB) ? n : NB;
+    GDML_TRY(panel_factor(ctx, st, A, n_rows, ld, 0, nb));
+    for (;;) {
       const int64_t t0 = k0 + nb;
       if (t0 >= n) break;
-      const int64_t nb2 = (n - t0 < NB) ? n - t0 : NB;
+      const int64_t nb2 = width_at(t0);
       const int64_t t1 = t0 + nb2;
       const double* P = A + t0 * ld + k0;
       GDML_TRY(launch_gemm_nt_sub(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, nb2, nb, 0));
       const bool fuse = (nb2 % 64 == 0) && (n - t1 >= min_rows) && (n_rows - t1 > 0);
-      if (fuse) {
+      if (fuse && nb2 == 2 * NB) {
+        const double* P1 = A + t1 * ld + k0;
+        const int64_t ta = t0 + NB;  // first row / column of b
+        DiagJob dj;
+        dj.A = A + t0 * ld + t0; dj.nbw = (int)(NB / 64); dj.off = t0;
+        GDML_TRY(launch_gemm_nt_sub_part(ctx, st, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1, 0.0,
+                                         0.5, true, &dj));
+        double* Xa = A + ta * ld + t0;  // rows below block a (they include b's rows of the outer panel)
+        GDML_TRY(launch_panel_trsm(ctx, st, A + t0 * ld + t0, Xa, ld, (int)NB, n_rows - ta));
+        GDML_TRY(launch_gemm_nt_sub(ctx, st, Xa, ld, Xa, ld, A + ta * ld + ta, ld, n_rows - ta, NB, NB, 0));
+        dj.A = A + ta * ld + ta; dj.off = ta;
+        GDML_TRY(launch_gemm_nt_sub_part(ctx, st, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1, 0.5,
+                                         1.0, true, &dj));
+        GDML_TRY(launch_panel_trsm(ctx, st, A + ta * ld + ta, A + t1 * ld + ta, ld, (int)NB, n_rows - t1));
+      } else if (fuse) {
         DiagJob dj;
         dj.A = A + t0 * ld + t0;
         dj.nbw = (int)(nb2 / 64);
@@ -968,6 +1002,8 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
           GDML_TRY(launch_gemm_nt_sub(ctx, st, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1));
         }
       }
+      k0 = t0;
+      nb = nb2;
     }
     HIP_CHECK(ctx, hipGetLastError());
     int info = 0;

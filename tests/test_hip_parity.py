@@ -242,6 +242,45 @@ def test_cholesky_multi_panel(ctx, n):
     assert np.linalg.norm(A @ x - y) <= 1e-11 * np.linalg.norm(y)
 
 
+@pytest.mark.parametrize('opts', [
+    {'chol.outer': 1024, 'chol.outer_min_rows': 512, 'chol.fused_min_rows': 256},   # panel pairs (K = 1024 bulk in two halves)
+    {'chol.outer': 512, 'chol.fused_min_rows': 256},                                # one-level fused schedule
+    {'chol.fused_diag': 0},                                                         # look-ahead schedule on two streams
+])
+def test_cholesky_schedules_small(ctx_factory, opts):
+    """The schedules that only engage on large matrices by default (panel pairs with a K = 1024 trailing update split in two halves, each hiding one
+    diagonal block; the one-level fused schedule), forced on a 3.3k matrix, and the two-stream
+    fallback: same factor as LAPACK, the right-hand side row rides through."""
+    import ctypes as C
+
+    import scipy.linalg as sla
+    c = ctx_factory()
+    for k, v in opts.items():
+        c.set_option(k, v)
+    M = 556  # 2 atoms: 3N = 6 -> n = 3336 = 6.5 inner panels, ragged last block
+    ds = orc.synth_dataset(2, M, seed=2)
+    xo, go = orc.desc_from_R(ds['R'].reshape(M, -1))
+    c.train_upload(xo, go, np.zeros((1, 1), dtype=np.int64))
+    c.assemble_K(10.0, False, alloc_extra_rows=1)
+    n = c.K_shape()[0]
+    rs = np.random.RandomState(7)
+    B = rs.normal(size=(n, n + 30))
+    A = B @ B.T / n + 0.5 * np.eye(n)
+    p, ld = C.c_void_p(), C.c_int64()
+    c._check(c._lib.gdml_K_dev(c._h, C.byref(p), C.byref(ld)))
+    buf = np.zeros((n + 1, ld.value))
+    buf[:n, :n] = -A
+    c._check(c._lib.gdml_memcpy_h2d(c._h, p, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+    y = rs.normal(size=n)
+    c.chol_set_rhs(y)
+    assert c.chol_factor(0.0) == 0
+    L = np.tril(c.K_to_host()[:n])
+    Lref = sla.cholesky(A, lower=True)
+    assert np.abs(L - Lref).max() <= 1e-11 * np.abs(Lref).max()
+    x = -c.chol_solve(None)
+    assert np.linalg.norm(A @ x - y) <= 1e-11 * np.linalg.norm(y)
+
+
 def test_cholesky_not_pd_reports_lapack_info(ctx):
     import ctypes as C
 
