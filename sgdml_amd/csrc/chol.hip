@@ -65,6 +65,12 @@ struct GemmArgs {
   int64_t diag_off; // global index of its first row (LAPACK info)
   int* diag_info;
   int dbg;          // option gemm.debug: ablation bits: 1 no epilogue, 2 no tile loads, 4 no LDS reads, 8 no barrier
+  // merged trailing update (lower): the first super-tile COLUMN (the next outer panel's own columns) is enumerated
+  // first; the tiles of its leading ready_rows x ready_rows tile block (the diagonal block workgroup 0 is about to
+  // factor) count themselves into *ready when their C tile is stored, workgroup 0 waits for ready_target
+  int col0_first;
+  int* ready;
+  int ready_target, ready_rows;
 };
 
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g);
@@ -238,11 +244,20 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
   if (s >= g.n_super) return;
   int64_t SI, SJ;
   if (g.lower) {
-    // s = SI (SI+1)/2 + SJ
-    SI = (int64_t)((sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
-    while (SI * (SI + 1) / 2 > s) --SI;
-    while ((SI + 1) * (SI + 2) / 2 <= s) ++SI;
-    SJ = s - SI * (SI + 1) / 2;
+    int64_t sr = s, shift = 0;
+    const int64_t sm = (g.tiles_m + 7) / 8;
+    if (g.col0_first) {  // column SJ = 0 (all SI) first, then the lower triangle of the remaining sm - 1 super rows
+      if (s < sm) { SI = s; SJ = 0; sr = -1; }
+      else { sr = s - sm; shift = 1; }
+    }
+    if (sr >= 0) {
+      // sr = SI (SI+1)/2 + SJ
+      SI = (int64_t)((sqrt(8.0 * (double)sr + 1.0) - 1.0) * 0.5);
+      while (SI * (SI + 1) / 2 > sr) --SI;
+      while ((SI + 1) * (SI + 2) / 2 <= sr) ++SI;
+      SJ = sr - SI * (SI + 1) / 2;
+      SI += shift; SJ += shift;
+    }
   } else {
     SI = s / g.super_n;
     SJ = s - SI * g.super_n;
@@ -261,6 +276,11 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
     gemm_tile_body<true, ABL>(g, lds, row0, col0);
   else
     gemm_tile_body<false, ABL>(g, lds, row0, col0);
+  if (g.ready && ti < g.ready_rows && tj < g.ready_rows) {  // publish the tile (release: every thread's stores, then one count)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(g.ready, 1);
+  }
 }
 
 template <bool ABL>
@@ -276,6 +296,10 @@ struct DiagJob {
   double* A = nullptr;  // top-left of the next panel's diagonal block
   int nbw = 0;
   int64_t off = 0;
+  // merged launch: the block's own tiles are part of this launch (GemmArgs::col0_first); they count into *ready
+  int* ready = nullptr;
+  int ready_target = 0;
+  bool col0_first = false;
 };
 
 static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
@@ -288,6 +312,8 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   g.lower = lower;
   g.diagA = nullptr; g.diag_nbw = 0; g.diag_off = 0; g.diag_info = nullptr;
   g.cyc_W = 0; g.cyc_rank = 0; g.cyc_lb0 = 0; g.cyc_nb = 0; g.cyc_col0 = 0; g.cyc_block_rows = 0;
+  g.col0_first = (diag && diag->col0_first) ? 1 : 0;
+  g.ready = nullptr; g.ready_target = 0; g.ready_rows = 0;
   if (cyc) { g.cyc_W = cyc->W; g.cyc_rank = cyc->rank; g.cyc_lb0 = cyc->lb0; g.cyc_nb = cyc->nb; g.cyc_col0 = cyc->col0; g.cyc_block_rows = cyc->block_rows; }
   g.dbg = ctx_opt_i(ctx, "gemm.debug", 0);
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
@@ -309,6 +335,7 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   const int slot = (timed && st == (ctx->kt_stream ? ctx->kt_stream : ctx->stream)) ? ktime_begin(ctx) : -1;
   if (has_diag) {
     g.diagA = diag->A; g.diag_nbw = diag->nbw; g.diag_off = diag->off; g.diag_info = ctx->d_info;
+    if (diag->ready) { g.ready = diag->ready; g.ready_target = diag->ready_target; g.ready_rows = diag->nbw * 64 / GT; }
     hipLaunchKernelGGL(gemm_nt_sub_diag_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, st, g);
   } else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
@@ -527,6 +554,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
   static_assert(sizeof(double) * 2 * 2 * GT * GPITCH >= sizeof(double) * (2 * 64 * 65 + 64 + 128), "LDS of the diagonal role");
   if (blockIdx.x == 0) {
+    if (g.ready) {  // the block's tiles are computed by workgroups of this launch (dispatched right behind this one)
+      if (threadIdx.x == 0)
+        while (__hip_atomic_load(g.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.ready_target) __builtin_amdgcn_s_sleep(8);
+      __syncthreads();
+      __threadfence();
+    }
     diag_block_role(g.diagA, g.ldc, g.diag_nbw, g.diag_off, g.diag_info, &lds[0][0][0]);
     return;
   }
@@ -717,8 +750,9 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
 #define PT_SP 66   // pitch of the row-major block in LDS (doubles): 16-byte aligned rows, 16-lane b128 reads conflict-free
 #define PT_LP 65   // pitch of L_jj^T
 
+template <bool ABL>
 __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __restrict__ L, int64_t ldl,
-                                                            double* __restrict__ X, int64_t ld, int nbw, int64_t m) {
+                                                            double* __restrict__ X, int64_t ld, int nbw, int64_t m, int dbg) {
   __shared__ __attribute__((aligned(16))) double S[PT_ROWS * PT_SP];
   __shared__ __attribute__((aligned(16))) double Lt[64 * PT_LP];
   __shared__ double rinv[64];
@@ -797,7 +831,7 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
     }
     __syncthreads();
     // (2) substitution: x_c = t_c / L[c][c];  t_k -= x_c L[k][c] for k > c
-    {
+    if (!ABL || !(dbg & 1)) {
       double t[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) t[i] = S[srow * PT_SP + sq + 8 * i];
@@ -822,8 +856,10 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
     }
     __syncthreads();
     // (4) right-looking update of the blocks c > jj this wavefront owns
-    if (blkA > jj && blkA < nbw) update(accA, blkA, jj);
-    if (blkB > jj && blkB < nbw) update(accB, blkB, jj);
+    if (!ABL || !(dbg & 2)) {
+      if (blkA > jj && blkA < nbw) update(accA, blkA, jj);
+      if (blkB > jj && blkB < nbw) update(accB, blkB, jj);
+    }
     __syncthreads();  // S and Lt are rewritten by the next step
   }
 }
@@ -832,8 +868,15 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
 int launch_panel_trsm(gdml_ctx* ctx, hipStream_t st, const double* L, double* X, int64_t ld, int nb, int64_t m,
                       int64_t ldl) {
   if (m <= 0) return GDML_OK;
-  hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, L, ldl > 0 ? ldl : ld, X, ld,
-                     nb / 64, m);
+  const int dbg = ctx_opt_i(ctx, "trsm.debug", 0);  // ablation bits: 1 no substitution, 2 no MFMA update (timing only)
+  const int slot = (st == (ctx->kt_stream ? ctx->kt_stream : ctx->stream)) ? ktime_begin(ctx) : -1;
+  if (dbg)
+    hipLaunchKernelGGL(panel_trsm_kernel<true>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, L, ldl > 0 ? ldl : ld,
+                       X, ld, nb / 64, m, dbg);
+  else
+    hipLaunchKernelGGL(panel_trsm_kernel<false>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, L, ldl > 0 ? ldl : ld,
+                       X, ld, nb / 64, m, 0);
+  ktime_end(ctx, slot, "panel_trsm", (double)m * (double)nb * (double)nb);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;
@@ -963,6 +1006,8 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
     };
     // first panel: always one level (nothing to hide its diagonal block behind)
     int64_t k0 = 0, nb = (n < NB) ? n : NB;
+    int ready_count = 0;  // cumulative target of the tile counter d_info[6]
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info + 6, 0, sizeof(int), ctx->stream));
     GDML_TRY(panel_factor(ctx, st, A, n_rows, ld, 0, nb));
     for (;;) {
       const int64_t t0 = k0 + nb;
@@ -970,9 +1015,34 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
       const int64_t nb2 = width_at(t0);
       const int64_t t1 = t0 + nb2;
       const double* P = A + t0 * ld + k0;
-      GDML_TRY(launch_gemm_nt_sub(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, nb2, nb, 0));
       const bool fuse = (nb2 % 64 == 0) && (n - t1 >= min_rows) && (n_rows - t1 > 0);
-      if (fuse && nb2 == 2 * NB) {
+      const bool merged = fuse && nb2 == 2 * NB && ctx_opt_i(ctx, "chol.merge_gemm1", 1) != 0;
+      if (!merged) GDML_TRY(launch_gemm_nt_sub(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, nb2, nb, 0));
+      if (merged) {
+        // ONE lower SYRK over everything right of the finished panel, in two launches of its super-tile list.  The first
+        // super-tile column is exactly the columns of a | b (2 NB = 8 tiles): it is enumerated first, workgroup 0 of the
+        // first launch waits for the 10 tiles of block a (counter) and factors it while the rest of the launch runs.
+        const int64_t ta = t0 + NB;  // first row / column of b
+        const int64_t sm = (ceil_div(n_rows - t0, GT) + 7) / 8, n_super_all = sm * (sm + 1) / 2;
+        int64_t s_split = n_super_all / 2;
+        if (s_split < sm) s_split = sm;
+        const double fs = ((double)s_split + 0.5) / (double)n_super_all;
+        DiagJob dj;
+        dj.A = A + t0 * ld + t0; dj.nbw = (int)(NB / 64); dj.off = t0;
+        dj.col0_first = true;
+        dj.ready = ctx->d_info + 6;
+        ready_count += (int)((NB / GT) * (NB / GT + 1) / 2);
+        dj.ready_target = ready_count;
+        GDML_TRY(launch_gemm_nt_sub_part(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, n - t0, nb, 1, 0.0, fs, true,
+                                         &dj));
+        double* Xa = A + ta * ld + t0;  // rows below block a (they include b's rows of the outer panel)
+        GDML_TRY(launch_panel_trsm(ctx, st, A + t0 * ld + t0, Xa, ld, (int)NB, n_rows - ta));
+        GDML_TRY(launch_gemm_nt_sub(ctx, st, Xa, ld, Xa, ld, A + ta * ld + ta, ld, n_rows - ta, NB, NB, 0));
+        dj.A = A + ta * ld + ta; dj.off = ta; dj.ready = nullptr;
+        GDML_TRY(launch_gemm_nt_sub_part(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, n - t0, nb, 1, fs, 1.0, true,
+                                         &dj));
+        GDML_TRY(launch_panel_trsm(ctx, st, A + ta * ld + ta, A + t1 * ld + ta, ld, (int)NB, n_rows - t1));
+      } else if (fuse && nb2 == 2 * NB) {
         const double* P1 = A + t1 * ld + k0;
         const int64_t ta = t0 + NB;  // first row / column of b
         DiagJob dj;
