@@ -71,6 +71,14 @@ struct GemmArgs {
   int col0_first;
   int* ready;
   int ready_target, ready_rows;
+  // second, plain (non-symmetric) problem carried by the first tiles2 workgroups of the launch:  C2 -= A2 B2^T,
+  // M2 x N2, depth K2, same leading dimensions (the K = NB update of panel b's columns by panel a); tiles above the
+  // diagonal of its leading N2 x N2 block are skipped; with `ready` set ITS leading tiles are the counted ones
+  const double* A2;
+  const double* B2;
+  double* C2;
+  int64_t M2, N2, K2;
+  int tiles2;
 };
 
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g);
@@ -238,6 +246,27 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 // block index -> tile (XCD-aware 8x8 super tiles: block b runs on XCD b % 8) and the tile's GEMM
 template <bool ABL>
 __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][GT * GPITCH], int64_t b) {
+  if (b < g.tiles2) {  // second problem (workgroup-uniform branch)
+    const int tn2 = (int)((g.N2 + GT - 1) / GT);
+    const int64_t ti = b / tn2, tj = b - ti * tn2;
+    if (ti < tn2 && tj > ti) return;
+    GemmArgs h = g;
+    h.A = g.A2; h.B = g.B2; h.C = g.C2; h.M = g.M2; h.N = g.N2; h.K = g.K2;
+    h.aligned = ((reinterpret_cast<uintptr_t>(g.A2) | reinterpret_cast<uintptr_t>(g.B2)) & 15) == 0 && g.aligned;
+    const int64_t row0 = ti * GT, col0 = tj * GT;
+    const bool full = (row0 + GT <= h.M) && (col0 + GT <= h.N) && ((h.K & (GBK - 1)) == 0) && h.aligned;
+    if (full)
+      gemm_tile_body<true, ABL>(h, lds, row0, col0);
+    else
+      gemm_tile_body<false, ABL>(h, lds, row0, col0);
+    if (g.ready && ti < g.ready_rows && tj < g.ready_rows) {
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) atomicAdd(g.ready, 1);
+    }
+    return;
+  }
+  b -= g.tiles2;
   const int64_t xcd = b & 7, loc = b >> 3;
   const int64_t s = g.s_begin + (loc >> 6) * 8 + xcd;
   const int within = (int)(loc & 63);
@@ -276,7 +305,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
     gemm_tile_body<true, ABL>(g, lds, row0, col0);
   else
     gemm_tile_body<false, ABL>(g, lds, row0, col0);
-  if (g.ready && ti < g.ready_rows && tj < g.ready_rows) {  // publish the tile (release: every thread's stores, then one count)
+  if (g.ready && g.tiles2 == 0 && ti < g.ready_rows && tj < g.ready_rows) {  // publish the tile (release: every thread's stores, then one count)
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(g.ready, 1);
@@ -300,6 +329,11 @@ struct DiagJob {
   int* ready = nullptr;
   int ready_target = 0;
   bool col0_first = false;
+  // second problem of the launch (GemmArgs::A2 ...)
+  const double* A2 = nullptr;
+  const double* B2 = nullptr;
+  double* C2 = nullptr;
+  int64_t M2 = 0, N2 = 0, K2 = 0;
 };
 
 static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
@@ -314,6 +348,7 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   g.cyc_W = 0; g.cyc_rank = 0; g.cyc_lb0 = 0; g.cyc_nb = 0; g.cyc_col0 = 0; g.cyc_block_rows = 0;
   g.col0_first = (diag && diag->col0_first) ? 1 : 0;
   g.ready = nullptr; g.ready_target = 0; g.ready_rows = 0;
+  g.A2 = g.B2 = nullptr; g.C2 = nullptr; g.M2 = g.N2 = g.K2 = 0; g.tiles2 = 0;
   if (cyc) { g.cyc_W = cyc->W; g.cyc_rank = cyc->rank; g.cyc_lb0 = cyc->lb0; g.cyc_nb = cyc->nb; g.cyc_col0 = cyc->col0; g.cyc_block_rows = cyc->block_rows; }
   g.dbg = ctx_opt_i(ctx, "gemm.debug", 0);
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
@@ -336,14 +371,19 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   if (has_diag) {
     g.diagA = diag->A; g.diag_nbw = diag->nbw; g.diag_off = diag->off; g.diag_info = ctx->d_info;
     if (diag->ready) { g.ready = diag->ready; g.ready_target = diag->ready_target; g.ready_rows = diag->nbw * 64 / GT; }
-    hipLaunchKernelGGL(gemm_nt_sub_diag_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, st, g);
+    if (diag->A2 && diag->M2 > 0) {
+      g.A2 = diag->A2; g.B2 = diag->B2; g.C2 = diag->C2; g.M2 = diag->M2; g.N2 = diag->N2; g.K2 = diag->K2;
+      g.tiles2 = (int)(ceil_div(g.M2, GT) * ceil_div(g.N2, GT));
+    }
+    hipLaunchKernelGGL(gemm_nt_sub_diag_kernel, dim3((unsigned)(blocks + 1 + g.tiles2)), dim3(256), 0, st, g);
   } else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL(gemm_nt_sub_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   const double part = (double)(g.n_super - g.s_begin) / (double)n_super_all;  // share of the tile list in this launch
   ktime_end(ctx, slot, "gemm_nt_sub",
-            part * (lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K));
+            part * (lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K) +
+                2.0 * (double)g.M2 * (double)g.N2 * (double)g.K2);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   return GDML_OK;
@@ -750,15 +790,38 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
 #define PT_SP 66   // pitch of the row-major block in LDS (doubles): 16-byte aligned rows, 16-lane b128 reads conflict-free
 #define PT_LP 65   // pitch of L_jj^T
 
+#define PT_TB (64 * PT_LP + 64)  // per 64-block image in the prep buffer: L_jj^T (pitch PT_LP) followed by 1 / diag
+
+// One workgroup per 64 x 64 diagonal block of L: transposed copy (zero above the diagonal) + reciprocal pivots, in the
+// exact LDS image of panel_trsm_kernel.  Every row block of the solve used to redo this transpose (and its 64 divisions)
+// per step; it was 13 of the kernel's 53 ms (profiles/r02_panel_trsm_breakdown.txt).
+__global__ void __launch_bounds__(256) panel_trsm_prep_kernel(const double* __restrict__ L, int64_t ldl,
+                                                              double* __restrict__ Tb) {
+  const int jj = blockIdx.x, tid = threadIdx.x;
+  double* T = Tb + (int64_t)jj * PT_TB;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;  // L_jj[r][c], c <= r
+    const double v = (c <= r) ? L[(int64_t)(jj * 64 + r) * ldl + jj * 64 + c] : 0.0;
+    T[c * PT_LP + r] = v;
+    if (r == c) T[64 * PT_LP + r] = 1.0 / v;
+  }
+  if (tid < 64) T[tid * PT_LP + 64] = 0.0;  // pitch padding (copied along, never read)
+}
+
 template <bool ABL>
-__global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __restrict__ L, int64_t ldl,
+__global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __restrict__ Tb, const double* __restrict__ L, int64_t ldl,
                                                             double* __restrict__ X, int64_t ld, int nbw, int64_t m, int dbg) {
   __shared__ __attribute__((aligned(16))) double S[PT_ROWS * PT_SP];
-  __shared__ __attribute__((aligned(16))) double Lt[64 * PT_LP];
-  __shared__ double rinv[64];
+  __shared__ __attribute__((aligned(16))) double Lt[PT_TB];
+  double* const rinv = Lt + 64 * PT_LP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * PT_ROWS;
+  if (ABL && (dbg >> 8)) {  // experiment: delay every other group of 2^shift workgroups by n x 8128 cycles
+    const int shift = (dbg >> 8) & 15, nsl = (dbg >> 12) & 15;
+    if ((blockIdx.x >> shift) & 1)
+      for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   // ---- strip into registers (C layout: row = lk + 4 r + 16 i, col = li + 16 j); two separately named register
   // blocks (an array indexed by the owner test would be demoted to scratch memory)
@@ -770,7 +833,7 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        if (blk < nbw) {
+        if (blk < nbw && !(ABL && (dbg & 8))) {
           // clamped row index + select instead of predicated loads (no divergent branches; rows past m read row m-1)
           const int64_t gr = row0 + 16 * i + lk;
           const double* pc = X + blk * 64 + 16 * j + li;
@@ -823,11 +886,14 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
     } else {
       if (wave == 7 - jj) to_lds(accB);
     }
-    for (int e = tid; e < 64 * 64; e += 256) {
-      const int r = e >> 6, c = e & 63;  // L_jj[r][c], c <= r
-      const double v = (c <= r) ? L[(int64_t)(jj * 64 + r) * ldl + jj * 64 + c] : 0.0;
-      Lt[c * PT_LP + r] = v;
-      if (r == c) rinv[r] = 1.0 / v;
+    if (!(ABL && (dbg & 4))) {  // L_jj^T and reciprocal pivots: straight copy of the prepared image
+      const d2* src = reinterpret_cast<const d2*>(Tb + (int64_t)jj * PT_TB);
+      d2* dst = reinterpret_cast<d2*>(Lt);
+#pragma unroll
+      for (int k = 0; k < (PT_TB / 2 + 255) / 256; ++k) {
+        const int e = tid + 256 * k;
+        if (e < PT_TB / 2) dst[e] = src[e];
+      }
     }
     __syncthreads();
     // (2) substitution: x_c = t_c / L[c][c];  t_k -= x_c L[k][c] for k > c
@@ -851,7 +917,7 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         S[srow * PT_SP + sq + 8 * i] = t[i];
-        if (gr < m) X[gr * ld + jj * 64 + sq + 8 * i] = t[i];
+        if (gr < m && !(ABL && (dbg & 16))) X[gr * ld + jj * 64 + sq + 8 * i] = t[i];
       }
     }
     __syncthreads();
@@ -868,14 +934,19 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
 int launch_panel_trsm(gdml_ctx* ctx, hipStream_t st, const double* L, double* X, int64_t ld, int nb, int64_t m,
                       int64_t ldl) {
   if (m <= 0) return GDML_OK;
-  const int dbg = ctx_opt_i(ctx, "trsm.debug", 0);  // ablation bits: 1 no substitution, 2 no MFMA update (timing only)
+  const int dbg = ctx_opt_i(ctx, "trsm.debug", 0);  // timing-only ablation bits: 1 no substitution, 2 no MFMA update,
+                                                    // 4 no L_jj staging, 8 no strip load, 16 no stores
+  double* Tb = nullptr;
+  GDML_TRY(ctx_slot(ctx, 8, (int64_t)8 * PT_TB * 8, &Tb));
   const int slot = (st == (ctx->kt_stream ? ctx->kt_stream : ctx->stream)) ? ktime_begin(ctx) : -1;
+  hipLaunchKernelGGL(panel_trsm_prep_kernel, dim3((unsigned)(nb / 64)), dim3(256), 0, st, L, ldl > 0 ? ldl : ld, Tb);
   if (dbg)
-    hipLaunchKernelGGL(panel_trsm_kernel<true>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, L, ldl > 0 ? ldl : ld,
+    hipLaunchKernelGGL(panel_trsm_kernel<true>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, Tb, L, ldl > 0 ? ldl : ld,
                        X, ld, nb / 64, m, dbg);
   else
-    hipLaunchKernelGGL(panel_trsm_kernel<false>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, L, ldl > 0 ? ldl : ld,
+    hipLaunchKernelGGL(panel_trsm_kernel<false>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, Tb, L, ldl > 0 ? ldl : ld,
                        X, ld, nb / 64, m, 0);
+  ctx->launch_counter++;
   ktime_end(ctx, slot, "panel_trsm", (double)m * (double)nb * (double)nb);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
@@ -1037,8 +1108,12 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
                                          &dj));
         double* Xa = A + ta * ld + t0;  // rows below block a (they include b's rows of the outer panel)
         GDML_TRY(launch_panel_trsm(ctx, st, A + t0 * ld + t0, Xa, ld, (int)NB, n_rows - ta));
-        GDML_TRY(launch_gemm_nt_sub(ctx, st, Xa, ld, Xa, ld, A + ta * ld + ta, ld, n_rows - ta, NB, NB, 0));
-        dj.A = A + ta * ld + ta; dj.off = ta; dj.ready = nullptr;
+        // second launch: the K = NB update of b's columns by panel a rides in front of the remaining SYRK tiles; workgroup 0
+        // waits for the tiles of block b and factors it
+        dj.A = A + ta * ld + ta; dj.off = ta;
+        dj.A2 = Xa; dj.B2 = Xa; dj.C2 = A + ta * ld + ta; dj.M2 = n_rows - ta; dj.N2 = NB; dj.K2 = NB;
+        ready_count += (int)((NB / GT) * (NB / GT + 1) / 2);
+        dj.ready_target = ready_count;
         GDML_TRY(launch_gemm_nt_sub_part(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, n - t0, nb, 1, fs, 1.0, true,
                                          &dj));
         GDML_TRY(launch_panel_trsm(ctx, st, A + ta * ld + ta, A + t1 * ld + ta, ld, (int)NB, n_rows - t1));

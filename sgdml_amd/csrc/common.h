@@ -104,8 +104,8 @@ struct gdml_ctx {
   // scratch
   double* scratch = nullptr;
   int64_t scratch_bytes = 0;
-  double* slot[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // cached work buffers (ctx_slot)
-  int64_t slot_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double* slot[12] = {};  // cached work buffers (ctx_slot)
+  int64_t slot_bytes[12] = {};
   int* d_info = nullptr;
 
   // comm
