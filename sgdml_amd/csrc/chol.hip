@@ -1140,6 +1140,17 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
         GDML_TRY(launch_gemm_nt_sub_part(ctx, st, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1, 0.0,
                                          1.0, true, &dj));
         GDML_TRY(launch_panel_trsm(ctx, st, A + t0 * ld + t0, A + t1 * ld + t0, ld, (int)nb2, n_rows - t1));
+      } else if (ctx_opt_i(ctx, "chol.tail_lookahead", 1) && t1 < n) {
+        // tail: the SYRK is too short to hide the single-workgroup block factorisation; the multi-workgroup step chain and
+        // the row-local solve of panel k+1 run on the high-priority stream next to the (small) SYRK grid of panel k
+        hipStream_t sp = ctx->stream2;
+        HIP_CHECK(ctx, hipEventRecord(ctx->ev_la[0], st));
+        HIP_CHECK(ctx, hipStreamWaitEvent(sp, ctx->ev_la[0], 0));
+        GDML_TRY(panel_factor(ctx, sp, A, n_rows, ld, t0, nb2));
+        HIP_CHECK(ctx, hipEventRecord(ctx->ev_la[1], sp));
+        const double* P1 = A + t1 * ld + k0;
+        GDML_TRY(launch_gemm_nt_sub(ctx, st, P1, ld, P1, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, nb, 1));
+        HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_la[1], 0));
       } else {
         GDML_TRY(panel_factor(ctx, st, A, n_rows, ld, t0, nb2));
         if (t1 < n) {
