@@ -21,6 +21,7 @@
 // chol.fused_diag = 0; profiles/r02_panel_fusion_ab.txt has the comparison.  The CU-masked / split-stream / chunked
 // variants measured in rounds 1-2 (profiles/r01_chol_timeline_split.txt, r02_sched_probe.txt) are gone.
 #include "common.h"
+#include <utility>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -786,6 +787,32 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
 //       bijection on both sides.
 // LDS 50 KB, ~200 VGPRs: two workgroups per CU, the second one covers the substitution phases of the first.
 // ------------------------------------------------------------------------------------------
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): compile-time expansion of a loop body
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// DPP moves of a double (both halves): quad broadcast of lane q, row shifts
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_bcast(double v, int q) {
+  switch (q) {
+    case 0: return dpp_mov<0x00>(v);
+    case 1: return dpp_mov<0x55>(v);
+    case 2: return dpp_mov<0xaa>(v);
+    default: return dpp_mov<0xff>(v);
+  }
+}
+
 #define PT_ROWS 32
 #define PT_SP 66   // pitch of the row-major block in LDS (doubles): 16-byte aligned rows, 16-lane b128 reads conflict-free
 #define PT_LP 65   // pitch of L_jj^T
@@ -878,7 +905,6 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
     }
   };
 
-  const int srow = tid >> 3, sq = tid & 7;  // substitution: 8 threads per row
   for (int jj = 0; jj < nbw; ++jj) {
     // (1) owner's block -> LDS row-major; L_jj^T and reciprocal diagonal -> LDS
     if (jj < 4) {
@@ -896,23 +922,42 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
       }
     }
     __syncthreads();
-    // (2) substitution: x_c = t_c / L[c][c];  t_k -= x_c L[k][c] for k > c
+    // (2) substitution: x_c = t_c / L[c][c];  t_k -= x_c L[k][c] for k > c.  8 threads per row, thread q holds the columns
+    // k = q (mod 8).  What this phase costs is its 64-step dependent chain, so the solved entry travels by DPP (quad
+    // broadcast, then a 4-lane row shift into the row's other quad: VALU latency instead of an LDS permute round trip)
+    // and the L values of column c + 1 are fetched from LDS while column c is applied.
     if (!ABL || !(dbg & 1)) {
-      double t[8];
+      const int srow = tid >> 3, sq = tid & 7;
+      double t[8], ln[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) t[i] = S[srow * PT_SP + sq + 8 * i];
 #pragma unroll
-      for (int c = 0; c < 64; ++c) {
-        const int qc = c & 7, ic = c >> 3;
-        const double mine = t[ic] * rinv[c];
-        const double x = __shfl(mine, (lane & ~7) | qc, 64);
+      for (int i = 0; i < 8; ++i) ln[i] = Lt[sq + 8 * i];
+      double rn = rinv[0];
+      // one column step; expanded 64 times with compile-time c (a 64-trip loop of this size is only partially unrolled
+      // by the compiler even under #pragma unroll, which turns t[c >> 3] into a dynamically indexed register array)
+      auto column = [&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int qc = c & 7, ic = c >> 3;
+        double lc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lc[i] = ln[i];
+        const double rc = rn;
+        if constexpr (c + 1 < 64) {
+          rn = rinv[c + 1];
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i >= ((c + 1) >> 3)) ln[i] = Lt[(c + 1) * PT_LP + sq + 8 * i];
+        }
+        const double xq = quad_bcast(t[ic] * rc, qc & 3);             // lane (qc & 3) of the own quad
+        const double xo = (qc < 4) ? dpp_mov<0x114>(xq) : dpp_mov<0x104>(xq);  // the other quad's: row_shr:4 / row_shl:4
+        const double x = ((sq >> 2) == (qc >> 2)) ? xq : xo;
         if (sq == qc) t[ic] = x;
 #pragma unroll
-        for (int i = ic; i < 8; ++i) {
-          const double l = Lt[c * PT_LP + sq + 8 * i];
-          if (i > ic || sq > qc) t[i] -= x * l;
-        }
-      }
+        for (int i = 0; i < 8; ++i)
+          if (i > ic || (i == ic && sq > qc)) t[i] -= x * lc[i];
+      };
+      if (!(ABL && (dbg & 32))) static_for<64>(column);
       const int64_t gr = row0 + srow;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
