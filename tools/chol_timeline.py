@@ -52,27 +52,12 @@ if pt:
             parts[short(n)] = parts.get(short(n), 0) + (e - s)
         print('  t=%7.1f ms: wall %6.1f us | %s' % ((seg[p][1] - t0) / 1e6, (seg[p][2] - chain[0][1]) / 1e3,
                                                   ', '.join('%s %.0f' % (k[:18], v / 1e3) for k, v in parts.items())))
-# fused steps: GEMM1 (gemm_nt_sub_kernel) -> SYRK + diagonal block (gemm_nt_sub_diag_kernel) -> panel_trsm_kernel
-n_order = int(sys.argv[2]) if len(sys.argv) > 2 else 63000
-nbw = 512
-steps = []
-for i in range(1, len(seg) - 1):
-    if 'gemm_nt_sub_diag_kernel' in seg[i][0] and 'gemm_nt_sub_kernel' in seg[i - 1][0] and 'panel_trsm' in seg[i + 1][0]:
-        steps.append(i)
-if steps:
-    g1 = sum(seg[i - 1][2] - seg[i - 1][1] for i in steps)
-    sy = sum(seg[i][2] - seg[i][1] for i in steps)
-    tr = sum(seg[i + 1][2] - seg[i + 1][1] for i in steps)
-    gap_a = sum(seg[i][1] - seg[i - 1][2] for i in steps)          # GEMM1 -> SYRK
-    gap_b = sum(seg[i + 1][1] - seg[i][2] for i in steps)          # SYRK -> trsm
-    gap_c = sum(seg[i + 2][1] - seg[i + 1][2] for i in steps if i + 2 < len(seg))  # trsm -> next GEMM1
-    fl1 = sum(2.0 * (n_order + 1 - (s + 1) * nbw) * nbw * nbw for s in range(len(steps)))
-    fl2 = sum(float(n_order + 1 - (s + 2) * nbw) * (n_order - (s + 2) * nbw) * nbw for s in range(len(steps)))
-    print('%d fused steps: GEMM1 %.1f ms (%.1f TFLOP/s), SYRK+diag %.1f ms (%.1f TFLOP/s), panel_trsm %.1f ms; launch gaps '
-          'GEMM1->SYRK %.2f ms, SYRK->trsm %.2f ms, trsm->GEMM1 %.2f ms' % (len(steps), g1 / 1e6, fl1 / g1 / 1e3, sy / 1e6,
-          fl2 / sy / 1e3, tr / 1e6, gap_a / 1e6, gap_b / 1e6, gap_c / 1e6))
-    for i in steps[::max(1, len(steps) // 6)]:
-        print('  t=%7.1f ms: GEMM1 %6.1f us | gap %5.1f | SYRK %8.1f us | gap %5.1f | trsm %6.1f us | gap %5.1f' % (
-            (seg[i][1] - t0) / 1e6, (seg[i - 1][2] - seg[i - 1][1]) / 1e3, (seg[i][1] - seg[i - 1][2]) / 1e3,
-            (seg[i][2] - seg[i][1]) / 1e3, (seg[i + 1][1] - seg[i][2]) / 1e3, (seg[i + 1][2] - seg[i + 1][1]) / 1e3,
-            (seg[i + 2][1] - seg[i + 1][2]) / 1e3 if i + 2 < len(seg) else 0.0))
+# one panel pair in the middle of the run, launch by launch (schedule of chol_factor_device: merged SYRK half 1 with the
+# diagonal block of a -> prep + row-local solve of a -> SYRK half 2 with the K = NB update of b and its diagonal block ->
+# prep + row-local solve of b)
+dk = [i for i, r in enumerate(seg) if 'gemm_nt_sub_diag_kernel' in r[0]]
+if len(dk) > 8:
+    i0 = dk[len(dk) // 2 // 2 * 2]
+    print('launch sequence around t = %.1f ms:' % ((seg[i0][1] - t0) / 1e6))
+    for n, s_, e_ in seg[i0:i0 + 8]:
+        print('  %-34s %9.1f us' % (short(n)[:34], (e_ - s_) / 1e3))
