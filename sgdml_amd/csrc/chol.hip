@@ -382,7 +382,8 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   else
     hipLaunchKernelGGL(gemm_nt_sub_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   const double part = (double)(g.n_super - g.s_begin) / (double)n_super_all;  // share of the tile list in this launch
-  ktime_end(ctx, slot, "gemm_nt_sub",
+  // the fused launches (trailing update + diagonal-block workgroup) are the dominant kernel: timed under their own name
+  ktime_end(ctx, slot, has_diag ? "gemm_nt_sub_diag" : "gemm_nt_sub",
             part * (lower ? (double)M * (double)(M + 1) * (double)K : 2.0 * (double)M * (double)N * (double)K) +
                 2.0 * (double)g.M2 * (double)g.N2 * (double)g.K2);
   ctx->launch_counter++;

@@ -37,7 +37,7 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 0, 0])
     print('%-40s %8d %16.3f %16.3f %14.4f' % (k[:40], n, rd / 1e9, wr / 1e9, (rd + wr) / max(1, n) / 1e9))
     out[k] = {'launches': n, 'read_bytes': rd, 'written_bytes': wr, 'hbm_bytes_per_launch': (rd + wr) / max(1, n)}
 res = {}
-for key, pat in (('gemm_nt_sub', 'gemm_nt_sub'), ('assemble', 'assemble_strip_kernel')):
+for key, pat in (('gemm_nt_sub_diag', 'gemm_nt_sub_diag_kernel'), ('gemm_nt_sub', 'gemm_nt_sub_kernel'), ('assemble', 'assemble_strip_kernel')):
     sel = [v for k, v in out.items() if pat in k]  # all instantiations (plain + fused diagonal-block launch)
     if sel:
         n = sum(v['launches'] for v in sel)

@@ -29,7 +29,7 @@ for spec in (sys.argv[1:] or ['-']):
         except Exception as e:      # ablations break positive definiteness
             pass
         ms, nl, work = ctx.kernel_stat('panel_trsm')
-        gms, gnl, gwork = ctx.kernel_stat('gemm_nt_sub')
+        gms, gnl, gwork = ctx.kernel_stat('gemm_nt_sub_diag')
         out.append('trsm %.1f ms / %d launches (%.1f TFLOP/s) gemm %.1f ms (%.1f TF) factor %.1f ms' % (
             ms, nl, work / ms / 1e9 if ms else 0, gms, gwork / gms / 1e9 if gms else 0, ctx.phase_ms('factor')[0]))
         ctx.profile(False)
