@@ -88,6 +88,11 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
  *   chol.nb (512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),
  *   chol.lookahead (1)    factorisation schedule (fused_diag = 0: the round-1 second-stream look-ahead schedule)
+ *   chol.outer (1024)     panel pairs: K = 2 nb trailing update in two launches (= chol.nb: single panels only)
+ *   chol.outer_min_rows (16384)  trailing rows below which new panels are single again
+ *   chol.merge_gemm1 (1)  the pair's own columns as first super-tile column of the trailing-update launch
+ *   chol.tail_lookahead (1)  tail: step chain of the next panel on the high-priority stream
+ *   trsm.debug (0)        timing-only ablation mask of the row-local panel solve (results are wrong when set)
  *   trsv.persist (1)      backward substitution as one persistent launch
  *   predict.wave_only (0), predict.mfma (1), predict.mfma_wide (1), predict.fill   prediction kernel choice
  *   lu.nb (64)            panel width of the LU fallback
