@@ -456,6 +456,70 @@ __device__ __forceinline__ int potrf64_wave(double* T, double* col, int lane) {
   return fail;
 }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): compile-time expansion of a loop body
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// DPP moves of a double (both halves): quad broadcast of lane q, row shifts
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_bcast(double v, int q) {
+  switch (q) {
+    case 0: return dpp_mov<0x00>(v);
+    case 1: return dpp_mov<0x55>(v);
+    case 2: return dpp_mov<0xaa>(v);
+    default: return dpp_mov<0xff>(v);
+  }
+}
+
+// Exact substitution x <- x L^-T of one 64-column block for a row held by 8 threads (thread sq owns the columns k = sq mod 8
+// in t[0..7]); Lt = L^T with pitch lp and rinv = 1 / diag(L) in LDS.  What this costs is its 64-step dependent chain, so
+// the solved entry travels by DPP (quad broadcast, then a 4-lane row shift into the row's other quad: VALU latency instead
+// of an LDS permute round trip), the L values of column c + 1 are fetched from LDS while column c is applied, and the
+// column steps are expanded at compile time (a 64-trip loop of this size is only partially unrolled even under
+// #pragma unroll, which turns t[c >> 3] into a dynamically indexed register array).
+template <int LP>
+__device__ __forceinline__ void subst64_row8(double (&t)[8], const double* __restrict__ Lt, const double* __restrict__ rinv,
+                                             int sq) {
+  double ln[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ln[i] = Lt[sq + 8 * i];
+  double rn = rinv[0];
+  auto column = [&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
+    constexpr int qc = c & 7, ic = c >> 3;
+    double lc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lc[i] = ln[i];
+    const double rc = rn;
+    if constexpr (c + 1 < 64) {
+      rn = rinv[c + 1];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i >= ((c + 1) >> 3)) ln[i] = Lt[(c + 1) * LP + sq + 8 * i];
+    }
+    const double xq = quad_bcast(t[ic] * rc, qc & 3);                      // lane (qc & 3) of the own quad
+    const double xo = (qc < 4) ? dpp_mov<0x114>(xq) : dpp_mov<0x104>(xq);  // the other quad's: row_shr:4 / row_shl:4
+    const double x = ((sq >> 2) == (qc >> 2)) ? xq : xo;
+    if (sq == qc) t[ic] = x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i > ic || (i == ic && sq > qc)) t[i] -= x * lc[i];
+    if constexpr ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // bounds the scheduler's hoisting of later columns' reads
+  };
+  static_for<64>(column);
+}
+
 // ------------------------------------------------------------------------------------------
 // Diagonal block of a panel, factored by ONE workgroup (256 threads) inside the trailing-update launch.
 // The 64-wide step chain (potrf64, rows below by substitution, rank-64 update) of the nb x nb block is a
@@ -543,48 +607,54 @@ __device__ __forceinline__ void diag_block_role(double* __restrict__ D, int64_t 
       double t[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) t[i] = xr[sq + 8 * i];
-#pragma unroll
-      for (int c = 0; c < 64; ++c) {
-        const int qc = c & 7, ic = c >> 3;
-        const double mine = t[ic] * rinv[c];
-        const double x = __shfl(mine, (lane & ~7) | qc, 64);
-        if (sq == qc) t[ic] = x;
-#pragma unroll
-        for (int i = ic; i < 8; ++i) {
-          const double l = Lt[c * 65 + sq + 8 * i];
-          if (i > ic || sq > qc) t[i] -= x * l;
-        }
-        // keep the scheduler from hoisting all 288 L reads of the unrolled loop to its top (register pressure)
-        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
+      subst64_row8<65>(t, Lt, rinv, sq);
 #pragma unroll
       for (int i = 0; i < 8; ++i) xr[sq + 8 * i] = t[i];
     }
     __syncthreads();
-    // rank-64 update of the rest of the block (lower 16 x 16 tiles): C -= X_r X_c^T, X = columns [c0, c0+64)
-    const int nt = mrows / 16;
+    // rank-64 update of the rest of the block, C -= X_r X_c^T with X = columns [c0, c0+64): lower 32 x 32 macro tiles
+    // (2 x 2 MFMA tiles, each operand run loaded once for two tiles), one macro tile per wavefront and turn
+    const int nt = mrows / 32;
     const int ntiles = nt * (nt + 1) / 2;
     for (int t = wave; t < ntiles; t += 4) {
       int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
       while (ti * (ti + 1) / 2 > t) --ti;
       while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
       const int tj = t - ti * (ti + 1) / 2;
-      const int r0 = c0 + 64 + 16 * ti, q0 = c0 + 64 + 16 * tj;
-      double* Cp = D + (int64_t)(r0 + lk) * ld + q0 + li;  // C layout: row = lk + 4 r, col = li
-      d4 acc;
+      const int r0 = c0 + 64 + 32 * ti, q0 = c0 + 64 + 32 * tj;
+      double* Cp = D + (int64_t)(r0 + lk) * ld + q0 + li;  // C layout of tile (i, j): row = 16 i + lk + 4 r, col = 16 j + li
+      d4 acc[2][2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = Cp[(int64_t)(4 * r) * ld];
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = Cp[(int64_t)(16 * i + 4 * r) * ld + 16 * j];
       const double* Ap = D + (int64_t)(r0 + li) * ld + c0 + 4 * lk;
       const double* Bp = D + (int64_t)(q0 + li) * ld + c0 + 4 * lk;
+      d4 a[2][4], bb[2][4];
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        const d4 a = *reinterpret_cast<const d4*>(Ap + 16 * ch);
-        const d4 b = *reinterpret_cast<const d4*>(Bp + 16 * ch);
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[sidx], b[sidx], acc, 0, 0, 0);
-      }
+        for (int ch = 0; ch < 4; ++ch) {
+          a[i][ch] = *reinterpret_cast<const d4*>(Ap + (int64_t)(16 * i) * ld + 16 * ch);
+          bb[i][ch] = *reinterpret_cast<const d4*>(Bp + (int64_t)(16 * i) * ld + 16 * ch);
+        }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Cp[(int64_t)(4 * r) * ld] = acc[r];
+      for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[i][ch][sidx], bb[j][ch][sidx], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cp[(int64_t)(16 * i + 4 * r) * ld + 16 * j] = acc[i][j][r];
     }
     __syncthreads();
   }
@@ -788,32 +858,6 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
 //       bijection on both sides.
 // LDS 50 KB, ~200 VGPRs: two workgroups per CU, the second one covers the substitution phases of the first.
 // ------------------------------------------------------------------------------------------
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): compile-time expansion of a loop body
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// DPP moves of a double (both halves): quad broadcast of lane q, row shifts
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double quad_bcast(double v, int q) {
-  switch (q) {
-    case 0: return dpp_mov<0x00>(v);
-    case 1: return dpp_mov<0x55>(v);
-    case 2: return dpp_mov<0xaa>(v);
-    default: return dpp_mov<0xff>(v);
-  }
-}
-
 #define PT_ROWS 32
 #define PT_SP 66   // pitch of the row-major block in LDS (doubles): 16-byte aligned rows, 16-lane b128 reads conflict-free
 #define PT_LP 65   // pitch of L_jj^T
@@ -923,42 +967,13 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
       }
     }
     __syncthreads();
-    // (2) substitution: x_c = t_c / L[c][c];  t_k -= x_c L[k][c] for k > c.  8 threads per row, thread q holds the columns
-    // k = q (mod 8).  What this phase costs is its 64-step dependent chain, so the solved entry travels by DPP (quad
-    // broadcast, then a 4-lane row shift into the row's other quad: VALU latency instead of an LDS permute round trip)
-    // and the L values of column c + 1 are fetched from LDS while column c is applied.
+    // (2) substitution: x_c = t_c / L[c][c];  t_k -= x_c L[k][c] for k > c.  8 threads per row (subst64_row8)
     if (!ABL || !(dbg & 1)) {
       const int srow = tid >> 3, sq = tid & 7;
-      double t[8], ln[8];
+      double t[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) t[i] = S[srow * PT_SP + sq + 8 * i];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ln[i] = Lt[sq + 8 * i];
-      double rn = rinv[0];
-      // one column step; expanded 64 times with compile-time c (a 64-trip loop of this size is only partially unrolled
-      // by the compiler even under #pragma unroll, which turns t[c >> 3] into a dynamically indexed register array)
-      auto column = [&](auto cc) __attribute__((always_inline)) {
-        constexpr int c = decltype(cc)::value;
-        constexpr int qc = c & 7, ic = c >> 3;
-        double lc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) lc[i] = ln[i];
-        const double rc = rn;
-        if constexpr (c + 1 < 64) {
-          rn = rinv[c + 1];
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (i >= ((c + 1) >> 3)) ln[i] = Lt[(c + 1) * PT_LP + sq + 8 * i];
-        }
-        const double xq = quad_bcast(t[ic] * rc, qc & 3);             // lane (qc & 3) of the own quad
-        const double xo = (qc < 4) ? dpp_mov<0x114>(xq) : dpp_mov<0x104>(xq);  // the other quad's: row_shr:4 / row_shl:4
-        const double x = ((sq >> 2) == (qc >> 2)) ? xq : xo;
-        if (sq == qc) t[ic] = x;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (i > ic || (i == ic && sq > qc)) t[i] -= x * lc[i];
-      };
-      if (!(ABL && (dbg & 32))) static_for<64>(column);
+      if (!(ABL && (dbg & 32))) subst64_row8<PT_LP>(t, Lt, rinv, sq);
       const int64_t gr = row0 + srow;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
