@@ -61,3 +61,16 @@ if len(dk) > 8:
     print('launch sequence around t = %.1f ms:' % ((seg[i0][1] - t0) / 1e6))
     for n, s_, e_ in seg[i0:i0 + 8]:
         print('  %-34s %9.1f us' % (short(n)[:34], (e_ - s_) / 1e3))
+
+# optional: launch-by-launch listing of the last TAIL_MS milliseconds (start offset from the end, duration, queue)
+import os
+tail_ms = float(os.environ.get('TAIL_MS', '0'))
+if tail_ms > 0:
+    try:
+        rows_q = cur.execute("select name, start, end, queue_id from kernels order by start").fetchall()
+    except Exception:
+        rows_q = [(n, s_, e_, -1) for n, s_, e_ in rows]
+    print('last %.1f ms of the factorisation (t relative to its end, us):' % tail_ms)
+    for n, s_, e_, q in rows_q:
+        if s_ >= t1 - tail_ms * 1e6 and e_ <= t1 + 1000 and not n.startswith('__amd_rocclr'):
+            print('  t=%9.1f  %-30s %8.1f us  q%s' % ((s_ - t1) / 1e3, short(n)[:30], (e_ - s_) / 1e3, q))

@@ -9,7 +9,7 @@ rm -rf /tmp/prof
 (cd $R && timeout 900 rocprofv3 --kernel-trace -d /tmp/prof -- $CMD) > /tmp/prof.log 2>&1
 f=$(find /tmp/prof -name "*.db" | head -1)
 { echo "== rocprofv3 --kernel-trace -- $CMD"; python $R/tools/rocpd_stats.py $f; } > $R/gpurun_out/${tag}_kernel_stats.txt
-{ echo "== tools/chol_timeline.py on the same trace (last of the 4 factorisations)"; python $R/tools/chol_timeline.py $f; } > $R/gpurun_out/${tag}_chol_timeline.txt
+{ echo "== tools/chol_timeline.py on the same trace (last of the 4 factorisations)"; TAIL_MS=${TAIL_MS:-0} python $R/tools/chol_timeline.py $f; } > $R/gpurun_out/${tag}_chol_timeline.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   (cd $R && timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --steps 1 --warmup 0 --no-cpu --no-configs --no-profile) > /tmp/pmc_$c.log 2>&1
