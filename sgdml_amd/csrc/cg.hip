@@ -234,6 +234,11 @@ static int tall_trsm(gdml_ctx* ctx, const double* L, double* X, int64_t n, int64
   hipStream_t st = ctx->stream;
   for (int64_t k0 = 0; k0 < m; k0 += NB) {
     const int64_t nb = (m - k0 < NB) ? m - k0 : NB;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(L) | reinterpret_cast<uintptr_t>(X)) & 31) == 0 && (ld % 4 == 0);
+    if (nb % 64 == 0 && aligned && ctx_opt_i(ctx, "chol.panel_kernel", 1)) {
+      // whole NB-wide strip in one row-local launch (the kernel of the Cholesky panels) instead of 8 x (trsm64 + K = 64 GEMM)
+      GDML_TRY(launch_panel_trsm(ctx, st, L + k0 * ld + k0, X + k0, ld, (int)nb, n));
+    } else
     for (int64_t jj = 0; jj < nb; jj += 64) {
       const int64_t c0 = k0 + jj;
       const int w = (int)((nb - jj < 64) ? nb - jj : 64);
