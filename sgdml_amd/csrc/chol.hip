@@ -82,6 +82,7 @@ struct GemmArgs {
   int tiles2;
 };
 
+template <bool PIPE>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g);
 
 template <bool FULL>
@@ -121,7 +122,7 @@ __device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid,
 
 // ABL = true only in the ablation instantiation (option gemm.debug != 0): the production kernel carries
 // none of the ablation branches.
-template <bool FULL, bool ABL>
+template <bool FULL, bool ABL, bool PIPE = true>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[2][GT * GPITCH],
                                                int64_t row0, int64_t col0) {
   const int dbg = ABL ? g.dbg : 0;
@@ -143,39 +144,95 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   gemm_store_tile(lds[0][1], tid, rb);
   __syncthreads();
 
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    if (kt + 1 < nk && !(dbg & 2)) {
-      gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
-      gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
-    }
-    const double* As = lds[cur][0] + (wm * 64 + li) * GPITCH + lk;
-    const double* Bs = lds[cur][1] + (wn * 64 + li) * GPITCH + lk;
-#pragma unroll
-    for (int ks = 0; ks < GBK; ks += 4) {
-      double a[4], bb[4];
+  if constexpr (PIPE) {
+    // Operand reads run one k-step (4 of the 16 k of a tile) ahead of the MFMAs that use them, ACROSS the tile boundary: the
+    // tile's single barrier sits after the reads of its last k-step have landed and before that step's 16 MFMAs, so the first
+    // reads of the next tile (other buffer, written at k-step GEMM_COMMIT_KS and published by this barrier) are issued under
+    // those MFMAs instead of right after a barrier with nothing to overlap them.
+    double a[4], bb[4];
+    auto read_ops = [&](double (&ra_)[4], double (&rb_)[4], int buf, int ks) {
+      const double* As = lds[buf][0] + (wm * 64 + li) * GPITCH + lk;
+      const double* Bs = lds[buf][1] + (wn * 64 + li) * GPITCH + lk;
       if (dbg & 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = bb[i] = (double)(lane + i + ks);
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) ra_[i] = rb_[i] = (double)(lane + i + ks);
       } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = As[i * 16 * GPITCH + ks];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bb[j] = Bs[j * 16 * GPITCH + ks];
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) ra_[i] = As[i * 16 * GPITCH + ks];
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) rb_[j] = Bs[j * 16 * GPITCH + ks];
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-      if (ks == GEMM_COMMIT_KS && kt + 1 < nk && !(dbg & 2)) {
-        // the next tile's global loads were issued ~32 MFMAs ago: write them to the other LDS
-        // buffer now so that the stores drain under the remaining MFMAs of this tile
-        gemm_store_tile(lds[cur ^ 1][0], tid, ra);
-        gemm_store_tile(lds[cur ^ 1][1], tid, rb);
+    };
+    read_ops(a, bb, 0, 0);
+    for (int64_t kt = 0; kt < nk; ++kt) {
+      const int cur = (int)(kt & 1);
+      if (kt + 1 < nk && !(dbg & 2)) {
+        gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
+        gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
+      }
+  #pragma unroll
+      for (int ks = 0; ks < GBK; ks += 4) {
+        double an[4], bn[4];
+        if (ks + 4 < GBK) {
+          read_ops(an, bn, cur, ks + 4);
+        } else {
+          // last k-step of the tile: its operands are in registers; publish / wait for the other buffer, then fetch the next
+          // tile's first operands under this step's MFMAs
+          if (!(dbg & 8)) __syncthreads();
+          if (kt + 1 < nk) read_ops(an, bn, cur ^ 1, 0);
+        }
+  #pragma unroll
+        for (int i = 0; i < 4; ++i)
+  #pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+        if (ks == GEMM_COMMIT_KS && kt + 1 < nk && !(dbg & 2)) {
+          // the next tile's global loads were issued ~32 MFMAs ago: write them to the other LDS
+          // buffer now so that the stores drain under the remaining MFMAs of this tile
+          gemm_store_tile(lds[cur ^ 1][0], tid, ra);
+          gemm_store_tile(lds[cur ^ 1][1], tid, rb);
+        }
+        if (ks + 4 < GBK || kt + 1 < nk) {
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) { a[i] = an[i]; bb[i] = bn[i]; }
+        }
       }
     }
-    if (!(dbg & 8)) __syncthreads();
+  } else {
+    for (int64_t kt = 0; kt < nk; ++kt) {
+      const int cur = (int)(kt & 1);
+      if (kt + 1 < nk && !(dbg & 2)) {
+        gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
+        gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
+      }
+      const double* As = lds[cur][0] + (wm * 64 + li) * GPITCH + lk;
+      const double* Bs = lds[cur][1] + (wn * 64 + li) * GPITCH + lk;
+  #pragma unroll
+      for (int ks = 0; ks < GBK; ks += 4) {
+        double a[4], bb[4];
+        if (dbg & 4) {
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = bb[i] = (double)(lane + i + ks);
+        } else {
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = As[i * 16 * GPITCH + ks];
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) bb[j] = Bs[j * 16 * GPITCH + ks];
+        }
+  #pragma unroll
+        for (int i = 0; i < 4; ++i)
+  #pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+        if (ks == GEMM_COMMIT_KS && kt + 1 < nk && !(dbg & 2)) {
+          // the next tile's global loads were issued ~32 MFMAs ago: write them to the other LDS
+          // buffer now so that the stores drain under the remaining MFMAs of this tile
+          gemm_store_tile(lds[cur ^ 1][0], tid, ra);
+          gemm_store_tile(lds[cur ^ 1][1], tid, rb);
+        }
+      }
+      if (!(dbg & 8)) __syncthreads();
+    }
   }
   if (dbg & 1) {
     if (acc[0][0][0] == 1.2345e-300) g.C[0] = 0.0;  // keep the accumulators alive
@@ -245,7 +302,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 }
 
 // block index -> tile (XCD-aware 8x8 super tiles: block b runs on XCD b % 8) and the tile's GEMM
-template <bool ABL>
+template <bool ABL, bool PIPE = true>
 __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][GT * GPITCH], int64_t b) {
   if (b < g.tiles2) {  // second problem (workgroup-uniform branch)
     const int tn2 = (int)((g.N2 + GT - 1) / GT);
@@ -257,9 +314,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
     const int64_t row0 = ti * GT, col0 = tj * GT;
     const bool full = (row0 + GT <= h.M) && (col0 + GT <= h.N) && ((h.K & (GBK - 1)) == 0) && h.aligned;
     if (full)
-      gemm_tile_body<true, ABL>(h, lds, row0, col0);
+      gemm_tile_body<true, ABL, PIPE>(h, lds, row0, col0);
     else
-      gemm_tile_body<false, ABL>(h, lds, row0, col0);
+      gemm_tile_body<false, ABL, PIPE>(h, lds, row0, col0);
     if (g.ready && ti < g.ready_rows && tj < g.ready_rows) {
       __threadfence();
       __syncthreads();
@@ -303,9 +360,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
   }
   const bool full = (row0 + GT <= g.M) && (col0 + GT <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
   if (full)
-    gemm_tile_body<true, ABL>(g, lds, row0, col0);
+    gemm_tile_body<true, ABL, PIPE>(g, lds, row0, col0);
   else
-    gemm_tile_body<false, ABL>(g, lds, row0, col0);
+    gemm_tile_body<false, ABL, PIPE>(g, lds, row0, col0);
   if (g.ready && g.tiles2 == 0 && ti < g.ready_rows && tj < g.ready_rows) {  // publish the tile (release: every thread's stores, then one count)
     __threadfence();
     __syncthreads();
@@ -376,7 +433,10 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
       g.A2 = diag->A2; g.B2 = diag->B2; g.C2 = diag->C2; g.M2 = diag->M2; g.N2 = diag->N2; g.K2 = diag->K2;
       g.tiles2 = (int)(ceil_div(g.M2, GT) * ceil_div(g.N2, GT));
     }
-    hipLaunchKernelGGL(gemm_nt_sub_diag_kernel, dim3((unsigned)(blocks + 1 + g.tiles2)), dim3(256), 0, st, g);
+    if (ctx_opt_i(ctx, "gemm.pipe", 1))
+      hipLaunchKernelGGL(gemm_nt_sub_diag_kernel<true>, dim3((unsigned)(blocks + 1 + g.tiles2)), dim3(256), 0, st, g);
+    else  // A/B reference: operand reads of a k-step issued right before its MFMAs, barrier at the end of the tile
+      hipLaunchKernelGGL(gemm_nt_sub_diag_kernel<false>, dim3((unsigned)(blocks + 1 + g.tiles2)), dim3(256), 0, st, g);
   } else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   else
@@ -662,6 +722,7 @@ __device__ __forceinline__ void diag_block_role(double* __restrict__ D, int64_t 
 }
 
 // Trailing update + (workgroup 0) the next panel's diagonal block.
+template <bool PIPE>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
   static_assert(sizeof(double) * 2 * 2 * GT * GPITCH >= sizeof(double) * (2 * 64 * 65 + 64 + 128), "LDS of the diagonal role");
@@ -675,7 +736,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
     diag_block_role(g.diagA, g.ldc, g.diag_nbw, g.diag_off, g.diag_info, &lds[0][0][0]);
     return;
   }
-  gemm_block<false>(g, lds, (int64_t)blockIdx.x - 1);
+  gemm_block<false, PIPE>(g, lds, (int64_t)blockIdx.x - 1);
 }
 
 __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
