@@ -130,11 +130,27 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
 
+  // C -= A B^T as acc = C; acc += (-A) B^T; C = acc for interior tiles: the 64 C loads per lane are issued with the first
+  // operand tiles (their latency is paid once, together with the prologue's), the epilogue is stores only -- instead of
+  // four load->store round trips after the last MFMA.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r.
+  constexpr bool CIN = FULL && !ABL;
+  double* Cw = g.C + (row0 + wm * 64 + lk) * g.ldc + col0 + wn * 64 + li;
+  // wave-uniform tile corner + 32-bit lane offset: the 64 row addresses stay in SGPRs (saddr form), no address VGPRs
+  const int wu = __builtin_amdgcn_readfirstlane(wave);
+  double* const Ct = g.C + (row0 + (wu >> 1) * 64) * g.ldc + col0 + (wu & 1) * 64;
+  const unsigned coff = (unsigned)lk * (unsigned)g.ldc + (unsigned)li;
   d4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; ++j) {
+      if (CIN) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = (Ct + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff + j * 16];
+      } else {
+        acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+      }
+    }
 
   const int64_t nk = (g.K + GBK - 1) / GBK;
   d2 ra[4], rb[4];
@@ -158,7 +174,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
         for (int i = 0; i < 4; ++i) ra_[i] = rb_[i] = (double)(lane + i + ks);
       } else {
   #pragma unroll
-        for (int i = 0; i < 4; ++i) ra_[i] = As[i * 16 * GPITCH + ks];
+        for (int i = 0; i < 4; ++i) ra_[i] = -As[i * 16 * GPITCH + ks];
   #pragma unroll
         for (int j = 0; j < 4; ++j) rb_[j] = Bs[j * 16 * GPITCH + ks];
       }
@@ -215,7 +231,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
           for (int i = 0; i < 4; ++i) a[i] = bb[i] = (double)(lane + i + ks);
         } else {
   #pragma unroll
-          for (int i = 0; i < 4; ++i) a[i] = As[i * 16 * GPITCH + ks];
+          for (int i = 0; i < 4; ++i) a[i] = -As[i * 16 * GPITCH + ks];
   #pragma unroll
           for (int j = 0; j < 4; ++j) bb[j] = Bs[j * 16 * GPITCH + ks];
         }
@@ -241,7 +257,20 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 
   // ---- epilogue: C -= acc.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r.
   // All loads of a 64x16 column strip are issued before the first use (no serialised round trips).
-  double* Cw = g.C + (row0 + wm * 64 + lk) * g.ldc + col0 + wn * 64 + li;
+  if (CIN) {
+    // recompute the store addresses from laundered copies: the compiler otherwise keeps the prologue's 32 load addresses
+    // alive across the main loop (spilled to scratch)
+    double* Ct2 = Ct;
+    unsigned coff2 = coff;
+    asm volatile("" : "+v"(Ct2), "+v"(coff2));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) (Ct2 + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff2 + j * 16] = acc[i][j][r];
+    return;
+  }
 #if GEMM_EPI_PIPE
   if (FULL) {
     double cv[2][4][4];
@@ -260,7 +289,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[j & 1][i][r] - acc[i][j][r];
+        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[j & 1][i][r] + acc[i][j][r];
     }
     return;
   }
@@ -276,7 +305,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[i][r] - acc[i][j][r];
+        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[i][r] + acc[i][j][r];
     } else {
       const int64_t gc = col0 + wn * 64 + j * 16 + li;
       const bool cok = gc < g.N;
@@ -295,7 +324,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
-          if (cok && gr < g.M) g.C[gr * g.ldc + gc] = cv[i][r] - acc[i][j][r];
+          if (cok && gr < g.M) g.C[gr * g.ldc + gc] = cv[i][r] + acc[i][j][r];
         }
     }
   }
