@@ -86,7 +86,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   asm.i_chunk (32)      row points walked by one wavefront of the strip kernel
  *   asm.threads, asm.ib, asm.minw, asm.gj_global, asm.j_chunk, asm.debug   LDS-kernel shape / ablations
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
- *   gemm.pipe (1)         fused GEMM launches: operand reads one k-step ahead across the tile boundary (0: A/B reference)
+ *   gemm.cacc (1)         fused GEMM launches: interior tiles accumulate into C loaded up front (0: load-subtract-store epilogue)
+ *   gemm.pipe (0)         fused GEMM launches: operand reads one k-step ahead across the tile boundary
  *   chol.nb (512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),
  *   chol.lookahead (1)    factorisation schedule (fused_diag = 0: the round-1 second-stream look-ahead schedule)
  *   chol.outer (1024)     panel pairs: K = 2 nb trailing update in two launches (= chol.nb: single panels only)

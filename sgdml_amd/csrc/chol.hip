@@ -82,7 +82,7 @@ struct GemmArgs {
   int tiles2;
 };
 
-template <bool PIPE>
+template <bool PIPE, bool CACC>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g);
 
 template <bool FULL>
@@ -122,7 +122,7 @@ __device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid,
 
 // ABL = true only in the ablation instantiation (option gemm.debug != 0): the production kernel carries
 // none of the ablation branches.
-template <bool FULL, bool ABL, bool PIPE = true>
+template <bool FULL, bool ABL, bool PIPE = false, bool CACC = true>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[2][GT * GPITCH],
                                                int64_t row0, int64_t col0) {
   const int dbg = ABL ? g.dbg : 0;
@@ -133,7 +133,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   // C -= A B^T as acc = C; acc += (-A) B^T; C = acc for interior tiles: the 64 C loads per lane are issued with the first
   // operand tiles (their latency is paid once, together with the prologue's), the epilogue is stores only -- instead of
   // four load->store round trips after the last MFMA.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r.
-  constexpr bool CIN = FULL && !ABL;
+  constexpr bool CIN = FULL && !ABL && CACC;
   double* Cw = g.C + (row0 + wm * 64 + lk) * g.ldc + col0 + wn * 64 + li;
   // wave-uniform tile corner + 32-bit lane offset: the 64 row addresses stay in SGPRs (saddr form), no address VGPRs
   const int wu = __builtin_amdgcn_readfirstlane(wave);
@@ -331,7 +331,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 }
 
 // block index -> tile (XCD-aware 8x8 super tiles: block b runs on XCD b % 8) and the tile's GEMM
-template <bool ABL, bool PIPE = true>
+template <bool ABL, bool PIPE = false, bool CACC = true>
 __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][GT * GPITCH], int64_t b) {
   if (b < g.tiles2) {  // second problem (workgroup-uniform branch)
     const int tn2 = (int)((g.N2 + GT - 1) / GT);
@@ -343,9 +343,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
     const int64_t row0 = ti * GT, col0 = tj * GT;
     const bool full = (row0 + GT <= h.M) && (col0 + GT <= h.N) && ((h.K & (GBK - 1)) == 0) && h.aligned;
     if (full)
-      gemm_tile_body<true, ABL, PIPE>(h, lds, row0, col0);
+      gemm_tile_body<true, ABL, PIPE, CACC>(h, lds, row0, col0);
     else
-      gemm_tile_body<false, ABL, PIPE>(h, lds, row0, col0);
+      gemm_tile_body<false, ABL, PIPE, CACC>(h, lds, row0, col0);
     if (g.ready && ti < g.ready_rows && tj < g.ready_rows) {
       __threadfence();
       __syncthreads();
@@ -389,9 +389,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
   }
   const bool full = (row0 + GT <= g.M) && (col0 + GT <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
   if (full)
-    gemm_tile_body<true, ABL, PIPE>(g, lds, row0, col0);
+    gemm_tile_body<true, ABL, PIPE, CACC>(g, lds, row0, col0);
   else
-    gemm_tile_body<false, ABL, PIPE>(g, lds, row0, col0);
+    gemm_tile_body<false, ABL, PIPE, CACC>(g, lds, row0, col0);
   if (g.ready && g.tiles2 == 0 && ti < g.ready_rows && tj < g.ready_rows) {  // publish the tile (release: every thread's stores, then one count)
     __threadfence();
     __syncthreads();
@@ -462,10 +462,12 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
       g.A2 = diag->A2; g.B2 = diag->B2; g.C2 = diag->C2; g.M2 = diag->M2; g.N2 = diag->N2; g.K2 = diag->K2;
       g.tiles2 = (int)(ceil_div(g.M2, GT) * ceil_div(g.N2, GT));
     }
-    if (ctx_opt_i(ctx, "gemm.pipe", 1))
-      hipLaunchKernelGGL(gemm_nt_sub_diag_kernel<true>, dim3((unsigned)(blocks + 1 + g.tiles2)), dim3(256), 0, st, g);
-    else  // A/B reference: operand reads of a k-step issued right before its MFMAs, barrier at the end of the tile
-      hipLaunchKernelGGL(gemm_nt_sub_diag_kernel<false>, dim3((unsigned)(blocks + 1 + g.tiles2)), dim3(256), 0, st, g);
+    const dim3 grid((unsigned)(blocks + 1 + g.tiles2));
+    const int pipe = ctx_opt_i(ctx, "gemm.pipe", 0), cacc = ctx_opt_i(ctx, "gemm.cacc", 1);
+    if (pipe && cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true>), grid, dim3(256), 0, st, g);
+    else if (pipe) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else if (cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, false>), grid, dim3(256), 0, st, g);
   } else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   else
@@ -751,7 +753,7 @@ __device__ __forceinline__ void diag_block_role(double* __restrict__ D, int64_t 
 }
 
 // Trailing update + (workgroup 0) the next panel's diagonal block.
-template <bool PIPE>
+template <bool PIPE, bool CACC>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
   static_assert(sizeof(double) * 2 * 2 * GT * GPITCH >= sizeof(double) * (2 * 64 * 65 + 64 + 128), "LDS of the diagonal role");
@@ -765,7 +767,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
     diag_block_role(g.diagA, g.ldc, g.diag_nbw, g.diag_off, g.diag_info, &lds[0][0][0]);
     return;
   }
-  gemm_block<false, PIPE>(g, lds, (int64_t)blockIdx.x - 1);
+  gemm_block<false, PIPE, CACC>(g, lds, (int64_t)blockIdx.x - 1);
 }
 
 __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
