@@ -88,6 +88,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
  *   gemm.cacc (1)         fused GEMM launches: interior tiles accumulate into C loaded up front (0: load-subtract-store epilogue)
  *   gemm.pipe (0)         fused GEMM launches: operand reads one k-step ahead across the tile boundary
+ *   gemm.commit_ks (12)   fused GEMM launches: 4 = A/B reference with the early LDS commit of the prefetched tile
  *   chol.nb (512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),
  *   chol.lookahead (1)    factorisation schedule (fused_diag = 0: the round-1 second-stream look-ahead schedule)
  *   chol.outer (1024)     panel pairs: K = 2 nb trailing update in two launches (= chol.nb: single panels only)

@@ -38,7 +38,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GBK 16
 #define GPITCH 17
 #ifndef GEMM_COMMIT_KS
-#define GEMM_COMMIT_KS 4   // k-step after which the prefetched tile is written to LDS (0,4,8,12)
+#define GEMM_COMMIT_KS 12  // k-step after which the prefetched tile is written to LDS (0,4,8,12): 12 = as late as possible,
+                           // the global loads of the next tile get the whole tile to arrive (4 -> 12: -1.1 % factorisation time)
 #endif
 #ifndef GEMM_EPI_PIPE
 #define GEMM_EPI_PIPE 0    // 1: software-pipelined epilogue (strip j+1 loads before strip j stores)
@@ -82,7 +83,7 @@ struct GemmArgs {
   int tiles2;
 };
 
-template <bool PIPE, bool CACC>
+template <bool PIPE, bool CACC, int CKS = GEMM_COMMIT_KS>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g);
 
 template <bool FULL>
@@ -122,7 +123,7 @@ __device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid,
 
 // ABL = true only in the ablation instantiation (option gemm.debug != 0): the production kernel carries
 // none of the ablation branches.
-template <bool FULL, bool ABL, bool PIPE = false, bool CACC = true>
+template <bool FULL, bool ABL, bool PIPE = false, bool CACC = true, int CKS = GEMM_COMMIT_KS>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[2][GT * GPITCH],
                                                int64_t row0, int64_t col0) {
   const int dbg = ABL ? g.dbg : 0;
@@ -202,7 +203,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-        if (ks == GEMM_COMMIT_KS && kt + 1 < nk && !(dbg & 2)) {
+        if (ks == (CKS > 8 ? 8 : CKS) && kt + 1 < nk && !(dbg & 2)) {
           // the next tile's global loads were issued ~32 MFMAs ago: write them to the other LDS
           // buffer now so that the stores drain under the remaining MFMAs of this tile
           gemm_store_tile(lds[cur ^ 1][0], tid, ra);
@@ -240,7 +241,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-        if (ks == GEMM_COMMIT_KS && kt + 1 < nk && !(dbg & 2)) {
+        if (ks == CKS && kt + 1 < nk && !(dbg & 2)) {
           // the next tile's global loads were issued ~32 MFMAs ago: write them to the other LDS
           // buffer now so that the stores drain under the remaining MFMAs of this tile
           gemm_store_tile(lds[cur ^ 1][0], tid, ra);
@@ -331,7 +332,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 }
 
 // block index -> tile (XCD-aware 8x8 super tiles: block b runs on XCD b % 8) and the tile's GEMM
-template <bool ABL, bool PIPE = false, bool CACC = true>
+template <bool ABL, bool PIPE = false, bool CACC = true, int CKS = GEMM_COMMIT_KS>
 __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][GT * GPITCH], int64_t b) {
   if (b < g.tiles2) {  // second problem (workgroup-uniform branch)
     const int tn2 = (int)((g.N2 + GT - 1) / GT);
@@ -343,9 +344,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
     const int64_t row0 = ti * GT, col0 = tj * GT;
     const bool full = (row0 + GT <= h.M) && (col0 + GT <= h.N) && ((h.K & (GBK - 1)) == 0) && h.aligned;
     if (full)
-      gemm_tile_body<true, ABL, PIPE, CACC>(h, lds, row0, col0);
+      gemm_tile_body<true, ABL, PIPE, CACC, CKS>(h, lds, row0, col0);
     else
-      gemm_tile_body<false, ABL, PIPE, CACC>(h, lds, row0, col0);
+      gemm_tile_body<false, ABL, PIPE, CACC, CKS>(h, lds, row0, col0);
     if (g.ready && ti < g.ready_rows && tj < g.ready_rows) {
       __threadfence();
       __syncthreads();
@@ -389,9 +390,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
   }
   const bool full = (row0 + GT <= g.M) && (col0 + GT <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
   if (full)
-    gemm_tile_body<true, ABL, PIPE, CACC>(g, lds, row0, col0);
+    gemm_tile_body<true, ABL, PIPE, CACC, CKS>(g, lds, row0, col0);
   else
-    gemm_tile_body<false, ABL, PIPE, CACC>(g, lds, row0, col0);
+    gemm_tile_body<false, ABL, PIPE, CACC, CKS>(g, lds, row0, col0);
   if (g.ready && g.tiles2 == 0 && ti < g.ready_rows && tj < g.ready_rows) {  // publish the tile (release: every thread's stores, then one count)
     __threadfence();
     __syncthreads();
@@ -464,7 +465,9 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
     }
     const dim3 grid((unsigned)(blocks + 1 + g.tiles2));
     const int pipe = ctx_opt_i(ctx, "gemm.pipe", 0), cacc = ctx_opt_i(ctx, "gemm.cacc", 1);
-    if (pipe && cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true>), grid, dim3(256), 0, st, g);
+    const int cks = ctx_opt_i(ctx, "gemm.commit_ks", GEMM_COMMIT_KS);
+    if (!pipe && cacc && cks == 4) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, true, 4>), grid, dim3(256), 0, st, g);
+    else if (pipe && cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true>), grid, dim3(256), 0, st, g);
     else if (pipe) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, false>), grid, dim3(256), 0, st, g);
     else if (cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, true>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, false>), grid, dim3(256), 0, st, g);
@@ -753,7 +756,7 @@ __device__ __forceinline__ void diag_block_role(double* __restrict__ D, int64_t 
 }
 
 // Trailing update + (workgroup 0) the next panel's diagonal block.
-template <bool PIPE, bool CACC>
+template <bool PIPE, bool CACC, int CKS>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
   static_assert(sizeof(double) * 2 * 2 * GT * GPITCH >= sizeof(double) * (2 * 64 * 65 + 64 + 128), "LDS of the diagonal role");
@@ -767,7 +770,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
     diag_block_role(g.diagA, g.ldc, g.diag_nbw, g.diag_off, g.diag_info, &lds[0][0][0]);
     return;
   }
-  gemm_block<false, PIPE, CACC>(g, lds, (int64_t)blockIdx.x - 1);
+  gemm_block<false, PIPE, CACC, CKS>(g, lds, (int64_t)blockIdx.x - 1);
 }
 
 __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
