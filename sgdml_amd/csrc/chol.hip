@@ -41,9 +41,6 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GEMM_COMMIT_KS 12  // k-step after which the prefetched tile is written to LDS (0,4,8,12): 12 = as late as possible,
                            // the global loads of the next tile get the whole tile to arrive (4 -> 12: -1.1 % factorisation time)
 #endif
-#ifndef GEMM_EPI_PIPE
-#define GEMM_EPI_PIPE 0    // 1: software-pipelined epilogue (strip j+1 loads before strip j stores)
-#endif
 
 struct GemmArgs {
   const double* A;
@@ -272,29 +269,6 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
         for (int r = 0; r < 4; ++r) (Ct2 + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff2 + j * 16] = acc[i][j][r];
     return;
   }
-#if GEMM_EPI_PIPE
-  if (FULL) {
-    double cv[2][4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cv[0][i][r] = Cw[(i * 16 + 4 * r) * g.ldc];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j + 1 < 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cv[(j + 1) & 1][i][r] = Cw[(i * 16 + 4 * r) * g.ldc + (j + 1) * 16];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[j & 1][i][r] + acc[i][j][r];
-    }
-    return;
-  }
-#endif
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     double cv[4][4];
