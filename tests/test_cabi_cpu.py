@@ -269,3 +269,24 @@ def test_draw_strat_sample_reproduces_reference_indices():
             assert np.array_equal(np.asarray(idx, dtype=np.int64), g['idx%d' % k]), k
     finally:
         t.__del__()
+
+
+def test_documented_options_match_the_library():
+    """Every option key the library accepts (kKnownOptions, csrc/ctx.hip) is documented in include/gdml_hip.h and every
+    documented key is accepted; every key read with ctx_opt / ctx_opt_i anywhere in csrc/ is a known one."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ctx_src = open(os.path.join(root, 'sgdml_amd', 'csrc', 'ctx.hip')).read()
+    blk = ctx_src[ctx_src.index('kKnownOptions[] = {'):]
+    blk = blk[:blk.index('};')]
+    known = set(re.findall(r'"([a-z_]+\.[a-z0-9_]+)"', blk))
+    hdr = open(os.path.join(root, 'include', 'gdml_hip.h')).read()
+    doc = hdr[hdr.index('Tuning / ablation options of a context'):hdr.index('Unknown keys return GDML_ERR_INVALID')]
+    documented = set(re.findall(r'\b((?:asm|gemm|chol|trsm|trsv|predict|lu|comm|dist|nys)\.[a-z0-9_]+)', doc))
+    assert known == documented, (sorted(known - documented), sorted(documented - known))
+    used = set()
+    csrc = os.path.join(root, 'sgdml_amd', 'csrc')
+    for fn in os.listdir(csrc):
+        if fn.endswith(('.hip', '.h')):
+            used |= set(re.findall(r'ctx_opt(?:_i)?\(\s*ctx\s*,\s*"([^"]+)"', open(os.path.join(csrc, fn)).read()))
+    assert used <= known, sorted(used - known)
