@@ -958,12 +958,6 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * PT_ROWS;
-  if (ABL && (dbg >> 8)) {  // experiment: delay every other group of 2^shift workgroups by n x 8128 cycles
-    const int shift = (dbg >> 8) & 15, nsl = (dbg >> 12) & 15;
-    if ((blockIdx.x >> shift) & 1)
-      for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
   // ---- strip into registers (C layout: row = lk + 4 r + 16 i, col = li + 16 j); two separately named register
   // blocks (an array indexed by the owner test would be demoted to scratch memory)
   d4 accA[2][4], accB[2][4];
