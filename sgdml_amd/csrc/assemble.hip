@@ -583,6 +583,9 @@ int assemble_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int
   TrainSet& ts = ctx->ts;
   if (assemble_wave_applicable(ctx))
     return assemble_wave_launch(ctx, sig, 0, nullptr, nullptr, 0, ts.M, K, ld, 0, ts.M, 1, lam, cyc_W, cyc_rank, cyc_nb);
+  if (ctx_opt_i(ctx, "asm.perm", 1))
+    return assemble_perm_launch(ctx, sig, 0, nullptr, nullptr, 0, ts.M, 0, K, ld, 0, ts.M, 1, lam, cyc_W > 1 ? cyc_W : 0,
+                                cyc_rank, cyc_nb);
   AsmArgs A;
   A.x = ts.x; A.g = ts.g; A.tp = ts.tp; A.perm = ts.perm; A.pinv = ts.pinv;
   A.M = ts.M; A.N = ts.N; A.D = ts.D; A.P = ts.P; A.sig = sig; A.use_E = 0;
@@ -752,6 +755,8 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
     else if (assemble_wave_applicable(ctx))
       rc = assemble_wave_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, ctx->K, ld, i_beg, i_end,
                                 lower_A ? 1 : 0, lam);
+    else if (ctx_opt_i(ctx, "asm.perm", 1))
+      rc = assemble_perm_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, 0, ctx->K, ld, i_beg, i_end, 0, 0.0, 0, 0, 0);
     else
       rc = assemble_dispatch(ctx, A, n_j);
   }
