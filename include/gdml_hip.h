@@ -85,9 +85,12 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   asm.strip (1)         64-column-strip assembly kernel (full-line stores) for P = 1, 11 <= N <= 21, all columns
  *   asm.i_chunk (32)      row points walked by one wavefront of the strip kernel
  *   asm.perm (1)          general assembly kernel (any permutation group, any N): column-atom strips (0: the LDS kernel, N <= 64)
- *   asm.perm_img, asm.perm_gjs (-1 = automatic), asm.perm_pg (0 = automatic), asm.perm_na (3), asm.perm_fast_store (1),
- *   asm.perm_i_chunk (16) its shape: row-point image / G_j strip in LDS, permutations per group, row atoms per wavefront,
- *                         transposed full-line stores, row points per workgroup
+ *   asm.perm_level (-1 = automatic: 0 nothing, 1 row-point image, 2 + G_j strip, 3 + x_j tables resident in LDS),
+ *   asm.perm_debug (0)    timing-only ablation mask of that kernel (results are wrong when set)
+ *   asm.perm_w (0 = automatic: 4 wavefronts per workgroup for N <= 24, else 8), asm.perm_lds_kb (80: per workgroup of 4),
+ *   asm.perm_nimg (0 = automatic), asm.perm_pg (0 = automatic), asm.perm_na (0 = automatic), asm.perm_fast_store (1),
+ *   asm.perm_i_chunk (16) its shape: image buffers, permutations per group, row atoms per wavefront, transposed
+ *                         full-line stores, row points per workgroup
  *   asm.threads, asm.ib, asm.minw, asm.gj_global, asm.j_chunk, asm.debug   LDS-kernel shape / ablations
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
  *   gemm.cacc (1)         fused GEMM launches: interior tiles accumulate into C loaded up front (0: load-subtract-store epilogue)

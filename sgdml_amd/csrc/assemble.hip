@@ -424,19 +424,15 @@ __global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = A.N, D = A.D, N3 = 3 * N;
   double* xq = smem;        // D  (x_jj)
-  double* xi = xq + D;      // D
-  double* gi = xi + D;      // 3D
-  double* dv = gi + 3 * D;  // D
+  double* dv = xq + D;      // D
   double* red = dv + D;     // 32
   const int tid = threadIdx.x, T = blockDim.x, nwaves = T >> 6;
   const int64_t jj = A.jj_list[blockIdx.x];
   const int64_t col = A.out_cols[blockIdx.x];
   const int64_t i = (int64_t)blockIdx.y + A.i0;  // grid.y is tiled by the host (65535 limit)
-  for (int k = tid; k < D; k += T) {
-    xq[k] = A.x[jj * D + k];
-    xi[k] = A.x[i * D + k];
-  }
-  for (int k = tid; k < 3 * D; k += T) gi[k] = A.g[i * 3 * D + k];
+  for (int k = tid; k < D; k += T) xq[k] = A.x[jj * D + k];
+  const double* xi = A.x + i * D;        // row point: descriptor and compressed Jacobian through L1/L2 (any N)
+  const double* gi = A.g + i * 3 * (int64_t)D;
   const double sig = A.sig, inv_sig = 1.0 / sig;
   const double sqrt5 = 2.23606797749978969641;
   const double e_fact = 5.0 / (3.0 * sig * sig * sig);
@@ -767,7 +763,7 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
       E.x = ts.x; E.g = ts.g; E.tp = ts.tp; E.perm = ts.perm; E.pinv = ts.pinv;
       E.M = M; E.N = N; E.D = ts.D; E.P = ts.P; E.sig = sig;
       E.jj_list = d_ep; E.out_cols = d_ec; E.K = ctx->K; E.ld = ld;
-      size_t lds = (size_t)(6 * ts.D + 32) * 8;
+      size_t lds = (size_t)(2 * ts.D + 32) * 8;
       hipFuncSetAttribute((const void*)ecol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds);
       for (int64_t i0 = 0; i0 < M; i0 += 65535) {  // grid.y limit

@@ -14,15 +14,19 @@
 //     aligned) -- it straddles NQ column points -- and walks over row points i;
 //   * every wavefront has lane = column atom (j, b) with its 3 columns, so that G_i(a, pi^-1 b) and v_p[a] are read
 //     once for 3 x 3 outputs (the LDS read rate, not the fp64 rate, bounds a one-column-per-lane mapping);
-//   * the W wavefronts split the ROW atoms (a = k W + w): 9 NA accumulators per lane, summed over p in registers;
+//   * the 8 wavefronts split the ROW atoms (a = k 8 + w): 9 NA accumulators per lane, summed over p in registers;
 //   * per row point and group of PG permutations two phases, one barrier each:
-//       V  (tasks spread over the wavefronts)  V12(p, pass): lane = (column point q, row atom a): v_p, partial |d_p|^2
+//       V  (tasks spread over the wavefronts)  V12(p, pass): lane = (column point q, row atom a): v_p, |d_p|^2 and from
+//                                                            it the Matern scalars of (p, q)
 //                                              V3(p):        lane = column atom: u_p (3), dg_p (3 x 3)      -> LDS
-//       O  every wavefront, its own row atoms:  acc[a] += beta v_p[a] (x) u_p + (-c_p) G_i(a,a') (x) G_j(b, pi a) + [a = a'] (-c_p) dg_p
-//   * finished rows are transposed through a per-wavefront LDS row so that every store instruction writes 64 consecutive
-//     doubles (full cache lines; the pattern of assemble_strip.hip).
-// Row-point image (GD_i, XF_i) and the strip's G_j table live in LDS when they fit (IMG / GJS), otherwise they are read
-// through L1/L2 from the dense tables (any N up to GDML_MAX_ATOMS; more than W NA row atoms take several rounds).
+//       O  every wavefront, its own row atoms:  acc[a] += beta v_p[a] (x) u_p + (-c_p) G_i(a,a') (x) G_j(b, pi a)
+//                                               and the one row atom a = pi^-1 b gets (-c_p) dg_p
+//   * finished rows are transposed through LDS (three rows at a time) so that every store instruction writes 64
+//     consecutive doubles (full cache lines; the pattern of assemble_strip.hip).
+// Everything an inner loop reads comes from LDS when it fits -- row-point image (GD_i, XF_i: IMG), the strip's G_j
+// table (GJS), its x_j tables (JX) -- otherwise through L1/L2 from the dense tables (any N up to GDML_MAX_ATOMS;
+// more than 8 NA row atoms take several rounds).  Permutation rows are held one entry per lane and read with
+// v_readlane (wave-uniform index), so no inner loop has an index load in its dependency chain.
 #include "common.h"
 
 struct PermArgs {
@@ -36,38 +40,63 @@ struct PermArgs {
   int use_E;             // also write the energy-constraint row K[3N M + i, .]  (train.py:235-248)
   const int32_t* jlist;  // virtual column point -> training point (null: j0 + v)
   const int32_t* colmap; // (n_j, 3N) output column or -1 (null: col0 + 3N v + c)
-  int64_t j0, n_j, col0, n_cols;
+  int64_t j0, n_j, col0;
   int64_t i_beg, i_end;  // row points of this launch; rows are written relative to i_beg
   int i_chunk;
   int lower;             // store -K + lam I, only blocks j <= i (dense full column range)
   double lam;
   int cyc_W, cyc_rank, cyc_nb;  // block-row-cyclic local layout of the distributed Cholesky (implies lower)
   int fast_store;        // dense columns, plain row layout: transposed full-line stores
-  int NQ, PG, npass;
-  int o_SG, o_GjS, o_vs, o_part, o_scal, o_ud, o_tr, o_perm;  // LDS offsets in doubles
+  int dbg;               // timing-only ablation mask (asm.perm_debug): 1 no stores, 2 no V tasks, 4 no O phase, 8 no image prefetch
+  int NQ, PG, npass, n_img;
+  int o_IM, o_GjS, o_XjS, o_Xq, o_vs, o_part, o_scal, o_ud, o_tr, o_pinv;  // LDS offsets in doubles
   double* K;
   int64_t ld;
 };
 
-constexpr int PERM_W = 8;  // wavefronts per workgroup
 
-// NA: row atoms per wavefront and round (3: N <= 24, two workgroups per CU; 6: N <= 48 in one round)
-template <int NA, bool IMG, bool GJS>
-__global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs A) {
+// entry m of a permutation row held one entry per lane (row0: 0..63, row1: 64..127, only for BIG molecules); m is
+// wave-uniform.  Branch-free: a branch here keeps the compiler from unrolling / pipelining the loops around it.
+template <bool BIG>
+__device__ __forceinline__ int perm_at(int row0, int row1, int m) {
+  if (!BIG) return __builtin_amdgcn_readlane(row0, m);
+  const int lo = __builtin_amdgcn_readlane(row0, m & 63), hi = __builtin_amdgcn_readlane(row1, m & 63);
+  return (m < 64) ? lo : hi;
+}
+
+// inclusive scan inside segments of consecutive lanes; pos = position of the lane in its segment.  Only additions of
+// the segment's own terms (a scan over the whole wavefront and a difference would cancel: |d|^2 = 0 must stay 0)
+__device__ __forceinline__ double seg_incl_scan(double v, int pos) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double t = __shfl_up(v, off, 64);
+    if (pos >= off) v += t;
+  }
+  return v;
+}
+
+// W: wavefronts per workgroup; NA: row atoms per wavefront and round (W NA >= N: one round); BIG: N > 64.
+// Shapes built: (W, NA) = (4, 6): N <= 24, two independent workgroups per CU when the LDS allows; (8, 3): N <= 24, one
+// workgroup; (8, 6): N <= 48 in one round, larger molecules in several.
+template <int W, int NA, bool IMG, bool GJS, bool JX, bool BIG>
+__global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int W = PERM_W;
   constexpr int T = 64 * W;
   const int N = A.N, N3 = 3 * N, NN = N * N, P = A.P, NQ = A.NQ, PG = A.PG, npass = A.npass;
-  // image of the row point (IMG): [G | X] = [m][b][al] | [m][b], two buffers of 4 N^2 doubles
-  double* const IM0 = smem + A.o_SG;
+  const int SEG = BIG ? (N + 63) >> 6 : 1;  // 64-atom segments of a point (V12 passes of large molecules)
+  const int ppp = BIG ? 1 : 64 / N;          // whole column points per V12 pass (N <= 64)
+  // image of the row point (IMG): [G | X] = [m][b][al] | [m][b]; one or two buffers of 4 N^2 doubles
+  double* const IM0 = smem + A.o_IM;
   double* const GjS = smem + A.o_GjS;    // [m][lane][be] G_j(b,m) of the lane's column atom (GJS)
+  double* const XjS = smem + A.o_XjS;    // [m][lane]     x_j[pair(b,m)]                       (JX)
+  double* const Xq = smem + A.o_Xq;      // [q][m][b]     dense x of the strip's column points  (JX)
   double* const vs = smem + A.o_vs;      // [pl][q][a][al]
-  double* const part = smem + A.o_part;  // [pl][q][a]
-  double* const scal = smem + A.o_scal;  // [w][pl][q][3]   beta, -c, E-row coefficient
+  double* const part = smem + A.o_part;  // [pl][q][seg]  |d|^2 pieces (N > 64)
+  double* const scal = smem + A.o_scal;  // [pl][q][3]    beta, -c, E-row coefficient   (N > 64: one copy per wavefront)
   double* const ud = smem + A.o_ud;      // [pl][12][lane]  u (3), dg (3 x 3)
-  double* const tr = smem + A.o_tr;      // [w][192]        transposed output row (aliases the V-phase results)
-  int* const permS = reinterpret_cast<int*>(smem + A.o_perm);
-  int* const pinvS = permS + P * N;
+  double* const tr = smem + A.o_tr;      // [w][3][192]   transposed output rows (aliases the V-phase results)
+  int* const pinvS = reinterpret_cast<int*>(smem + A.o_pinv);  // [P][N]
+  int* const permS = pinvS + P * N;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,6 +110,7 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
   const int q = jv - jv0;
   const int jpt = A.jlist ? A.jlist[jv] : (int)A.j0 + jv;
   const bool lower = A.lower != 0;
+  const bool two_img = A.n_img == 2;
 
   const int64_t i_lo = (lower ? (int64_t)jv0 : A.i_beg) + (int64_t)blockIdx.y * A.i_chunk;
   const int64_t i_top = lower ? A.M : A.i_end;
@@ -94,8 +124,8 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
 
   // ---- resident tables: permutations, the strip's column-atom data
   for (int e = tid; e < P * N; e += T) {
-    permS[e] = A.perm[e];
     pinvS[e] = A.pinv[e];
+    permS[e] = A.perm[e];
   }
   if (GJS) {
     const double* gd = A.GD + ((int64_t)jpt * NN + b) * 3;
@@ -103,6 +133,17 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
       GjS[(m * 64 + lane) * 3 + 0] = gd[m * N3 + 0];
       GjS[(m * 64 + lane) * 3 + 1] = gd[m * N3 + 1];
       GjS[(m * 64 + lane) * 3 + 2] = gd[m * N3 + 2];
+    }
+  }
+  if (JX) {
+    const double* xf = A.XF + (int64_t)jpt * NN + b;
+    for (int m = w; m < N; m += W) XjS[m * 64 + lane] = xf[m * N];
+    for (int e = tid; e < NQ * NN; e += T) {
+      const int qq = e / NN;
+      int64_t jvq = jv0 + qq;
+      if (jvq > A.n_j - 1) jvq = A.n_j - 1;
+      const int64_t jq = A.jlist ? (int64_t)A.jlist[jvq] : A.j0 + jvq;
+      Xq[e] = A.XF[jq * NN + (e - qq * NN)];
     }
   }
   if (IMG) {
@@ -129,12 +170,13 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
     tpt[t] = (int)(c / N3);
   }
 
-  constexpr int NPF = IMG ? (4 * (W * NA) * (W * NA) + T - 1) / T : 1;  // 4 N^2 doubles of the next image over T threads
+  constexpr bool PF_REG = IMG && NA == 3;  // next image through registers underneath the first V phase (when they are there)
+  constexpr int NPF = PF_REG ? (4 * (W * NA) * (W * NA) + T - 1) / T : 1;
   const int n_rounds = (N + W * NA - 1) / (W * NA);
   const int n_groups = (P + PG - 1) / PG;
 
   for (int64_t i = i_lo; i < i_hi; ++i) {
-    const int64_t row0 = i * N3;                 // first row of the point in the full matrix
+    const int64_t row0 = i * N3;  // first row of the point in the full matrix
     // transposed-row stores: which of the lane's three columns are written for this row point, and where the matrix
     // diagonal crosses them (lower form: + lam)
     bool tok[3];
@@ -145,7 +187,7 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
       dcol[t] = lower ? (int)((int64_t)tcol[t] - row0) : -1;
     }
     const double lamv = lower ? A.lam : 0.0;
-    const int64_t lrow0 = row0 - A.i_beg * N3;   // ... in the stored matrix (plain layout)
+    const int64_t lrow0 = row0 - A.i_beg * N3;  // ... in the stored matrix (plain layout)
     int coff0 = 0;
     int64_t clrow0 = 0, clrow1 = 0;
     bool cmine0 = true, cmine1 = true;
@@ -158,7 +200,7 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
       clrow1 = ((cb0 + 1) / A.cyc_W) * A.cyc_nb;
       const bool spans = coff0 + N3 > A.cyc_nb;
       if (!(cmine0 || (spans && cmine1))) {  // no row of this point on this rank
-        if (IMG && i + 1 < i_hi) {  // keep the image in step
+        if (IMG && i + 1 < i_hi) {           // keep the image in step
           __syncthreads();
           const double* gi = A.GD + (i + 1) * (int64_t)NN * 3;
           const double* xi = A.XF + (i + 1) * (int64_t)NN;
@@ -172,9 +214,10 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
     __syncthreads();  // image of point i (and the resident tables) visible; the previous point's LDS readers are done
     const double* const SG = IM0 + cur * 4 * NN;
     const double* const SX = SG + 3 * NN;
-    double* const IMn = IM0 + (cur ^ 1) * 4 * NN;  // next point's image, filled during the first V phase
+    double* const IMn = IM0 + (two_img ? (cur ^ 1) : 0) * 4 * NN;  // where the next point's image goes
     const double* const GDi = A.GD + i * (int64_t)NN * 3;
     const double* const XFi = A.XF + i * (int64_t)NN;
+    const int64_t i_next = (i + 1 < i_hi) ? i + 1 : i;
 
     for (int r = 0; r < n_rounds; ++r) {
       double acc[NA][3][3];
@@ -188,15 +231,11 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
         const int npg = (P - g0 < PG) ? P - g0 : PG;
         if (r == 0 || n_groups > 1) {
           // ================= phase V
-          // the next row point's image travels global -> registers -> other LDS buffer: underneath the first V phase when
-          // the registers are there (NA = 3), in batches ahead of it otherwise
-          constexpr bool PF_REG = IMG && NA == 3;
-          double pf[PF_REG ? NPF : 1];
-          const bool do_pf = IMG && g0 == 0;
+          double pf[NPF];
+          const bool do_pf = IMG && two_img && g0 == 0 && !(A.dbg & 8);
           if (do_pf) {
-            const int64_t in = (i + 1 < i_hi) ? i + 1 : i;
-            const double* gi = A.GD + in * (int64_t)NN * 3;
-            const double* xi = A.XF + in * (int64_t)NN;
+            const double* gi = A.GD + i_next * (int64_t)NN * 3;
+            const double* xi = A.XF + i_next * (int64_t)NN;
             if (PF_REG) {
 #pragma unroll
               for (int t = 0; t < NPF; ++t) {
@@ -208,55 +247,86 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
               for (int e = tid; e < 4 * NN; e += T) IMn[e] = (e < 3 * NN) ? gi[e] : xi[e - 3 * NN];
             }
           }
-          const int ntask = npg * (npass + 1);
+          const int ntask = (A.dbg & 2) ? 0 : npg * (npass + 1);
           for (int t = w; t < ntask; t += W) {
             const int pl = t / (npass + 1), kind = t - pl * (npass + 1);
             const int p = g0 + pl;
-            const int* pm_tab = permS + p * N;
-            const int* pi_tab = pinvS + p * N;
             if (kind < npass) {
-              // ---- V12: lane = (column point qq, row atom a)
-              const int idx = kind * 64 + lane;
-              const int qq = idx / N;
-              const int a = idx - qq * N;
+              // ---- V12: lane = (column point qq, row atom a); whole points per pass (N <= 64) or 64-atom segments
+              int qq, a, seg = 0;
+              if (!BIG) {
+                const int ql = lane / N;
+                qq = kind * ppp + ql;
+                a = lane - ql * N;
+                if (ql >= ppp) qq = NQ;  // idle lanes
+              } else {
+                qq = kind / SEG;
+                seg = kind - qq * SEG;
+                a = 64 * seg + lane;
+              }
               const int jvq = jv0 + qq;
-              if (qq < NQ && jvq < A.n_j) {
-                const int64_t jq = A.jlist ? (int64_t)A.jlist[jvq] : A.j0 + jvq;
-                const double* xfj = A.XF + jq * NN + pm_tab[a];
-                double v0 = 0.0, v1 = 0.0, v2 = 0.0, nn = 0.0;
+              const bool ok = qq < NQ && a < N && jvq < A.n_j;
+              const int pr0 = (lane < N) ? permS[p * N + lane] : 0;
+              const int pr1 = (BIG && lane + 64 < N) ? permS[p * N + 64 + lane] : 0;
+              const int ac = ok ? a : 0, qc = ok ? qq : 0;
+              const int pa = permS[p * N + ac];
+              const int jvc = (jvq < A.n_j) ? jvq : (int)A.n_j - 1;
+              const int64_t jq = A.jlist ? (int64_t)A.jlist[jvc] : A.j0 + jvc;
+              const double* xjg = A.XF + jq * NN + pa;  // x_j[pair(pi a, .)] (global; JX: the LDS copy)
+              const double* xjl = Xq + qc * NN + pa;
+              double v0 = 0.0, v1 = 0.0, v2 = 0.0, nn = 0.0;
 #pragma unroll 4
-                for (int m = 0; m < N; ++m) {
-                  const int pm = pm_tab[m];
-                  const double xi = IMG ? SX[m * N + a] : XFi[m * N + a];
-                  const double xj = xfj[pm * N];
-                  const double d = xi - xj;
-                  const double* g = IMG ? SG + (m * N + a) * 3 : GDi + (m * N + a) * 3;
-                  nn += d * d;
-                  v0 += d * g[0];
-                  v1 += d * g[1];
-                  v2 += d * g[2];
-                }
+              for (int m = 0; m < N; ++m) {
+                const int pm = perm_at<BIG>(pr0, pr1, m);
+                const double xi = IMG ? SX[m * N + ac] : XFi[m * N + ac];
+                const double xj = JX ? xjl[pm * N] : xjg[pm * N];
+                const double* g = IMG ? SG + (m * N + ac) * 3 : GDi + (m * N + ac) * 3;
+                const double d = xi - xj;
+                nn += d * d;
+                v0 += d * g[0];
+                v1 += d * g[1];
+                v2 += d * g[2];
+              }
+              if (!ok) nn = 0.0;
+              if (ok) {
                 double* dst = vs + ((pl * NQ + qq) * N + a) * 3;
                 dst[0] = v0;
                 dst[1] = v1;
                 dst[2] = v2;
-                part[(pl * NQ + qq) * N + a] = nn;
+              }
+              // |d_p|^2 of every point of the pass (segmented sum over its N lanes), then the Matern scalars
+              if (!BIG) {
+                const double nrm2 = seg_incl_scan(nn, a);  // complete in the lane of the point's last atom
+                if (ok && a == N - 1) {
+                  const double nrm = sqrt5 * sqrt(0.5 * nrm2);
+                  const double ex = exp(-nrm * inv_sig);
+                  const double bp = ex * base_div;
+                  double* sc = scal + (pl * NQ + qq) * 3;
+                  sc[0] = 5.0 * bp;
+                  sc[1] = -(sig * sig + sig * nrm) * bp;
+                  sc[2] = -e_fact * (nrm + sig) * ex;
+                }
+              } else {
+                const double tot = wave_sum(nn);
+                if (lane == 0 && qq < NQ) part[(pl * NQ + qq) * SEG + seg] = tot;
               }
             } else {
               // ---- V3: lane = column atom (j, b)
-              const int ap = pi_tab[b];
+              const int pi0 = (lane < N) ? pinvS[p * N + lane] : 0;
+              const int pi1 = (BIG && lane + 64 < N) ? pinvS[p * N + 64 + lane] : 0;
+              const int ap = pinvS[p * N + b];
               const double* xfj = A.XF + (int64_t)jpt * NN + b;
               const double* gdj = A.GD + ((int64_t)jpt * NN + b) * 3;
               double u0 = 0.0, u1 = 0.0, u2 = 0.0;
               double d00 = 0.0, d01 = 0.0, d02 = 0.0, d10 = 0.0, d11 = 0.0, d12 = 0.0, d20 = 0.0, d21 = 0.0, d22 = 0.0;
-#pragma unroll 2
+#pragma unroll 4
               for (int mp = 0; mp < N; ++mp) {
-                const int mi = pi_tab[mp];
+                const int mi = perm_at<BIG>(pi0, pi1, mp);
                 const double xi = IMG ? SX[mi * N + ap] : XFi[mi * N + ap];
-                const double xj = xfj[mp * N];
-                const double d = xi - xj;
+                const double xj = JX ? XjS[mp * 64 + lane] : xfj[mp * N];
                 const double* rj = GJS ? GjS + (mp * 64 + lane) * 3 : gdj + mp * N3;
                 const double* gi = IMG ? SG + (mi * N + ap) * 3 : GDi + (mi * N + ap) * 3;
+                const double d = xi - xj;
                 const double r0 = rj[0], r1 = rj[1], r2 = rj[2];
                 const double g0v = gi[0], g1v = gi[1], g2v = gi[2];
                 u0 += d * r0; u1 += d * r1; u2 += d * r2;
@@ -280,30 +350,31 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
           }
           __syncthreads();
         }
-        // ================= Matern scalars of the (pl, q) pairs: every wavefront for itself
-        double* const sc_w = scal + (size_t)w * PG * NQ * 3;
-        for (int t = lane; t < npg * NQ; t += 64) {
-          const int pl = t / NQ, qq = t - pl * NQ;
-          double nrm2 = 0.0;
-          if (jv0 + qq < A.n_j) {
-            const double* pp = part + (pl * NQ + qq) * N;
-            for (int a = 0; a < N; ++a) nrm2 += pp[a];
+        // ================= large molecules: the Matern scalars from the segment sums, every wavefront for itself
+        const double* sc_base = scal;
+        if (BIG) {
+          double* const sc_w = scal + (size_t)w * PG * NQ * 3;
+          for (int t = lane; t < npg * NQ; t += 64) {
+            double nrm2 = 0.0;
+            for (int sg = 0; sg < SEG; ++sg) nrm2 += part[t * SEG + sg];
+            const double nrm = sqrt5 * sqrt(0.5 * nrm2);
+            const double ex = exp(-nrm * inv_sig);
+            const double bp = ex * base_div;
+            sc_w[t * 3 + 0] = 5.0 * bp;
+            sc_w[t * 3 + 1] = -(sig * sig + sig * nrm) * bp;
+            sc_w[t * 3 + 2] = -e_fact * (nrm + sig) * ex;
           }
-          const double nrm = sqrt5 * sqrt(0.5 * nrm2);
-          const double ex = exp(-nrm * inv_sig);
-          const double bp = ex * base_div;
-          sc_w[t * 3 + 0] = 5.0 * bp;
-          sc_w[t * 3 + 1] = -(sig * sig + sig * nrm) * bp;
-          sc_w[t * 3 + 2] = -e_fact * (nrm + sig) * ex;
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+          sc_base = sc_w;
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
         // ================= phase O: this wavefront's row atoms, all permutations of the group
-        for (int pl = 0; pl < npg; ++pl) {
+        for (int pl = 0; pl < ((A.dbg & 4) ? 0 : npg); ++pl) {
           const int p = g0 + pl;
-          const int* pm_tab = permS + p * N;
+          const int pr0 = (lane < N) ? permS[p * N + lane] : 0;
+          const int pr1 = (BIG && lane + 64 < N) ? permS[p * N + 64 + lane] : 0;
           const int ap = pinvS[p * N + b];
-          const double* sc = sc_w + (pl * NQ + q) * 3;
+          const double* sc = sc_base + (pl * NQ + q) * 3;
           const double beta = sc[0], cn = sc[1];
           const double* udp = ud + pl * 12 * 64 + lane;
           const double ur0 = udp[0], ur1 = udp[64], ur2 = udp[128];
@@ -324,77 +395,100 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
               }
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
           if (A.use_E && w == 0 && r == 0) {
             const double ce = sc[2];
             erow[0] += ce * ur0; erow[1] += ce * ur1; erow[2] += ce * ur2;
           }
           const double* vq = vs + (pl * NQ + q) * N * 3;
           const double* gjg = A.GD + ((int64_t)jpt * NN + b) * 3;
+          const double* gib = IMG ? SG + ap * N3 : GDi + ap * N3;  // G_i(., pi^-1 b): [a][al]
 #pragma unroll
-          for (int k = 0; k < NA; ++k) {
-            const int a = (r * NA + k) * W + w;
-            if (a < N) {
-              const int pa = pm_tab[a];
-              const double* vv = vq + a * 3;
-              const double* gi = IMG ? SG + (ap * N + a) * 3 : GDi + (ap * N + a) * 3;
-              const double* gj = GJS ? GjS + (pa * 64 + lane) * 3 : gjg + pa * N3;
-              const double v0 = vv[0], v1 = vv[1], v2 = vv[2];
-              const double g0v = gi[0], g1v = gi[1], g2v = gi[2];
-              const double w0 = cn * gj[0], w1 = cn * gj[1], w2 = cn * gj[2];
-              acc[k][0][0] += v0 * U0 + g0v * w0;
-              acc[k][0][1] += v0 * U1 + g0v * w1;
-              acc[k][0][2] += v0 * U2 + g0v * w2;
-              acc[k][1][0] += v1 * U0 + g1v * w0;
-              acc[k][1][1] += v1 * U1 + g1v * w1;
-              acc[k][1][2] += v1 * U2 + g1v * w2;
-              acc[k][2][0] += v2 * U0 + g2v * w0;
-              acc[k][2][1] += v2 * U1 + g2v * w1;
-              acc[k][2][2] += v2 * U2 + g2v * w2;
+          for (int h = 0; h < NA / 3; ++h) {
+            // operands of three row atoms in one batch of loads, then their 81 multiply-adds
+            double vv[3][3], gi[3][3], gj[3][3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+              const int a0 = (r * NA + 3 * h + kk) * W + w;
+              const int a = (a0 < N) ? a0 : N - 1;
+              const int pa = perm_at<BIG>(pr0, pr1, a);
+              const double* gjp = GJS ? GjS + (pa * 64 + lane) * 3 : gjg + pa * N3;
+#pragma unroll
+              for (int c3 = 0; c3 < 3; ++c3) {
+                vv[kk][c3] = vq[a * 3 + c3];
+                gi[kk][c3] = gib[a * 3 + c3];
+                gj[kk][c3] = gjp[c3];
+              }
             }
-            __builtin_amdgcn_sched_barrier(0);  // bounds the hoisting of the next atom's LDS reads (register pressure)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+              const int k = 3 * h + kk;
+              const int a0 = (r * NA + k) * W + w;
+              if (a0 < N) {
+                const double w0 = cn * gj[kk][0], w1 = cn * gj[kk][1], w2 = cn * gj[kk][2];
+#pragma unroll
+                for (int al = 0; al < 3; ++al) {
+                  acc[k][al][0] = fma(gi[kk][al], w0, fma(vv[kk][al], U0, acc[k][al][0]));
+                  acc[k][al][1] = fma(gi[kk][al], w1, fma(vv[kk][al], U1, acc[k][al][1]));
+                  acc[k][al][2] = fma(gi[kk][al], w2, fma(vv[kk][al], U2, acc[k][al][2]));
+                }
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
         __syncthreads();  // V-phase results of this group are free
       }
 
-      // ---- write the rows of this round
-      double* const trw = tr + w * 192;
+      // ---- write the rows of this round: three rows (one row atom) per LDS round trip
+      double* const trw = tr + w * 3 * 192;
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
         const int a = (r * NA + k) * W + w;
-        if (a < N) {
+        if (a < N && (!(A.dbg & 1) || acc[k][0][0] == 1.2345e-300)) {
+          if (A.fast_store) {
 #pragma unroll
-          for (int al = 0; al < 3; ++al) {
-            const int rr = 3 * a + al;                 // row inside the point
-            const int64_t grow = row0 + rr;            // row of the full matrix
-            int64_t lrow = lrow0 + rr;
-            bool row_ok = true;
-            if (A.cyc_W > 0) {  // the point's rows lie in row block cb0 (from offset coff0) and, past its end, in cb0 + 1
-              const bool second = coff0 + rr >= A.cyc_nb;
-              row_ok = second ? cmine1 : cmine0;
-              lrow = second ? clrow1 + (coff0 + rr - A.cyc_nb) : clrow0 + coff0 + rr;
+            for (int al = 0; al < 3; ++al) {
+#pragma unroll
+              for (int be = 0; be < 3; ++be) trw[al * 192 + 3 * lane + be] = lower ? -acc[k][al][be] : acc[k][al][be];
             }
-            double o0 = acc[k][al][0], o1 = acc[k][al][1], o2 = acc[k][al][2];
-            if (lower) { o0 = -o0; o1 = -o1; o2 = -o2; }
-            if (A.fast_store) {
-              trw[3 * lane + 0] = o0;
-              trw[3 * lane + 1] = o1;
-              trw[3 * lane + 2] = o2;
-              __builtin_amdgcn_s_waitcnt(0xc07f);
-              __builtin_amdgcn_wave_barrier();
-              double* dst = A.K + lrow * A.ld;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            double val[3][3];
+#pragma unroll
+            for (int al = 0; al < 3; ++al)
+#pragma unroll
+              for (int t = 0; t < 3; ++t) val[al][t] = trw[al * 192 + 64 * t + lane];
+#pragma unroll
+            for (int al = 0; al < 3; ++al) {
+              const int rr = 3 * a + al;
+              double* dst = A.K + (lrow0 + rr) * A.ld;
 #pragma unroll
               for (int t = 0; t < 3; ++t) {
-                const double val = trw[64 * t + lane] + ((dcol[t] == rr) ? lamv : 0.0);
-                if (tok[t]) dst[(unsigned)tcol[t]] = val;
+                const double o = val[al][t] + ((dcol[t] == rr) ? lamv : 0.0);
+                if (tok[t]) dst[(unsigned)tcol[t]] = o;
               }
-              __builtin_amdgcn_wave_barrier();
-            } else if (row_ok && (!lower || jv <= i)) {
-              double* dst = A.K + lrow * A.ld;
-              if (outcol[0] >= 0) dst[outcol[0]] = o0 + ((lower && (int64_t)outcol[0] == grow) ? A.lam : 0.0);
-              if (outcol[1] >= 0) dst[outcol[1]] = o1 + ((lower && (int64_t)outcol[1] == grow) ? A.lam : 0.0);
-              if (outcol[2] >= 0) dst[outcol[2]] = o2 + ((lower && (int64_t)outcol[2] == grow) ? A.lam : 0.0);
+            }
+            __builtin_amdgcn_wave_barrier();
+          } else {
+#pragma unroll
+            for (int al = 0; al < 3; ++al) {
+              const int rr = 3 * a + al;        // row inside the point
+              const int64_t grow = row0 + rr;   // row of the full matrix
+              int64_t lrow = lrow0 + rr;
+              bool row_ok = true;
+              if (A.cyc_W > 0) {  // the point's rows lie in row block cb0 (from offset coff0) and, past its end, in cb0 + 1
+                const bool second = coff0 + rr >= A.cyc_nb;
+                row_ok = second ? cmine1 : cmine0;
+                lrow = second ? clrow1 + (coff0 + rr - A.cyc_nb) : clrow0 + coff0 + rr;
+              }
+              if (row_ok && (!lower || jv <= i)) {
+                double* dst = A.K + lrow * A.ld;
+#pragma unroll
+                for (int be = 0; be < 3; ++be) {
+                  const double o = (lower ? -acc[k][al][be] : acc[k][al][be]) + ((lower && (int64_t)outcol[be] == grow) ? A.lam : 0.0);
+                  if (outcol[be] >= 0) dst[outcol[be]] = o;
+                }
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -407,43 +501,55 @@ __global__ void __launch_bounds__(64 * PERM_W, 2) assemble_perm_kernel(PermArgs 
         if (outcol[2] >= 0) dst[outcol[2]] = erow[2];
       }
     }
-    if (IMG) cur ^= 1;
+    if (IMG) {
+      if (two_img) cur ^= 1;
+      else if (i + 1 < i_hi) {  // single buffer: every reader of the image passed the last barrier
+        const double* gi = A.GD + i_next * (int64_t)NN * 3;
+        const double* xi = A.XF + i_next * (int64_t)NN;
+#pragma unroll 6
+        for (int e = tid; e < 4 * NN; e += T) IM0[e] = (e < 3 * NN) ? gi[e] : xi[e - 3 * NN];
+      }
+    }
   }
 }
 
 int build_dense_tables(gdml_ctx* ctx);
 
-// LDS layout for one choice of (W, IMG, GJS, PG); returns the byte size
-static size_t perm_layout(int N, int P, int NA, bool img, bool gjs, int PG, PermArgs* A) {
-  const int W = PERM_W;
+// LDS layout for one choice of what is resident; returns the byte size
+static size_t perm_layout(int N, int P, int W, int NA, int n_img, bool gjs, bool jx, int PG, PermArgs* A) {
   const int NN = N * N;
   const int NQ = (62 + N) / N + 1;
+  const int SEG = (N + 63) / 64;
   int o = 0;
-  A->o_SG = o; o += img ? 8 * NN : 0;  // two buffers of [G | X]
+  A->o_IM = o; o += n_img * 4 * NN;
   A->o_GjS = o; o += gjs ? N * 64 * 3 : 0;
+  A->o_XjS = o; o += jx ? N * 64 : 0;
+  A->o_Xq = o; o += jx ? NQ * NN : 0;
   const int aux0 = o;
   A->o_vs = o; o += PG * NQ * N * 3;
-  A->o_part = o; o += PG * NQ * N;
   A->o_ud = o; o += PG * 12 * 64;
-  if (N <= W * NA) {  // one round per row point: the transposed rows alias vs | part | ud (free after the last O phase)
+  if (N <= W * NA) {  // one round per row point: the transposed rows alias vs | ud (free after the last O phase)
     A->o_tr = aux0;
-    if (o - aux0 < W * 192) o = aux0 + W * 192;
+    if (o - aux0 < W * 3 * 192) o = aux0 + W * 3 * 192;
   } else {            // several rounds reuse the V-phase results: own buffer
-    A->o_tr = o; o += W * 192;
+    A->o_tr = o; o += W * 3 * 192;
   }
-  A->o_scal = o; o += W * PG * NQ * 3;
+  A->o_part = o; o += PG * NQ * SEG;
+  A->o_scal = o; o += (N > 64 ? W : 1) * PG * NQ * 3;
   o = (o + 1) & ~1;
-  A->o_perm = o; o += (2 * P * N + 1) / 2;
+  A->o_pinv = o; o += (2 * P * N + 1) / 2;
   A->NQ = NQ;
   A->PG = PG;
-  A->npass = (NQ * N + 63) / 64;
+  A->n_img = n_img;
+  A->npass = (N <= 64) ? (NQ + (64 / N) - 1) / (64 / N) : NQ * SEG;
   return (size_t)o * 8;
 }
 
-template <int NA, bool IMG, bool GJS>
+template <int W, int NA, bool IMG, bool GJS, bool JX, bool BIG>
 static void perm_launch_t(gdml_ctx* ctx, const PermArgs& A, dim3 grid, size_t lds) {
-  hipFuncSetAttribute((const void*)assemble_perm_kernel<NA, IMG, GJS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((assemble_perm_kernel<NA, IMG, GJS>), grid, dim3(64 * PERM_W), lds, ctx->stream, A);
+  (void)hipFuncSetAttribute((const void*)assemble_perm_kernel<W, NA, IMG, GJS, JX, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((assemble_perm_kernel<W, NA, IMG, GJS, JX, BIG>), grid, dim3(64 * W), lds, ctx->stream, A);
 }
 
 // Launch over the column points [0, n_j) of (jlist | j0 + v) and the row points [i_beg, i_end).
@@ -462,46 +568,54 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   memset(&A, 0, sizeof(A));
   A.XF = ts.XF; A.GD = ts.GD; A.perm = ts.perm; A.pinv = ts.pinv;
   A.M = ts.M; A.N = N; A.P = P; A.sig = sig; A.use_E = use_E;
-  A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.n_j = n_j; A.col0 = col0; A.n_cols = n_j * 3 * N;
+  A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.n_j = n_j; A.col0 = col0;
   A.i_beg = i_beg; A.i_end = i_end; A.lower = (lower || cyc_W > 0) ? 1 : 0; A.lam = lam;
   A.cyc_W = cyc_W; A.cyc_rank = cyc_rank; A.cyc_nb = cyc_nb;
   A.K = K; A.ld = ld;
+  A.dbg = ctx_opt_i(ctx, "asm.perm_debug", 0);
   A.fast_store = (!d_colmap && cyc_W == 0 && (col0 % 16) == 0 && ctx_opt_i(ctx, "asm.perm_fast_store", 1)) ? 1 : 0;
 
-  // ---- shape: wavefronts per workgroup, what lives in LDS, permutations per group
-  const int W = PERM_W;
-  const int NA = (N <= 3 * W && ctx_opt_i(ctx, "asm.perm_na", 3) == 3) ? 3 : 6;
-  const bool img_ok = N <= W * NA;
-  int img = 0, gjs = 0, PG = 0;
-  // options: asm.perm_img / asm.perm_gjs (0 / 1 force, -1 automatic), asm.perm_pg (permutations per group, 0 automatic)
-  const int opt_gjs = ctx_opt_i(ctx, "asm.perm_gjs", -1), opt_img = ctx_opt_i(ctx, "asm.perm_img", -1);
-  const int opt_pg = ctx_opt_i(ctx, "asm.perm_pg", 0);
-  int pg_max = P < 8 ? P : 8, pg_want = P < 4 ? P : 4;
-  if (opt_pg > 0) pg_max = pg_want = (opt_pg < P ? opt_pg : P);
-  struct Cand { int img, gjs; };
-  std::vector<Cand> cands;
-  if (img_ok && opt_img != 0) {
-    if (opt_gjs != 0) cands.push_back({1, 1});
-    if (opt_gjs != 1) cands.push_back({1, 0});
+  // ---- shape: wavefronts and row atoms per wavefront, what lives in LDS, permutations per group.  Registers allow two
+  // wavefronts per SIMD: either one workgroup of 8 wavefronts per CU with the whole LDS, or (N <= 24) two independent
+  // workgroups of 4 that do not share barriers, with 80 KB each.  Residency levels, in the order they pay (the O phase
+  // reads G_i and G_j three times per row atom and permutation, the V phase everything once per permutation):
+  //   0: nothing   1: row-point image   2: + the strip's G_j table   3: + the x_j tables
+  // asm.perm_w (0 automatic) picks the workgroup shape, asm.perm_level (-1 automatic) caps the level, asm.perm_pg fixes
+  // the group size, asm.perm_nimg the image buffers.
+  const int opt_w = ctx_opt_i(ctx, "asm.perm_w", 0), opt_na = ctx_opt_i(ctx, "asm.perm_na", 0);
+  int W = 8, NA = 6;
+  if (N <= 24) {  // measured (profiles/r03_assemble_perm_shapes.txt): 8 x 3 beats 4 x 6 (19.2 vs 21.9 ms at N = 21, P = 4, M = 1000)
+    if (opt_w == 4) { W = 4; NA = 6; }
+    else NA = (opt_na == 6) ? 6 : 3;
   }
-  if (opt_img != 1 || !img_ok) cands.push_back({0, 0});
-  // one workgroup of 8 wavefronts per CU (register-bound): the whole LDS is the budget; a candidate is taken when it holds at
-  // least pg_want permutations per group, on the last pass with whatever fits
-  const size_t budgets[3] = {(size_t)160 * 1024, (size_t)160 * 1024, (size_t)160 * 1024};
-  bool found = false;
-  for (int bi = 0; bi < 3 && !found; ++bi)
-    for (const Cand& c : cands) {
-      int pg = pg_max;
-      PermArgs tmp;
-      while (pg >= 1 && perm_layout(N, P, NA, c.img, c.gjs, pg, &tmp) > budgets[bi]) --pg;
-      if (pg >= (bi < 2 ? pg_want : 1)) {
-        img = c.img; gjs = c.gjs; PG = pg; found = true;
+  const bool img_ok = N <= W * NA;
+  const size_t budget = (W == 4 && ctx_opt_i(ctx, "asm.perm_lds_kb", 80) <= 80) ? (size_t)80 * 1024 : (size_t)160 * 1024;
+  const int opt_level = ctx_opt_i(ctx, "asm.perm_level", -1), opt_pg = ctx_opt_i(ctx, "asm.perm_pg", 0);
+  const int opt_nimg = ctx_opt_i(ctx, "asm.perm_nimg", 0);
+  int pg_max = P < 8 ? P : 8;
+  if (opt_pg > 0) pg_max = opt_pg < P ? opt_pg : P;
+  int level = -1, PG = 0, n_img = 0;
+  PermArgs tmp;
+  for (int lv = (img_ok ? 3 : 0); lv >= 0 && level < 0; --lv) {
+    if (opt_level >= 0 && lv > opt_level) continue;
+    // group size that must fit for this level to be taken: min(P, 4), else min(P, 2); level 0 takes whatever fits
+    const int wants[3] = {pg_max < 4 ? pg_max : 4, pg_max < 2 ? pg_max : 2, 1};
+    for (int wi = 0; wi < 3; ++wi) {
+      const int want = (opt_pg > 0) ? pg_max : wants[wi];
+      if (wi == 2 && lv > 0 && pg_max > 1 && opt_pg <= 0) break;  // rather a lower level than one-permutation groups
+      if (perm_layout(N, P, W, NA, lv >= 1 ? 1 : 0, lv >= 2, lv >= 3, want, &tmp) <= budget) {
+        level = lv;
+        PG = want;
         break;
       }
     }
-  if (!found) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_perm: no LDS layout for N=%d P=%d", N, P);
+  }
+  if (level < 0) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_perm: no LDS layout for N=%d P=%d", N, P);
+  n_img = level >= 1 ? 1 : 0;
+  if (n_img == 1 && opt_nimg != 1 && perm_layout(N, P, W, NA, 2, level >= 2, level >= 3, PG, &tmp) <= budget) n_img = 2;
+  while (PG < pg_max && perm_layout(N, P, W, NA, n_img, level >= 2, level >= 3, PG + 1, &tmp) <= budget) ++PG;
   PG = (P + (P + PG - 1) / PG - 1) / ((P + PG - 1) / PG);  // equal groups
-  const size_t lds = perm_layout(N, P, NA, img, gjs, PG, &A);
+  const size_t lds = perm_layout(N, P, W, NA, n_img, level >= 2, level >= 3, PG, &A);
 
   // ---- grid: strips x chunks of row points
   const int64_t n_strips = (n_j * N + 63) / 64;
@@ -511,15 +625,18 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   A.i_chunk = i_chunk;
   dim3 grid((unsigned)n_strips, (unsigned)((n_i + i_chunk - 1) / i_chunk));
   const int slot = ktime_begin(ctx);
-  if (NA == 3) {
-    if (img && gjs) perm_launch_t<3, true, true>(ctx, A, grid, lds);
-    else if (img) perm_launch_t<3, true, false>(ctx, A, grid, lds);
-    else perm_launch_t<3, false, false>(ctx, A, grid, lds);
-  } else {
-    if (img && gjs) perm_launch_t<6, true, true>(ctx, A, grid, lds);
-    else if (img) perm_launch_t<6, true, false>(ctx, A, grid, lds);
-    else perm_launch_t<6, false, false>(ctx, A, grid, lds);
-  }
+#define PERM_GO(w, na)                                                                       \
+  do {                                                                                       \
+    if (level == 3) perm_launch_t<w, na, true, true, true, false>(ctx, A, grid, lds);        \
+    else if (level == 2) perm_launch_t<w, na, true, true, false, false>(ctx, A, grid, lds);  \
+    else if (level == 1) perm_launch_t<w, na, true, false, false, false>(ctx, A, grid, lds); \
+    else perm_launch_t<w, na, false, false, false, false>(ctx, A, grid, lds);                \
+  } while (0)
+  if (N > 64) perm_launch_t<8, 6, false, false, false, true>(ctx, A, grid, lds);
+  else if (W == 4) PERM_GO(4, 6);
+  else if (NA == 3) PERM_GO(8, 3);
+  else PERM_GO(8, 6);
+#undef PERM_GO
   const double blocks = A.lower ? 0.5 * (double)n_i * (double)(n_i + 1) : (double)n_i * (double)n_j;
   ktime_end(ctx, slot, "assemble", 8.0 * blocks * 9.0 * N * N);
   ctx->launch_counter++;

@@ -102,8 +102,8 @@ def do_check():
         ok &= check_case(N, M, kind, {})
     # option sets: no image / no G_j table / group sizes / slow stores / 6 atoms per wavefront for small molecules
     for N, M, kind in [(9, 9, 'c3xc2'), (21, 7, 'c2xc2'), (42, 4, 'c3^3')]:
-        for opts in [{'asm.perm_img': 0}, {'asm.perm_gjs': 0}, {'asm.perm_pg': 1}, {'asm.perm_pg': 2}, {'asm.perm_fast_store': 0},
-                     {'asm.perm_na': 6}, {'asm.perm_i_chunk': 2}]:
+        for opts in [{'asm.perm_level': 0}, {'asm.perm_level': 1}, {'asm.perm_level': 2}, {'asm.perm_nimg': 1}, {'asm.perm_pg': 1},
+                     {'asm.perm_pg': 2}, {'asm.perm_fast_store': 0}, {'asm.perm_na': 6}, {'asm.perm_i_chunk': 2}]:
             ok &= check_case(N, M, kind, opts)
     print('ALL OK' if ok else 'SOME FAILED')
     return ok
@@ -147,8 +147,8 @@ def do_time(quick):
         time_case(N, M, kind, {}, label='new')
     # variants at the two shapes of interest
     for N, M, kind in [(21, 1000, 'c2xc2'), (42, 300, 'c3^3')]:
-        for opts in [{'asm.perm_gjs': 0}, {'asm.perm_pg': 2}, {'asm.perm_pg': 1}, {'asm.perm_na': 6}, {'asm.perm_img': 0},
-                     {'asm.perm_fast_store': 0}, {'asm.perm_i_chunk': 32}, {'asm.perm_i_chunk': 8}]:
+        for opts in [{'asm.perm_level': 2}, {'asm.perm_level': 1}, {'asm.perm_level': 0}, {'asm.perm_nimg': 1}, {'asm.perm_pg': 2},
+                     {'asm.perm_pg': 1}, {'asm.perm_na': 6}, {'asm.perm_fast_store': 0}, {'asm.perm_i_chunk': 32}, {'asm.perm_i_chunk': 4}]:
             time_case(N, M, kind, opts, label='new')
         time_case(N, M, kind, {}, lower=True, label='new')
         time_case(N, M, kind, {'asm.perm': 0}, lower=True, label='old')
