@@ -248,6 +248,12 @@ def main():
     ap.add_argument('--comm', default='auto', help="N>1: 'rccl', 'host' (gloo-staged), or auto (rccl if every rank has a GPU)")
     args = ap.parse_args()
 
+    # ---- `--gpus N` with N > 1 and no launcher around us: become the launcher (one rank per GPU over RCCL)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) != args.gpus:
+        sys.exit('bench.py: --gpus {} but the launcher started {} ranks'.format(args.gpus, os.environ['WORLD_SIZE']))
+
     # stdout carries exactly one line (the JSON): libraries that print banners to fd 1 (gloo's rank
     # messages, RCCL's version block) are sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -260,6 +266,33 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
+
+
+def self_launch(args):
+    """python bench.py --gpus N (N > 1) without a launcher: re-run this script under torch.distributed.run, one rank per
+    GPU on 127.0.0.1.  With fewer GPUs than ranks the run is refused unless `--comm host` asks for the functional mode
+    (ranks share GPUs, collectives staged through the host)."""
+    import socket
+    import subprocess
+
+    from sgdml_amd import _lib
+
+    try:
+        n_dev = _lib.device_count()
+    except Exception as e:  # no library / no driver
+        sys.stderr.write('bench.py: --gpus {}: cannot count GPUs ({})\n'.format(args.gpus, e))
+        return 2
+    if n_dev < args.gpus and args.comm != 'host':
+        sys.stderr.write('bench.py: --gpus {} but {} GPU(s) visible; pass --comm host for a functional run with ranks sharing '
+                         'GPUs\n'.format(args.gpus, n_dev))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
 
 
 def run_sharded_cg(args, rank, world):

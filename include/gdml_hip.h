@@ -109,6 +109,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   comm.force_collectives (0)  issue collectives even for world == 1 without a communicator (tests)
  *   dist.nb (512)         row-block size of the distributed Cholesky (multiple of 128)
  *   nys.force_qr (0)      take the alternative (QR-equivalent) branch of the second Nystroem factorisation (tests)
+ *   nys.force_fail (0)    treat the first k attempts of the jitter-stabilised Cholesky of K_mm as failed (tests)
  * Unknown keys return GDML_ERR_INVALID. */
 int gdml_set_option(gdml_ctx* ctx, const char* key, double value);
 int gdml_get_option(gdml_ctx* ctx, const char* key, double* value_out, int* is_set_out);
@@ -231,7 +232,8 @@ int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, const double* 
  *   L^-1 K_mn (m x n) with the jitter-escalation semantics of _cho_factor_stable, keeps it
  *   resident as the preconditioner, returns the leverage scores (column squared norms,
  *   iterative.py:107-109) in lev_scores_out (n) and optionally the factor in
- *   LinvKmn_host_out (m x n row-major, may be NULL).  *info: 0 ok, 1 = the second Cholesky failed and
+ *   LinvKmn_host_out (m x n row-major, may be NULL).  *info: bits 8.. = number of jitter escalations the Cholesky of
+ *   K_mm needed (iterative.py:442-463); bit 0 = the second Cholesky failed and
  *   the alternative branch ran (the reference's QR of [K_nm; sqrt(lam) I], iterative.py:313-324; here a
  *   shifted CholeskyQR3 on fp64 MFMA with the same R^T R up to rounding).
  * gdml_precon_apply: out = (L^T L v - v)/lam  (iterative.py:120-140).

@@ -257,8 +257,9 @@ static int tall_trsm(gdml_ctx* ctx, const double* L, double* X, int64_t n, int64
 
 // Cholesky with escalating diagonal jitter (iterative.py:414-471).  A: m x m (lower referenced).
 // Returns GDML_OK with *ok = 1 on success, *ok = 0 if every attempt failed.
+// force_fail (test hook nys.force_fail): treat the first force_fail attempts as failed, whatever the factorisation says.
 static int cho_factor_stable_dev(gdml_ctx* ctx, double* A, int64_t m, int64_t ld, double* backup,
-                                 bool pre_reg, int eps_mag_max, int* ok) {
+                                 bool pre_reg, int eps_mag_max, int* ok, int force_fail = 0, int* n_jitter = nullptr) {
   const double eps = 2.220446049250313e-16;
   int eps_mag = (int)floor(log10(eps));  // -16
   if (pre_reg) {
@@ -266,13 +267,15 @@ static int cho_factor_stable_dev(gdml_ctx* ctx, double* A, int64_t m, int64_t ld
     eps_mag += 1;
   }
   *ok = 0;
-  for (int mag = eps_mag; mag <= eps_mag_max; ++mag) {
+  int attempt = 0;
+  for (int mag = eps_mag; mag <= eps_mag_max; ++mag, ++attempt) {
     HIP_CHECK(ctx, hipMemcpy2DAsync(backup, m * 8, A, ld * 8, m * 8, m, hipMemcpyDeviceToDevice,
                                     ctx->stream));
     int info = 0;
     GDML_TRY(chol_factor_device(ctx, A, m, ld, &info));
-    if (info == 0) {
+    if (info == 0 && attempt >= force_fail) {
       *ok = 1;
+      if (n_jitter) *n_jitter = attempt;
       return GDML_OK;
     }
     HIP_CHECK(ctx, hipMemcpy2DAsync(A, ld * 8, backup, m * 8, m * 8, m, hipMemcpyDeviceToDevice,
@@ -348,7 +351,9 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
                        ld, d_idx, m, sg.row0, n_loc);
     GDML_TRY(comm_allreduce_sum(ctx, S, m * ld));
     int ok = 0;
-    GDML_TRY(cho_factor_stable_dev(ctx, S, m, ld, backup, true, 1, &ok));  // iterative.py:263
+    int n_jit = 0;
+    GDML_TRY(cho_factor_stable_dev(ctx, S, m, ld, backup, true, 1, &ok, ctx_opt_i(ctx, "nys.force_fail", 0), &n_jit));  // iterative.py:263
+    if (info) *info |= n_jit << 8;
     if (!ok)
       return gdml_fail(ctx, GDML_ERR_NOT_PD,
                        "Failed to factorize despite strong regularization (max: 10)! You could try a larger sigma.");
@@ -370,7 +375,7 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
       // its factorisation cannot fail, the two repetitions remove the shift's error (R = R3 R2 R1 is never
       // formed: the triangular solves apply R1^-1, R2^-1, R3^-1 to K_nm in turn).  Backward stable like
       // Householder QR for cond([K_nm; sqrt(lam) I]) up to ~1/eps, and GEMM-shaped instead of panel-bound.
-      if (info) *info = 1;
+      if (info) *info |= 1;
       const double eps = 2.220446049250313e-16;
       double* B = S;  // the stacked sqrt(lam) I block lives right below X: one Gram launch covers both
       HIP_CHECK(ctx, hipMemsetAsync(B, 0, m * ld * 8, ctx->stream));

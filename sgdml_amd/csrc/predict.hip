@@ -159,6 +159,84 @@ __global__ void __launch_bounds__(256) predict_kernel(PredArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Large molecules (D > 1024, up to N = 128: D = 8128), batches below the GEMM pipeline of predict_wide.hip:
+// one workgroup of 512 threads per (query, row split); thread t owns the descriptor entries k = t + 512 s
+// (x, F_x and the current table row in registers), the two dot products of a row are block reductions.
+// Same arithmetic as predict_kernel (predict.py:168-245).
+// ------------------------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(512) predict_big_kernel(PredArgs A) {
+  __shared__ double red[2][2][8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t qi = blockIdx.x;
+  const int split = blockIdx.y;
+  const int D = A.D;
+  const double sig = A.sig, inv_sig = 1.0 / sig;
+  const double sqrt5 = 2.23606797749978969641;
+  const double fact = 5.0 / (3.0 * sig * sig * sig);
+  const double dscale = 5.0 / sig;
+  const double inv_3sig = 1.0 / (3.0 * sig);
+  double x[KT], Fx[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const int k = tid + 512 * t;
+    x[t] = (k < D) ? A.xq[qi * D + k] : 0.0;
+    Fx[t] = 0.0;
+  }
+  double E = 0.0;
+  const int64_t r0 = (int64_t)split * A.rows_per_split;
+  const int64_t r1 = (r0 + A.rows_per_split < A.MP) ? r0 + A.rows_per_split : A.MP;
+  const bool has_aE = A.aE != nullptr;
+  int buf = 0;
+  for (int64_t r = r0; r < r1; ++r, buf ^= 1) {
+    double d[KT], JA[KT];
+    double s2 = 0.0, sa = 0.0;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int k = tid + 512 * t;
+      const double X = (k < D) ? A.xp[r * D + k] : 0.0;
+      JA[t] = (k < D) ? A.jap[r * D + k] : 0.0;
+      d[t] = x[t] - X;
+      s2 += d[t] * d[t];
+      sa += d[t] * JA[t];
+    }
+    s2 = wave_sum(s2);
+    sa = wave_sum(sa);
+    if (lane == 0) {
+      red[buf][0][wv] = s2;
+      red[buf][1][wv] = sa;
+    }
+    __syncthreads();  // one barrier per row: the two buffers alternate
+    s2 = 0.0;
+    sa = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s2 += red[buf][0][u];
+      sa += red[buf][1][u];
+    }
+    const double nrm = sqrt5 * sqrt(s2);
+    const double ex = exp(-nrm * inv_sig);
+    const double b = fact * ex;
+    const double b2 = b * (nrm + sig);
+    double w1 = dscale * sa * b;
+    E += sa * b2;
+    if (has_aE) {
+      const double ae = A.aE[r];
+      w1 += ae * b2;
+      E += ae * (1.0 + (nrm * inv_sig) * (1.0 + nrm * inv_3sig)) * ex;
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) Fx[t] += w1 * d[t] - b2 * JA[t];
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const int k = tid + 512 * t;
+    if (k < D) A.part_F[((int64_t)split * A.B + qi) * D + k] = Fx[t];
+  }
+  if (tid == 0) A.part_E[(int64_t)split * A.B + qi] = E;
+}
+
+// ------------------------------------------------------------------------------------------
 // Bulk variant (B >= 32, D <= 256): no cross-lane reductions at all.
 // A workgroup owns 32 queries and a split of the table rows, processed in tiles of 32 rows.
 //   phase 1: every thread owns 2 x 2 (query,row) pairs and runs over k with the query / table
@@ -699,7 +777,8 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   const int64_t MP = md.M * md.P;
   int KPL = 1;
   while (KPL * 64 < D) KPL <<= 1;
-  if (KPL > 32) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "predict kernel supports D <= 2048");
+  if (D > 8192) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "predict kernels support D <= 8192 (N <= 128)");
+  const bool big = D > 1024;  // beyond the register-resident wave kernel
   // below ~1e9 (row, query, descriptor) triples the seven launches of the pipeline cost more than the wave kernel
   // (tools/predict_wide_probe.py); option predict.mfma_wide = 2 forces it (tests)
   const int wide_opt = ctx_opt_i(ctx, "predict.mfma_wide", 1);
@@ -717,7 +796,7 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
     HIP_CHECK(ctx, hipGetLastError());
     return GDML_OK;
   }
-  const bool bulk = (B >= 256) && (D <= 256) && !ctx_opt_i(ctx, "predict.wave_only", 0);
+  const bool bulk = !big && (B >= 256) && (D <= 256) && !ctx_opt_i(ctx, "predict.wave_only", 0);
   const bool mfma = bulk && ctx_opt_i(ctx, "predict.mfma", 1);
   int QB = max_qb_for(KPL);
   while (QB > 1 && B < QB) QB >>= 1;  // do not waste query slots
@@ -730,6 +809,11 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   int64_t n_qt = mfma ? (B + MQ - 1) / MQ : bulk ? (B + PQ - 1) / PQ : (B + QB - 1) / QB;
   int64_t JS = ((mfma ? 512 : bulk ? 2048 : 4096) + n_qt - 1) / n_qt;
   int64_t max_js = bulk ? (MP / 64 > 1 ? MP / 64 : 1) : (MP / 16 > 1 ? MP / 16 : 1);
+  if (big) {  // one workgroup per (query, split)
+    n_qt = B;
+    JS = (1024 + B - 1) / B;
+    max_js = MP / 4 > 1 ? MP / 4 : 1;
+  }
   if (JS > max_js) JS = max_js;
   if (JS < 1) JS = 1;
   if (mfma) {
@@ -791,6 +875,10 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
       BC(1) BC(2) BC(3) BC(4) BC(5) BC(6) BC(7) default: hipLaunchKernelGGL(predict_bulk_kernel<8>, grid, dim3(256), 0, ctx->stream, A); break;
 #undef BC
     }
+  } else if (big) {
+    dim3 grid((unsigned)B, (unsigned)JS);
+    if (D <= 4096) hipLaunchKernelGGL(predict_big_kernel<8>, grid, dim3(512), 0, ctx->stream, A);
+    else hipLaunchKernelGGL(predict_big_kernel<16>, grid, dim3(512), 0, ctx->stream, A);
   } else {
     switch (KPL) {
       case 1: dispatch_qb<1>(ctx, A, QB); break;

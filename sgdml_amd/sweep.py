@@ -72,8 +72,9 @@ def sigma_sweep(gdml_train, dataset, n_train, n_valid, n_test, sigs=None, valid_
         if 'solver_resid' in model:
             is_conv = model['solver_resid'] <= model['solver_tol'] * model['norm_y_train']
         converged_once = converged_once or is_conv
-        # cli.py:1136-1147: stop once the validation error (energy MAE first if present, like valid_errs[0]) rises
-        lead = float(e[0]) if 'energy' in errs else float(errs['force'][0])
+        # cli.py:1136-1147: stop once the validation error rises again; valid_errs there is what cli.test returns, the
+        # list of force RMSEs of the models it was given (cli.py:1792-1794), so valid_errs[0] is this model's force RMSE
+        lead = float(errs['force'][1])
         if early_stop and converged_once and prev_err != -1.0 and prev_err < lead:
             break
         prev_err = lead

@@ -22,7 +22,7 @@ def setup_case(g):
     return M, N, xd, gd, tp, orc.tril_perms_lin_from_tril_perms(tp)
 
 
-@pytest.mark.parametrize('name', ['cfg0_n9_p6', 'cfg3_n42_p27', 'cfg4_n60_p1'])
+@pytest.mark.parametrize('name', ['cfg0_n9_p6', 'cfg3_n42_p27', 'cfg4_n60_p1', 'cfg1_n21_m100', 'cfg3_n42_p27_m60', 'n100_m3'])
 def test_K_samples_and_solve_at_config_shapes(name):
     g = load(name)
     M, N, xd, gd, tp, lin = setup_case(g)
@@ -110,3 +110,39 @@ def test_lu_branch_fixture():
         F.append(orc.predict_from_desc(xq, gq, xd, JA, tp, sig)[1] * float(g['model_std']))
     assert np.abs(F[0] - g['F_test']).max() <= 1e-9 * np.abs(g['F_test']).max()
     assert np.abs(F[1] - g['F_test']).max() <= 1e-6 * np.abs(g['F_test']).max()
+
+
+def test_restart_fixture_first_stage_history():
+    """Round-3 fixture of the reference's restarting run (make_golden_r3.py: k = 1 inducing point, restart after 100
+    stagnating steps): the oracle's PCG on the first stage's inducing columns reproduces the reference's residual
+    history up to the restart, and the restart criterion of iterative.py:614-735 (efficiency <= 0 over a window of
+    100 steps) evaluated on the REFERENCE's own history fires at step 100 and never in the second stage."""
+    g = load('pcg_restart')
+    M = int(g['n_train'])
+    N = g['R_all'].shape[1]
+    xd, gd = orc.desc_from_R(g['R_all'][:M].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    lin = orc.tril_perms_lin_from_tril_perms(tp)
+    sig, lam = float(g['sig']), float(g['lam'])
+    y = g['F_all'][:M].ravel() / np.std(g['F_all'][:M].ravel())
+    assert abs(np.linalg.norm(y) - float(g['norm_y_train'])) <= 1e-9 * np.linalg.norm(y)
+    fac = orc.nystroem_factor(xd, gd, lin, sig, lam, g['inducing_stage0'])
+    r_hist = []
+    orc.pcg(lambda v: -orc.kernel_matvec(xd, gd, tp, sig, lam, v), y,
+            M_mv=lambda r: (r_hist.append(np.linalg.norm(r)), orc.precon_apply(fac, lam, r))[1], rtol=1e-4, maxiter=100)
+    ref = g['resid_hist']
+    np.testing.assert_allclose(np.array(r_hist[1:9]), ref[:8], rtol=1e-6)
+    np.testing.assert_allclose(np.array(r_hist[1:100]), ref[:99], rtol=0.15)
+
+    def eff_after(hist):  # iterative.py:640-655
+        steps = np.diff(np.concatenate([[hist[0]], hist]))
+        steps[0] = 0.0
+        tot = np.abs(steps).sum()
+        ratio = -steps.clip(max=0).sum() / tot if tot > 0 else 1.0
+        return (int(100 * ratio) - 50) * 2
+
+    starts = list(g['cg_starts'])
+    assert starts == [0, 100]
+    assert eff_after(ref[:100]) <= 0
+    second = ref[100:]
+    assert all(eff_after(second[k - 100:k]) > 0 for k in range(100, len(second), 50))
