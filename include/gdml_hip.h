@@ -239,8 +239,9 @@ int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, const double* 
  * gdml_precon_apply: out = (L^T L v - v)/lam  (iterative.py:120-140).
  * gdml_pcg: preconditioned CG for (-K + lam I) x = y with scipy.sparse.linalg.cg semantics
  *   (iterative.py:740-752: rtol*||y||, atol = 0, x0 optional).  cb(iter, resid, x_host, user)
- *   is called every cb_every iterations (0 = never) with the current iterate copied to the
- *   host; a non-zero return stops the solve (used for CGRestartException, iterative.py:729).
+ *   is called every cb_every iterations (0 = never) with the iterate x_iter copied to the host and
+ *   resid = ||y - A x_iter|| (the recurrence residual after the update, what the reference's callback reads from
+ *   scipy's frame, iterative.py:626-632); a non-zero return stops the solve (used for CGRestartException, iterative.py:729).
  *   info_out: 0 converged, 1 maxiter reached, 2 stopped by callback. */
 typedef int (*gdml_pcg_cb)(int64_t iter, double resid, const double* x_host, void* user);
 int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* idx, int64_t m,

@@ -566,10 +566,10 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
       HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
     double rho_prev = 0.0;
+    double rr = 0.0;
+    GDML_TRY(dev_dot(ctx, r, r, n, d_part, &rr));
+    rn = sqrt(rr);
     for (it = 0; it < maxiter; ++it) {
-      double rr = 0.0;
-      GDML_TRY(dev_dot(ctx, r, r, n, d_part, &rr));
-      rn = sqrt(rr);
       if (rn < atol) {
         info = 0;
         return GDML_OK;
@@ -592,6 +592,10 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
       hipLaunchKernelGGL(vec_axpy_kernel, dim3(grid), dim3(256), 0, ctx->stream, x, p, alpha, n);
       hipLaunchKernelGGL(vec_axpy_kernel, dim3(grid), dim3(256), 0, ctx->stream, r, q, alpha, n);  // r -= alpha A p
       rho_prev = rho;
+      // ||r_{it+1}||: tested at the top of the next iteration and handed to the callback together with x_{it+1} -- the
+      // pair scipy's callback sees after its update (the reference reads `r` from cg's frame, iterative.py:626-632)
+      GDML_TRY(dev_dot(ctx, r, r, n, d_part, &rr));
+      rn = sqrt(rr);
       if (cb && cb_every > 0 && ((it + 1) % cb_every) == 0) {
         hx.resize((size_t)n);
         HIP_CHECK(ctx, hipMemcpyAsync(hx.data(), x, n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -603,9 +607,6 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
         }
       }
     }
-    double rr = 0.0;
-    GDML_TRY(dev_dot(ctx, r, r, n, d_part, &rr));
-    rn = sqrt(rr);
     info = rn < atol ? 0 : 1;
     return GDML_OK;
   };

@@ -28,12 +28,18 @@ def _errors_into_model(model, errs, n_pts, is_test, md5=None):
 
 
 def sigma_sweep(gdml_train, dataset, n_train, n_valid, n_test, sigs=None, valid_dataset=None, test_dataset=None,
-                lam=1e-10, perms=None, use_sym=True, use_E=True, use_E_cstr=False, early_stop=True, callback=None):
+                lam=1e-10, perms=None, use_sym=True, use_E=True, use_E_cstr=False, early_stop=True, callback=None,
+                emulate_cli_rng=False):
     """Train one model per sigma on a shared task, validate each, select the best, test it.
 
     Returns (best_model, table, timings): `table` rows are (sig, e_mae, e_rmse, f_mae, f_rmse) of the validated
     models in training order (the columns `sgdml select` prints, cli.py:1852-1854); `timings` holds wall-clock
     seconds of the train / validate / test phases.
+
+    The train / validation / test samples come from the global NumPy stream like the reference's.  `emulate_cli_rng`
+    additionally consumes what a freshly installed reference CLI draws between them for its CPU worker benchmark (one
+    rand(min(1000, n_valid), 3N) per validation until its cache holds three runs: cli.py:1513-1518 -> predict.py:833-858,
+    :1087-1090), so that a seed reproduces the reference's test sample too (tests/test_hip_r3.py).
     """
     if sigs is None:
         sigs = list(range(10, 100, 10))  # cli.py:806: default grid '10:10:100'
@@ -61,6 +67,12 @@ def sigma_sweep(gdml_train, dataset, n_train, n_valid, n_test, sigs=None, valid_
         pred = GDMLPredict(model)
         errs = pred.test_errors(R_valid, F_valid, E_valid)
         del pred
+        # the reference shuffles the validation indices of every model before its online error loop (cli.py:1487-1488);
+        # the device reduction does not care about the order, but the draw keeps the global NumPy stream -- which picks
+        # the test sample below -- where the reference's is
+        np.random.shuffle(np.array(iv))
+        if emulate_cli_rng and len(models) < 3:
+            np.random.rand(min(1000, len(iv)), 3 * n_atoms)
         t2 = timeit.default_timer()
         t_train += t1 - t0
         t_valid += t2 - t1

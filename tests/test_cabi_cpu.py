@@ -290,3 +290,33 @@ def test_documented_options_match_the_library():
         if fn.endswith(('.hip', '.h')):
             used |= set(re.findall(r'ctx_opt(?:_i)?\(\s*ctx\s*,\s*"([^"]+)"', open(os.path.join(csrc, fn)).read()))
     assert used <= known, sorted(used - known)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 8` without a launcher around it becomes the launcher (one rank per GPU); on a box with
+    fewer GPUs it must refuse, not print a 1-GPU line labelled as the 8-GPU run."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ''
+    assert '--gpus 8' in p.stderr
+    # a launcher that started a different number of ranks than --gpus says is an error too
+    env.update(WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4'], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0 and p.stdout.strip() == '' and 'launcher started 2 ranks' in p.stderr
+
+
+def test_find_perms_matches_reference_on_the_cli_sweep_sample():
+    """The training sample the reference's `sgdml all` drew in the cli_sweep fixture: our host-side symmetry search
+    returns the reference's group, in its order (perm.py:395-404)."""
+    from sgdml_amd.utils import perm
+
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cli_sweep.npz'))
+    got = perm.find_perms(fx['R'][fx['idxs_train']], fx['z'])
+    assert np.array_equal(got, fx['perms'])

@@ -106,7 +106,7 @@ def test_iterative_restart_and_checkpoints_follow_reference(monkeypatch):
     assert abs(model['norm_y_train'] - float(fx['norm_y_train'])) <= 1e-9 * float(fx['norm_y_train'])
     # residual history: the first steps to rounding, the stagnating first stage within the drift of two PCG runs
     ref_hist = fx['resid_hist']
-    ours = np.array(hist[1:])  # callback k reports ||r_k||; the reference's spy records ||r_{k+1}||
+    ours = np.array(hist)  # callback k reports ||r_k|| after update k, like the reference's spy on scipy's cg
     np.testing.assert_allclose(ours[:8], ref_hist[:8], rtol=1e-6)
     np.testing.assert_allclose(ours[:99], ref_hist[:99], rtol=0.15)
     # ---- final model predicts like the reference's
@@ -114,9 +114,11 @@ def test_iterative_restart_and_checkpoints_follow_reference(monkeypatch):
     assert np.abs(F - fx['F_test']).max() <= 5e-3 * np.abs(fx['F_test']).max()
     assert abs(model['c'] - float(fx['model_c'])) <= 5e-3
     # ---- checkpoints
-    assert len(ckpts) >= 10
+    # under the fake clock tt = 1.2 s up to rounding, so ceil(120 / tt) flips between 100 and 101 with the float noise of
+    # the running clock value: the reference wrote checkpoints at 301 ... 801, 1011, 2021 -- and so do we, the timer being
+    # read in the same places (iterative.py:618-621, :675-680)
     its = [int(c['solver_iters']) for c in ckpts]
-    assert its[:5] == [101, 201, 301, 401, 501]  # every 100 iterations under the fake clock
+    assert its == [int(v) for v in fx['ckpt_iters_all']], its
     task = _task(fx, M)
     for c in (ckpts[2], ckpts[-1]):
         assert c['solver_name'] == 'cg' and c['solver_tol'] == 1e-4
@@ -190,12 +192,13 @@ def test_sigma_sweep_matches_reference_cli():
     ds = {'type': 'd', 'code_version': '1.0.3', 'name': np.array('rotors'), 'theory': np.array('toy'), 'z': fx['z'],
           'R': fx['R'], 'F': fx['F'], 'E': fx['E'], 'r_unit': 'Ang', 'e_unit': 'kcal/mol'}
     ds['md5'] = io.dataset_md5(ds)
-    assert ds['md5'] == str(fx['dataset_md5'])
+    assert ds['md5'] == fx['dataset_md5'].item()
     tr = GDMLTrain()
     try:
         np.random.seed(int(fx['seed']))
+        np.random.choice(len(ds['R']), 1)  # the CLI's "example geometry" banner draws one index first (cli.py:294, :642)
         best, table, timings = sigma_sweep(tr, ds, int(fx['n_train']), int(fx['n_valid']), int(fx['n_test']),
-                                           sigs=[int(s) for s in fx['sigs']])
+                                           sigs=[int(s) for s in fx['sigs']], emulate_cli_rng=True)
     finally:
         tr.__del__()
     assert np.array_equal(best['perms'], fx['perms'])
