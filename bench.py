@@ -49,6 +49,26 @@ def synth_geometries(n_atoms, n_frames, seed=0, jitter=0.3, n_conformers=4, spac
     base0 = grid[rng.choice(len(grid), n_atoms, replace=False)]
     bases = np.array([base0] + [base0 + rng.normal(0, 0.25, base0.shape) for _ in range(n_conformers - 1)])
     R = bases[rng.randint(0, len(bases), n_frames)] + rng.normal(0, jitter, (n_frames, n_atoms, 3))
+    return (R,) + pair_potential_labels(R)
+
+
+def synth_trajectory(n_atoms, n_frames, seed=0, n_modes=8, amp=0.15, noise=0.01, spacing=1.4):
+    """Seeded synthetic "MD trajectory" for the iterative-solver workload (configs[2]): the molecule of synth_geometries
+    moving along n_modes collective displacement modes (random amplitudes) plus a small thermal jitter -- like a real
+    trajectory the frames lie near a low-dimensional manifold, which is what makes the Nystroem preconditioner of the
+    reference (iterative.py:208-351) effective; labels from the same pair potential."""
+    rng = np.random.RandomState(seed)
+    g = int(np.ceil(n_atoms ** (1.0 / 3.0))) + 1
+    grid = np.array([[a, b, c] for a in range(g) for b in range(g) for c in range(g)], float) * spacing
+    base = grid[rng.choice(len(grid), n_atoms, replace=False)]
+    modes = np.linalg.qr(rng.normal(size=(3 * n_atoms, n_modes)))[0].T.reshape(n_modes, n_atoms, 3)
+    coef = rng.normal(0, amp, (n_frames, n_modes))
+    R = base[None] + np.einsum('fk,kad->fad', coef, modes) * np.sqrt(n_atoms) + rng.normal(0, noise, (n_frames, n_atoms, 3))
+    return (R,) + pair_potential_labels(R)
+
+
+def pair_potential_labels(R):
+    n_frames, n_atoms = R.shape[:2]
     i, j = np.tril_indices(n_atoms, -1)
     diff = R[:, i, :] - R[:, j, :]
     dist = np.sqrt((diff**2).sum(-1))
@@ -58,7 +78,7 @@ def synth_geometries(n_atoms, n_frames, seed=0, jitter=0.3, n_conformers=4, spac
     for m in range(n_frames):
         np.add.at(F[m], i, gp[m])
         np.subtract.at(F[m], j, gp[m])
-    return R, E, F
+    return E, F
 
 
 def cpu_baseline(n_atoms, sig, lam, full_M, M_single=100, M_threads=300):
@@ -106,7 +126,18 @@ def cpu_baseline(n_atoms, sig, lam, full_M, M_single=100, M_threads=300):
 
     est1, estt = extrap(m1), extrap(mt)
     best_threads = estt <= est1
+    # the one run at the benchmark size (tools/cpu_baseline_full.py on the GPU box's host, committed record)
+    measured_full = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r03_cpu_baseline_full.json')) as f:
+            rec = json.load(f)
+        if rec.get('M') == full_M and rec.get('n_atoms') == n_atoms:
+            measured_full = dict(rec, provenance='profiles/r03_cpu_baseline_full.json (tools/cpu_baseline_full.py, one run, all cores)',
+                                 extrapolation_error=min(est1, estt) / rec['build_solve_s'] - 1.0)
+    except (OSError, ValueError):
+        pass
     return {
+        'measured_full': measured_full,
         'value': min(est1, estt),  # EXTRAPOLATED build+solve seconds at the benchmark size (see `measured`)
         'unit': 's',
         'cores': cores if best_threads else 1,
@@ -215,6 +246,116 @@ def sigma_sweep_config0(n_train=200, n_valid=1000, n_test=5000, sigs=None):
         'best_sig': float(best['sig']), 'best_f_rmse': best['f_err']['rmse'],
         'valid_f_rmse_by_sig': {str(r[0]): r[4] for r in table},
     }
+
+
+def perm_group(n_atoms, kind):
+    """Permutation groups of the BASELINE shapes: 'c3x3' = three independent 3-cycles (27 elements, configs[3]),
+    'c2x2' = two independent swaps (4 elements); None = identity."""
+    if not kind:
+        return np.arange(n_atoms)[None, :]
+    gens = []
+    if kind == 'c3x3':
+        for a in (3, n_atoms // 2 - 4, n_atoms - 12):
+            g = list(range(n_atoms))
+            g[a], g[a + 1], g[a + 2] = a + 1, a + 2, a
+            gens.append(tuple(g))
+    elif kind == 'c2x2':
+        for a in (2, n_atoms - 5):
+            g = list(range(n_atoms))
+            g[a], g[a + 1] = a + 1, a
+            gens.append(tuple(g))
+    else:
+        raise ValueError(kind)
+    perms = [tuple(range(n_atoms))]
+    frontier = list(perms)
+    while frontier:
+        nxt = []
+        for a in frontier:
+            for g in gens:
+                c = tuple(a[i] for i in g)
+                if c not in perms:
+                    perms.append(c)
+                    nxt.append(c)
+        frontier = nxt
+    return np.array(perms)
+
+
+def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', sig=20, lam=1e-10, max_memory=None, seed=3,
+                 traj=None, n_inducing=None):
+    """One BASELINE configuration shape run to a SOLUTION through the drop-in GDMLTrain.train (sgdml/train.py:836-1088):
+    analytic = assemble + Cholesky + solves; cg = the reference's iterative policy (leverage-score inducing points,
+    Nystroem preconditioner, PCG to solver_tol = 1e-4, restarts) -- wall-clock to the converged model, phases,
+    iterations, and the residual of the returned coefficients through the matrix-free operator."""
+    from sgdml_amd.solvers.iterative import Iterative
+    from sgdml_amd.train import GDMLTrain
+
+    if traj is not None:
+        R, E, F = synth_trajectory(n_atoms, n_train, seed=seed, **traj)
+    else:
+        R, E, F = synth_geometries(n_atoms, n_train, seed=seed)
+    perms = perm_group(n_atoms, perms_kind)
+    task = {'type': 't', 'code_version': 'bench', 'dataset_name': np.array('synth'), 'dataset_theory': np.array('pair'),
+            'z': np.full(n_atoms, 6), 'R_train': R, 'F_train': F, 'E_train': E, 'idxs_train': np.arange(n_train),
+            'md5_train': 'x', 'idxs_valid': np.arange(0), 'md5_valid': 'x', 'sig': sig, 'lam': lam, 'use_E': True,
+            'use_E_cstr': False, 'use_sym': perms.shape[0] > 1, 'perms': perms}
+    n = 3 * n_atoms * n_train
+    draws = []
+    orig = Iterative.inducing_pts_from_lev_scores
+
+    def spy(self, lev, m):
+        idx = orig(self, lev, m)
+        draws.append(len(idx) // (3 * n_atoms))
+        return idx
+
+    Iterative.inducing_pts_from_lev_scores = spy
+    tr = GDMLTrain(max_memory=max_memory)
+    try:
+        tr._force_solver = solver
+        tr._force_n_inducing_pts = n_inducing
+        ctx = tr._context()
+        ctx.profile(True)
+        np.random.seed(seed)
+        ctx.sync()
+        t0 = time.perf_counter()
+        model = tr.train(task)
+        ctx.sync()
+        wall = time.perf_counter() - t0
+        out = {'config': label, 'n_atoms': n_atoms, 'n_train': n_train, 'n_perms': int(perms.shape[0]), 'matrix_n': n,
+               'solver': solver, 'sig': sig, 'lam': lam, 'train_wall_s': wall}
+        ph = {}
+        for k in ('assemble', 'factor', 'solve', 'precon', 'pcg'):
+            try:
+                ph[k] = ctx.phase_ms(k)[0]
+            except Exception:  # phase never ran on this solver branch
+                pass
+        out['phases_ms_last'] = ph
+        a_ms, a_n, a_by = ctx.kernel_stat('assemble')
+        if a_ms > 0 and solver == 'analytic':
+            out['roofline_assemble'] = {'bound': 'hbm', 'achieved': a_by / (a_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                        'frac': a_by / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'ms': a_ms / a_n,
+                                        'algorithmic_bytes_per_launch': a_by / a_n,
+                                        'fp64_valu_model_TFLOPs': n_train * (n_train + 1) / 2.0 * perms.shape[0] *
+                                        (2.0 * (3 * n_atoms) ** 2 + 100.0 * n_atoms * (n_atoms - 1) / 2) / (a_ms / a_n * 1e-3) / 1e12}
+        if solver == 'analytic' and 'factor' in ph:
+            out['cholesky_TFLOPs'] = n**3 / 3.0 / (ph['factor'] * 1e-3) / 1e12
+        y = F.ravel() / np.std(F.ravel())
+        tp = np.array([[0]])
+        from sgdml_amd.utils.desc import Desc
+        tril = np.array([Desc.perm(p_) for p_ in perms])
+        xd, gd = ctx.desc_from_R(R.reshape(n_train, -1), n_atoms)
+        ctx.train_upload(xd, gd, tril)
+        ctx.predict_upload_model(xd, np.zeros_like(xd), tril, sig, None)
+        Kv = ctx.kernel_matvec(lam, False, -np.asarray(model['alphas_F']).ravel())
+        out['resid_over_norm_y'] = float(np.linalg.norm(-Kv - y) / np.linalg.norm(y))
+        if solver == 'cg':
+            out.update({'time_to_tol_s': wall, 'solver_tol': float(model['solver_tol']), 'solver_iters': int(model['solver_iters']),
+                        'converged': bool(model['solver_resid'] <= model['solver_tol'] * model['norm_y_train']),
+                        'inducing_pts_per_stage': draws, 'restarts': max(0, len(draws) - 1),
+                        'ms_per_pcg_iteration': ph.get('pcg', 0.0) / max(1, int(model['solver_iters']))})
+        return out
+    finally:
+        Iterative.inducing_pts_from_lev_scores = orig
+        tr.__del__()
 
 
 def load_pmc_traffic():
@@ -540,19 +681,21 @@ def run_analytic(args):
             cfgs.append(sigma_sweep_config0())
         except Exception as e:  # the headline must not die with an extra
             cfgs.append({'config': 'configs[0] sweep', 'error': repr(e)})
-        try:
-            c2 = _lib.Context(0)
-            wl = make_cg_workload(c2, N, args.cg_n_train, args.cg_inducing, args.sig, args.lam)
-            r2 = time_cg(c2, wl, args.cg_iters, 1, 1, c2.sync)
-            c2.close()
-            tot_bytes, iter_bytes = cg_algorithmic_bytes(wl, args.cg_iters, 1)
-            r2['config'] = ('configs[2] workload on ONE GPU (1-GPU point of the strong-scaling curve `bench.py --gpus N` '
-                            'measures): N=21 N_train={} k={} inducing points, {} PCG iterations per step').format(
-                                args.cg_n_train, args.cg_inducing, args.cg_iters)
-            r2['precon_hbm_GBs'] = iter_bytes / (r2['ms_per_pcg_iteration'] * 1e-3) / 1e9
-            cfgs.append(r2)
-        except Exception as e:
-            cfgs.append({'config': 'configs[2] one-GPU point', 'error': repr(e)})
+        # the other BASELINE configuration shapes, each run to a SOLUTION through GDMLTrain.train on this one GPU
+        for label, kw in (
+            ('configs[2] shape: aspirin-sized N=21, N_train={} iterative solver to solver_tol 1e-4 on a synthetic trajectory '
+             '(bench.synth_trajectory), device-memory budget 32 GB -> k inducing points by the memory model'.format(args.cg_n_train),
+             dict(n_atoms=N, n_train=args.cg_n_train, solver='cg', max_memory=32,
+                  traj={'n_modes': 8, 'amp': 0.15, 'noise': 0.01})),
+            ('configs[3] shape: N=42 with a 27-element permutation group, N_train=1000 (n = 126 000, 127 GB), analytic',
+             dict(n_atoms=42, n_train=1000, perms_kind='c3x3', solver='analytic')),
+            ('configs[4] shape: 100-atom molecule, N_train=500 (n = 150 000, 180 GB), analytic',
+             dict(n_atoms=100, n_train=500, solver='analytic')),
+        ):
+            try:
+                cfgs.append(solve_config(label, sig=args.sig, lam=args.lam, **kw))
+            except Exception as e:
+                cfgs.append({'config': label, 'error': repr(e)})
         out['configs'] = cfgs
     out['cpu_baseline'] = None if args.no_cpu else cpu_baseline(N, args.sig, args.lam, M)
     return out

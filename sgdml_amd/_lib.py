@@ -167,6 +167,10 @@ class Context(object):
         if rc == GDML_OK:
             return
         msg = self._lib.gdml_last_error(self._h).decode()
+        cause = getattr(self, '_coll_exc', None)
+        if cause is not None:  # a host-collective callback failed: that exception is the real reason of this error code
+            self._coll_exc = None
+            raise GDMLHipError('[{}] {}'.format(rc, msg)) from cause
         if rc == ERR_INVALID:
             raise ValueError(msg)
         if rc == ERR_OOM:

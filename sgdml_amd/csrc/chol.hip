@@ -736,8 +736,16 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
   static_assert(sizeof(double) * 2 * 2 * GT * GPITCH >= sizeof(double) * (2 * 64 * 65 + 64 + 128), "LDS of the diagonal role");
   if (blockIdx.x == 0) {
     if (g.ready) {  // the block's tiles are computed by workgroups of this launch (dispatched right behind this one)
-      if (threadIdx.x == 0)
-        while (__hip_atomic_load(g.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.ready_target) __builtin_amdgcn_s_sleep(8);
+      if (threadIdx.x == 0) {
+        int spins = 0;  // bounded: a target that can never be reached must not hang the GPU (flag -> GDML_ERR_HIP)
+        while (__hip_atomic_load(g.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.ready_target) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 24)) {
+            atomicExch(g.ready + 1, 1);
+            break;
+          }
+        }
+      }
       __syncthreads();
       __threadfence();
     }
@@ -1202,7 +1210,7 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
     // first panel: always one level (nothing to hide its diagonal block behind)
     int64_t k0 = 0, nb = (n < NB) ? n : NB;
     int ready_count = 0;  // cumulative target of the tile counter d_info[6]
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info + 6, 0, sizeof(int), ctx->stream));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info + 6, 0, 2 * sizeof(int), ctx->stream));  // counter, wait-timeout flag
     GDML_TRY(panel_factor(ctx, st, A, n_rows, ld, 0, nb));
     for (;;) {
       const int64_t t0 = k0 + nb;
@@ -1211,7 +1219,9 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
       const int64_t t1 = t0 + nb2;
       const double* P = A + t0 * ld + k0;
       const bool fuse = (nb2 % 64 == 0) && (n - t1 >= min_rows) && (n_rows - t1 > 0);
-      const bool merged = fuse && nb2 == 2 * NB && ctx_opt_i(ctx, "chol.merge_gemm1", 1) != 0;
+      // the merged schedule counts finished GT x GT tiles of a diagonal block: NB must be a whole number of tiles, or the
+      // counter target is too small and the block is factored before its last update arrived
+      const bool merged = fuse && nb2 == 2 * NB && NB % GT == 0 && ctx_opt_i(ctx, "chol.merge_gemm1", 1) != 0;
       if (!merged) GDML_TRY(launch_gemm_nt_sub(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, nb2, nb, 0));
       if (merged) {
         // ONE lower SYRK over everything right of the finished panel, in two launches of its super-tile list.  The first
@@ -1286,10 +1296,12 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
       nb = nb2;
     }
     HIP_CHECK(ctx, hipGetLastError());
-    int info = 0;
-    HIP_CHECK(ctx, hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    int info8[8] = {0};
+    HIP_CHECK(ctx, hipMemcpyAsync(info8, ctx->d_info, sizeof(info8), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (info_out) *info_out = info;
+    if (info8[7] != 0)
+      return gdml_fail(ctx, GDML_ERR_HIP, "Cholesky: the diagonal-block workgroup gave up waiting for its tiles (schedule bug)");
+    if (info_out) *info_out = info8[0];
     return GDML_OK;
   }
   // ---- round-1 schedule (option chol.fused_diag = 0; A/B reference): the step chain of panel k+1 on a second

@@ -139,6 +139,9 @@ class Iterative(object):
         n_inducing_pts = max(1, n_inducing_pts)
         if getattr(self.gdml_train, '_force_n_inducing_pts', None):
             n_inducing_pts = min(n_train, int(self.gdml_train._force_n_inducing_pts))
+        # sharded mode: rank 0's memory model decides for everybody (the reuse branch below, the restart growth and the
+        # sizes of every collective derive from this number)
+        n_inducing_pts = int(self._sync(np.array([n_inducing_pts], dtype=np.int64))[0])
         n_inducing_pts_init = (
             len(task['inducing_pts_idxs']) // dim_i if 'inducing_pts_idxs' in task else None
         )
@@ -180,10 +183,14 @@ class Iterative(object):
         steps_hist = collections.deque(maxlen=CG_STEPS_HIST_LEN)
         maxiter = 3 * n_atoms * n_train * 10  # iterative.py:747-750
 
+        sharded = getattr(ctx, '_bcast', None) is not None
+
         def _cg_status(it, resid, xk):
             """Reference policy per iteration (iterative.py:614-735); returns True to stop for a restart."""
             stop = timeit.default_timer()
             tt = 0.0 if state['start'] == 0 else (stop - state['start'])
+            if sharded:  # the cadence tests below gate collectives (checkpoint predict): every rank uses rank 0's clock
+                tt = float(self._sync(np.array([tt]))[0])
             state['avg_tt'] += tt
             state['start'] = timeit.default_timer()
             old_resid = state['resid']
@@ -223,7 +230,8 @@ class Iterative(object):
                     ctx.set_alphas(alphas_F, alphas_E)
                     E_pred, _ = ctx.predict(None)
                     unconv_model['c'] = np.mean(np.squeeze(task['E_train']) - E_pred * y_std)
-                save_progr_callback(unconv_model)
+                if not sharded or ctx.comm_info()[0] == 0:  # one writer
+                    save_progr_callback(unconv_model)
 
             state['num_iters'] += 1
             if len(steps_hist) == CG_STEPS_HIST_LEN and eff <= EFF_RESTART_THRESH and n_inducing_pts < n_train:

@@ -317,6 +317,17 @@ class GDMLTrain(object):
         use_analytic_solver = est_analytic < 0.95 * budget
         if self._force_solver is not None:
             use_analytic_solver = self._force_solver == 'analytic'
+        if world > 1:
+            if task['use_E_cstr']:
+                raise ValueError(
+                    'Energy constraints (use_E_cstr) are not supported after init_distributed(): the sharded solvers '
+                    'carry force rows only. Train this task on a single GPU (a GDMLTrain without init_distributed).'
+                )
+            # free HBM differs between ranks (rank 0 usually holds more): every rank must take rank 0's branch, or one
+            # enters the distributed Cholesky's collectives while another builds a preconditioner
+            bcast = getattr(self._context(), '_bcast', None)
+            if bcast is not None:
+                use_analytic_solver = bool(np.asarray(bcast(np.array([int(use_analytic_solver)], dtype=np.int64)))[0])
         solver_keys = {}
 
         if use_analytic_solver:

@@ -306,7 +306,56 @@ def case_n100_m3():
     g2._train_and_sample('n100_m3', 100, 3, np.arange(100)[None, :], 60, 4, seed=63, jitter=0.3, n_rows=160, n_cols=400)
 
 
-CASES = ['pcg_restart', 'pcg_warm_start', 'cli_sweep', 'cfg1_n21_m100', 'cfg3_n42_p27_m60', 'n100_m3']
+def case_cfg2_traj_m300():
+    """The synthetic configs[2] workload of bench.py (synth_trajectory: N = 21, low-dimensional "trajectory") at the
+    largest N_train the reference's CPU path solves in minutes: its own Iterative.solve with its own leverage-score
+    inducing points (memory budget chosen for k = 30), residual after every iteration, final alphas, predictions."""
+    r = g2.ref()
+    Desc, GDMLPredict, Iterative, gt = r['Desc'], r['GDMLPredict'], r['Iterative'], r['train']
+    import sgdml.solvers.iterative as it_mod
+    import bench
+
+    N, M, sig, lam, k = 21, 300, 20, 1e-10, 30
+    R, E, F = bench.synth_trajectory(N, M + 20, seed=3)
+    ds = {'R': R, 'E': E, 'F': F, 'z': np.full(N, 6)}
+    perms = np.arange(N)[None, :]
+    task = g2.make_task(ds, M, perms, sig, lam)
+    desc = Desc(N, max_processes=1)
+    tril_perms = np.array([Desc.perm(p) for p in perms])
+    tril_perms_lin = (tril_perms + np.arange(len(perms))[:, None] * desc.dim).flatten('F')
+    R_desc, R_d_desc = desc.from_R(R[:M].reshape(M, -1))
+    y = F[:M].ravel().copy()
+    y_std = np.std(y)
+    y /= y_std
+    hist, starts = [], []
+    real_cg, spy = _spy_cg(it_mod, hist, starts)
+    it_mod.sp.sparse.linalg.cg = spy
+    orig_k = Iterative.max_n_inducing_pts
+    Iterative.max_n_inducing_pts = staticmethod(lambda n_train, n_atoms, mb: k)
+    np.random.seed(7)
+    t0 = time.time()
+    try:
+        it = Iterative(gt, desc, 1, 1, False)
+        alphas, tol, n_iters, resid, train_rmse, inducing, is_conv = it.solve(
+            task, R_desc, R_d_desc, tril_perms_lin, y, y_std, tol=1e-4)
+    finally:
+        it_mod.sp.sparse.linalg.cg = real_cg
+        Iterative.max_n_inducing_pts = orig_k
+    dt = time.time() - t0
+    print('  cfg2_traj: k=%d iters=%d resid=%.3e conv=%s cg calls at %s  %.1fs' % (
+        len(inducing) // (3 * N), n_iters, resid, is_conv, starts, dt), flush=True)
+    model = gt.create_model(task, 'cg', R_desc, R_d_desc, tril_perms_lin, y_std, alphas)
+    pred = GDMLPredict(model, max_processes=1, use_torch=False)
+    Rt = R[M:]
+    E_test, F_test = pred.predict(Rt.reshape(len(Rt), -1))
+    g2.save('cfg2_traj_m300', R_train=R[:M], E_train=E[:M], F_train=F[:M], z=ds['z'], perms=perms, sig=np.float64(sig),
+            lam=np.float64(lam), y=y, y_std=np.float64(y_std), inducing_pts_idxs=np.asarray(inducing), k=np.int64(k),
+            resid_hist=np.array(hist), cg_starts=np.array(starts), n_iters=np.int64(n_iters), resid=np.float64(resid),
+            is_conv=np.bool_(is_conv), alphas=alphas, R_test=Rt, E_test=E_test, F_test=F_test,
+            ref_seconds=np.float64(dt), traj_seed=np.int64(3))
+
+
+CASES = ['pcg_restart', 'pcg_warm_start', 'cli_sweep', 'cfg1_n21_m100', 'cfg3_n42_p27_m60', 'n100_m3', 'cfg2_traj_m300']
 
 if __name__ == '__main__':
     todo = sys.argv[1:] or CASES

@@ -284,3 +284,44 @@ def test_predict_near_duplicate_queries(n_atoms, n_train, n_query):
         c.close()
     assert np.abs(F - F_ref).max() <= 1e-10 * np.abs(F_ref).max()
     assert np.abs(E - E_ref).max() <= 1e-10 * max(1.0, np.abs(E_ref).max())
+
+
+def test_configs2_trajectory_workload_vs_reference():
+    """bench.py's configs[2] workload family (synth_trajectory, N = 21) at N_train = 300, where the reference's CPU path
+    converges in minutes (make_golden_r3.case_cfg2_traj_m300: k = 30 inducing points drawn by the reference, 183
+    iterations to solver_tol 1e-4): with the reference's inducing columns our PCG needs the same number of iterations
+    (+-10 %), follows its residual history and gives the same predictions."""
+    from sgdml_amd import _lib
+    from sgdml_amd.utils.desc import Desc
+
+    g = load('cfg2_traj_m300')
+    M, N = g['R_train'].shape[:2]
+    sig, lam, y = float(g['sig']), float(g['lam']), g['y']
+    c = _lib.Context()
+    try:
+        xd, gd = c.desc_from_R(g['R_train'].reshape(M, -1), N)
+        tp = orc.tril_perms_from_atom_perms(g['perms'])
+        idx = g['inducing_pts_idxs']
+        c.train_upload(xd, gd, tp)
+        c.assemble_K(sig, False, idx=idx, alloc_extra_rows=len(idx))
+        c.nystroem_factor(lam, idx)
+        c.predict_upload_model(xd, np.zeros_like(xd), tp, sig, None)
+        hist = []
+        x, info, iters, resid = c.pcg(lam, False, y, rtol=1e-4, maxiter=5000, callback=lambda it, r, xk: hist.append(r) or False)
+        assert info == 0
+        n_ref = int(g['n_iters'])
+        assert abs(iters - n_ref) <= max(2, n_ref // 10), (iters, n_ref)
+        ref = g['resid_hist']
+        ours = np.array(hist)
+        np.testing.assert_allclose(ours[:8], ref[:8], rtol=1e-6)
+        k = min(len(ours), len(ref))
+        np.testing.assert_allclose(ours[:k], ref[:k], rtol=0.25)
+        d = Desc(N)
+        F = []
+        for coeffs in (g['alphas'], -x):
+            c.predict_upload_model(xd, d.d_desc_dot_vec(gd, coeffs.reshape(M, -1)), tp, sig, None)
+            F.append(c.predict(g['R_test'].reshape(len(g['R_test']), -1))[1])
+        assert np.abs(F[1] - F[0]).max() <= 5e-3 * np.abs(F[0]).max()
+        assert np.abs(F[0] * float(g['y_std']) - g['F_test']).max() <= 1e-8 * np.abs(g['F_test']).max()
+    finally:
+        c.close()
