@@ -558,6 +558,11 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
                          int cyc_W, int cyc_rank, int cyc_nb) {
   TrainSet& ts = ctx->ts;
   if (n_j <= 0 || i_end <= i_beg) return GDML_OK;
+  // small molecules, whole column points, plain row layout: the producer / consumer kernel of assemble_pts.hip
+  if (!d_jlist && !d_colmap && col0 == 0 && cyc_W == 0 && assemble_pts_applicable(ctx)) {
+    const int rc = assemble_pts_launch(ctx, sig, use_E, j0, n_j, K, ld, i_beg, i_end, lower, lam);
+    if (rc != GDML_ERR_UNSUPPORTED) return rc;  // no LDS layout for this (N, P): the general kernel below
+  }
   GDML_TRY(build_dense_tables(ctx));
   const int N = ts.N, P = ts.P;
   if ((lower || cyc_W > 0) && (d_jlist || d_colmap || use_E || j0 != 0 || i_beg != 0 || n_j != ts.M || i_end != ts.M))

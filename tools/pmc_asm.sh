@@ -12,6 +12,6 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IN
   (cd $R && timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_$i -- python tools/asm_perm_one.py "$@") > /tmp/pmc_$i.log 2>&1
   f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   echo "== pass $i: $set" >> $out
-  if [ -n "$f" ]; then python $R/tools/pmc_summary.py $f assemble_perm 2 >> $out; else tail -5 /tmp/pmc_$i.log >> $out; fi
+  if [ -n "$f" ]; then python $R/tools/pmc_summary.py $f assemble_p 2 >> $out; else tail -5 /tmp/pmc_$i.log >> $out; fi
 done
 cat $out
