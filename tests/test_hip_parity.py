@@ -795,6 +795,11 @@ def test_predict_mfma_randomised(ctx_factory, monkeypatch):
         assert np.abs(F1 - F0).max() <= 1e-11 * np.abs(F0).max(), (N, M, B, P, with_aE, sig)
         assert np.abs(E1 - E0).max() <= 1e-11 * np.abs(E0).max(), (N, M, B, P, with_aE, sig)
         c.close()
+        # ... and both against the oracle (predict.py:168-245), north_star's 1e-10
+        xq, gq = orc.desc_from_R(Rf[M:])
+        Eo, Fo = orc.predict_from_desc(xq, gq, xd, ja, tp, sig, alphas_E=aE)
+        assert np.abs(F1 - Fo).max() <= 1e-10 * np.abs(Fo).max(), (N, M, B, P, with_aE, sig)
+        assert np.abs(E1 - Eo).max() <= 1e-10 * max(1.0, np.abs(Eo).max()), (N, M, B, P, with_aE, sig)
 
 
 _P6_9 = np.array([[0, 1, 2, 3, 4, 5, 6, 7, 8], [1, 2, 0, 3, 4, 5, 6, 7, 8], [2, 0, 1, 3, 4, 5, 6, 7, 8],
@@ -897,3 +902,8 @@ def test_predict_wide_mfma(ctx_factory, n_atoms, n_train, n_query, n_perms, with
     E0, F0 = c.predict(Rq)
     assert np.abs(F1 - F0).max() <= 1e-11 * np.abs(F0).max()
     assert np.abs(E1 - E0).max() <= 1e-11 * np.abs(E0).max()
+    # the pipeline directly against the oracle (predict.py:168-245), north_star's 1e-10
+    xq, gq = orc.desc_from_R(Rq)
+    Eo, Fo = orc.predict_from_desc(xq, gq, xd, ja, tp, 25.0, alphas_E=aE, chunk=32)
+    assert np.abs(F1 - Fo).max() <= 1e-10 * np.abs(Fo).max()
+    assert np.abs(E1 - Eo).max() <= 1e-10 * max(1.0, np.abs(Eo).max())
