@@ -167,21 +167,23 @@ static int host_stage(gdml_ctx* ctx, int64_t bytes) {
   return GDML_OK;
 }
 
-int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk) {
+int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk) { return comm_allgather_inplace_on(ctx, buf, chunk, ctx->stream); }
+
+int comm_allgather_inplace_on(gdml_ctx* ctx, double* buf, int64_t chunk, hipStream_t st) {
   if (ctx->virtual_rank) return GDML_OK;
   if (ctx->host_allgather) {
     const int64_t tot = chunk * ctx->world;
     GDML_TRY(host_stage(ctx, tot * 8));
     double* mine = ctx->h_coll + (int64_t)ctx->rank * chunk;
-    HIP_CHECK(ctx, hipMemcpyAsync(mine, buf + (int64_t)ctx->rank * chunk, chunk * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(ctx, hipMemcpyAsync(mine, buf + (int64_t)ctx->rank * chunk, chunk * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (ctx->host_allgather(ctx->h_coll, chunk, ctx->host_coll_user) != 0)
       return gdml_fail(ctx, GDML_ERR_COMM, "host all-gather callback failed");
-    HIP_CHECK(ctx, hipMemcpyAsync(buf, ctx->h_coll, tot * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next collective
+    HIP_CHECK(ctx, hipMemcpyAsync(buf, ctx->h_coll, tot * 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(ctx, hipStreamSynchronize(st));  // the staging buffer is reused by the next collective
   } else if (ctx->comm) {
     ncclResult_t_ r = g_rccl.AllGather(buf + (int64_t)ctx->rank * chunk, buf, (size_t)chunk, kNcclDouble,
-                                       (ncclComm_t_)ctx->comm, ctx->stream);
+                                       (ncclComm_t_)ctx->comm, st);
     if (r != 0) return rccl_fail(ctx, "ncclAllGather", r);
   } else {
     return GDML_OK;
@@ -214,5 +216,33 @@ int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count) {
     ctx->coll_calls++;
     ctx->coll_bytes += 8.0 * (double)c;
   }
+  return GDML_OK;
+}
+
+// buf (count doubles) of rank `root` to every rank, on stream st.  RCCL: ncclBroadcast.  Host-staged backend (two
+// callbacks only: all-reduce, all-gather): the other ranks contribute zeros to an all-reduce.
+int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipStream_t st) {
+  if (ctx->virtual_rank) return GDML_OK;
+  if (ctx->host_allreduce) {
+    GDML_TRY(host_stage(ctx, count * 8));
+    if (ctx->rank == root) {
+      HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_coll, buf, count * 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(ctx, hipStreamSynchronize(st));
+    } else {
+      HIP_CHECK(ctx, hipStreamSynchronize(st));  // the previous user of the staging buffer
+      memset(ctx->h_coll, 0, (size_t)count * 8);
+    }
+    if (ctx->host_allreduce(ctx->h_coll, count, ctx->host_coll_user) != 0)
+      return gdml_fail(ctx, GDML_ERR_COMM, "host all-reduce callback failed (broadcast)");
+    if (ctx->rank != root) HIP_CHECK(ctx, hipMemcpyAsync(buf, ctx->h_coll, count * 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(ctx, hipStreamSynchronize(st));
+  } else if (ctx->comm) {
+    ncclResult_t_ r = g_rccl.Broadcast(buf, buf, (size_t)count, kNcclDouble, root, (ncclComm_t_)ctx->comm, st);
+    if (r != 0) return rccl_fail(ctx, "ncclBroadcast", r);
+  } else {
+    return GDML_OK;
+  }
+  ctx->coll_calls++;
+  ctx->coll_bytes += 8.0 * (double)count;
   return GDML_OK;
 }

@@ -206,6 +206,8 @@ int ctx_slot(gdml_ctx* ctx, int slot, int64_t bytes, double** out);
 void shard_points(const gdml_ctx* ctx, int64_t M, int64_t* p0, int64_t* p1, int64_t* pts_per);
 int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk);
 int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count);
+int comm_allgather_inplace_on(gdml_ctx* ctx, double* buf, int64_t chunk, hipStream_t st);
+int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipStream_t st);
 void comm_destroy(gdml_ctx* ctx);
 static inline bool comm_active(const gdml_ctx* ctx) { return (ctx->comm || ctx->host_allreduce) && !ctx->virtual_rank; }
 bool assemble_wave_applicable(const gdml_ctx* ctx);

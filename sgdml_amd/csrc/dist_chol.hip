@@ -12,21 +12,27 @@
 // row-cyclic mode for everything else), so the matrix never exists in one place:
 // n^2 * 8 / W bytes per GPU.  Cyclic ownership balances the lower-triangular work (row b has b blocks).
 //
-// Per panel k (right-looking):
-//   1. owner(k) factors the 512 x 512 diagonal block                                   (local)
-//   2. the factored block goes to every rank                      2 MB    all-reduce of a zero-padded buffer
-//   3. every rank solves ITS rows of the panel: X <- X L_kk^-T                          (panel_trsm_kernel, local)
-//   4. the panel is gathered: every rank needs all rows of it      (n - k0) * 512 * 8 B   all-gather + unpack
-//   5. every rank updates its rows of the trailing matrix          fp64 MFMA GEMM with the block-cyclic lower
-//                                                                  tile predicate (gemm_nt_sub, CyclicLower)
+// Per panel k (right-looking, one panel of look-ahead, three streams):
+//   critical stream   1. every rank solves ITS rows of the panel: X <- X L_kk^-T          (panel_trsm_kernel, local)
+//                     2. owner(k+1) sends its solved rows of block k+1 to every rank   2 MB    ncclBroadcast
+//                     3. every rank updates the NEXT panel's columns of its rows          (K = 512 GEMM, 512 columns)
+//                     4. owner(k+1) factors the 512 x 512 diagonal block k+1 and sends it   2 MB    ncclBroadcast
+//   collective stream 5. the panel is gathered: every rank needs all rows of it   (n - k0) * 512 * 8 B   all-gather + unpack
+//   bulk stream       6. every rank updates the columns right of block k+1 of its rows    fp64 MFMA GEMM with the
+//                                                                  block-cyclic lower tile predicate (CyclicLower)
+// Steps 1-4 of panel k+1 run while step 6 of panel k is still busy, step 5 of panel k runs under step 6 of panel k-1
+// (two panel buffers).  One rank, n = 63 000 (profiles/r03_dist_chol_lookahead_1rank.txt): 1.53 s against 1.39 s for the
+// single-GPU schedule with its fused diagonal-block role -- the panel chain is hidden.  All collectives are issued by one
+// host thread in the same order on every rank; with ONE communicator RCCL runs them in that order, so the block
+// broadcast of step 4 queues behind the gather of step 5 (shorter than step 6 from W = 2 on).  The host-staged backend
+// (ranks sharing a GPU: tests) runs every collective synchronously.  The RCCL branch has not run on more than one GPU
+// yet (tests/test_hip_scale.py::test_distributed_cholesky_rccl_one_gpu_per_rank is skipped on one-GPU boxes).
 // The right-hand side is carried by EVERY rank as one extra local row (replicated, 1 row), so the forward
-// substitution happens inside steps 3/5 like on one GPU (gdml_chol_set_rhs).  Backward substitution: the owner of
+// substitution happens inside steps 1/3/6 like on one GPU (gdml_chol_set_rhs).  Backward substitution: the owner of
 // block k solves L_kk^T x_k = z_k - sum_{i>k} L[i,k]^T x_i; the sum is spread over the ranks that own the rows i, each
 // keeps an accumulator and one 512-double all-reduce per step collects it.
 // Collective volume per rank: sum_k (n - k0) 512 * 8 B = 4 n^2 B (16 GB at n = 63 000) gathered over the whole
-// factorisation, against n^3 / (3 W) flops: at 8 GPUs ~0.1 s of xGMI time for ~0.2 s of MFMA time; steps 1-3 of panel
-// k+1 only need the first 512 columns of update k, so the gather can be overlapped with the rest of the update (not
-// done yet: everything runs on the compute stream in order).
+// factorisation, against n^3 / (3 W) flops: at 8 GPUs ~0.1 s of xGMI time for ~0.2 s of MFMA time.
 #include "common.h"
 
 namespace {
@@ -142,12 +148,13 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
 
   void* tmp = nullptr;
   const int64_t chunk = (max_lr + 1) * nb;                    // one rank's rows of a panel (+ rhs row), padded
-  const int64_t tmp_doubles = (nb * nb + 16) + c.W * chunk + n * nb + 3 * n + 2 * nb + 64 + c.W;
+  const int64_t tmp_doubles = 2 * (nb * nb + 16) + 2 * c.W * chunk + 2 * n * nb + 3 * n + 2 * nb + 64 + c.W;
   GDML_TRY(ctx_alloc(ctx, &tmp, tmp_doubles * 8));
-  double* Lbuf = (double*)tmp;                 // nb x nb (+ info slot)
-  double* G = Lbuf + nb * nb + 16;             // W chunks
-  double* P = G + c.W * chunk;                 // panel in global row order
-  double* d_acc = P + n * nb;                  // backward substitution: accumulator, solution, z
+  double* Lbuf = (double*)tmp;                 // nb x nb (+ info slot): factored diagonal block of the current panel
+  double* Pn = Lbuf + nb * nb + 16;            // nb x nb: solved panel rows of the NEXT block (look-ahead)
+  double* Gb[2] = {Pn + nb * nb + 16, Pn + nb * nb + 16 + c.W * chunk};  // W chunks, two panels in flight
+  double* Pb[2] = {Gb[1] + c.W * chunk, Gb[1] + c.W * chunk + n * nb};   // panel in global row order, two in flight
+  double* d_acc = Pb[1] + n * nb;              // backward substitution: accumulator, solution, z
   double* d_x = d_acc + n;
   double* d_z = d_x + n;
   double* d_blk = d_z + n;                     // 2 nb scratch
@@ -162,58 +169,118 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
     HIP_CHECK(ctx, hipStreamSynchronize(st));  // y is the caller's pageable array
     HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), st));
 
-    // ---- factorisation
+    // ---- factorisation, one panel of look-ahead over three streams:
+    //   sa (critical path)  panel solve k -> broadcast of the solved rows of block k+1 -> update of the NEXT panel's columns
+    //                       -> owner(k+1) factors diagonal block k+1 -> broadcast of it
+    //   sn (collective)     pack + all-gather + unpack of the whole panel k            (under the bulk update of panel k-1)
+    //   sb (bulk)           update of the columns right of block k+1 by panel k         (under the critical path of k+1)
+    // All collectives are issued from this one host thread in the same order on every rank (RCCL's requirement for one
+    // communicator used from several streams); the host-staged backend runs them synchronously, same results.
     phase_begin(ctx);
-    for (int64_t k = 0; k < c.nblk; ++k) {
-      const int64_t k0 = k * nb, w = c.rows_of(k), t0 = k0 + w;
+    HIP_CHECK(ctx, hipStreamSynchronize(st));  // assembly, right-hand side, info slot: visible to the other streams
+    hipStream_t sa = ctx->stream2, sb = st, sn = nullptr;  // stream2 is the high-priority one
+    HIP_CHECK(ctx, hipStreamCreateWithFlags(&sn, hipStreamNonBlocking));
+    hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_p[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
+    for (int e = 0; e < 2; ++e) {
+      HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_x[e], hipEventDisableTiming));
+      HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_p[e], hipEventDisableTiming));
+      HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_b[e], hipEventDisableTiming));
+    }
+    bool have_b[2] = {false, false};
+    auto factor_and_bcast = [&](int64_t k) -> int {  // diagonal block k: owner factors, everybody gets it (Lbuf)
+      const int64_t k0 = k * nb, w = c.rows_of(k);
       const int owner = (int)(k % c.W);
       if (owner == c.rank) {
         const int64_t lr0 = (k / c.W) * nb;
         // diagonal block at local rows lr0.., columns k0..: address it like a global square matrix of order k0 + w
         double* Av = A + (lr0 - k0) * ld;
-        GDML_TRY(panel_factor_steps(ctx, st, Av, k0 + w, ld, k0, w));
-        hipLaunchKernelGGL(pack_diag_kernel, dim3(ceil_div(nb * nb, 256)), dim3(256), 0, st, A + lr0 * ld + k0, ld, (int)w,
+        GDML_TRY(panel_factor_steps(ctx, sa, Av, k0 + w, ld, k0, w));
+        hipLaunchKernelGGL(pack_diag_kernel, dim3(ceil_div(nb * nb, 256)), dim3(256), 0, sa, A + lr0 * ld + k0, ld, (int)w,
                            (int)nb, Lbuf, ctx->d_info);
-      } else {
-        HIP_CHECK(ctx, hipMemsetAsync(Lbuf, 0, (nb * nb + 1) * 8, st));
       }
-      GDML_TRY(comm_allreduce_sum(ctx, Lbuf, nb * nb + 1));
-      // my rows below the panel (blocks with global index > k) + the right-hand-side row
-      const int64_t lb0 = c.lb0(c.rank, k);
-      const int64_t r_below = lb0 * nb < Lr ? lb0 * nb : Lr;  // (the globally last block may be short: then nothing but
-      const int64_t m_blk = Lr - r_below;                     //  the right-hand-side row follows it)
-      const int64_t m_all = m_blk + 1;
-      double* X = A + r_below * ld + k0;
-      if (w % 64 == 0) {
-        GDML_TRY(launch_panel_trsm(ctx, st, Lbuf, X, ld, (int)w, m_all, nb));
-      } else {  // ragged last block: 64-wide steps
-        for (int64_t jj = 0; jj < w; jj += 64) {
-          const int ww = (int)((w - jj < 64) ? w - jj : 64);
-          GDML_TRY(launch_trsm64(ctx, st, Lbuf + jj * nb + jj, X + jj, ld, ww, m_all, nb));
-          const int64_t rest = w - jj - ww;
-          if (rest > 0)
-            GDML_TRY(launch_gemm_nt_sub(ctx, st, X + jj, ld, Lbuf + (jj + ww) * nb + jj, nb, X + jj + ww, ld, m_all, rest, ww, 0));
+      return comm_broadcast_on(ctx, Lbuf, nb * nb + 1, owner, sa);
+    };
+    auto loop = [&]() -> int {
+      GDML_TRY(factor_and_bcast(0));
+      for (int64_t k = 0; k < c.nblk; ++k) {
+        const int64_t k0 = k * nb, w = c.rows_of(k), t0 = k0 + w;
+        const int par = (int)(k & 1);
+        // my rows below the panel (blocks with global index > k) + the right-hand-side row
+        const int64_t lb0 = c.lb0(c.rank, k);
+        const int64_t r_below = lb0 * nb < Lr ? lb0 * nb : Lr;  // (the globally last block may be short: then nothing but
+        const int64_t m_blk = Lr - r_below;                     //  the right-hand-side row follows it)
+        const int64_t m_all = m_blk + 1;
+        double* X = A + r_below * ld + k0;
+        // the columns of this panel received their last update from the bulk stream (panel k-1's update right of block k
+        // covers them only for k-1's look-ahead block = these columns: done on sa) -- nothing to wait for here
+        if (w % 64 == 0) {
+          GDML_TRY(launch_panel_trsm(ctx, sa, Lbuf, X, ld, (int)w, m_all, nb));
+        } else {  // ragged last block: 64-wide steps
+          for (int64_t jj = 0; jj < w; jj += 64) {
+            const int ww = (int)((w - jj < 64) ? w - jj : 64);
+            GDML_TRY(launch_trsm64(ctx, sa, Lbuf + jj * nb + jj, X + jj, ld, ww, m_all, nb));
+            const int64_t rest = w - jj - ww;
+            if (rest > 0)
+              GDML_TRY(launch_gemm_nt_sub(ctx, sa, X + jj, ld, Lbuf + (jj + ww) * nb + jj, nb, X + jj + ww, ld, m_all, rest, ww, 0));
+          }
         }
+        if (t0 >= n) break;
+        HIP_CHECK(ctx, hipEventRecord(ev_x[par], sa));  // X of panel k is final
+        const int64_t w1 = c.rows_of(k + 1);
+        const int owner1 = (int)((k + 1) % c.W);
+        // ---- sa: solved rows of block k+1 to everybody (they are the first rows below the panel on their owner)
+        if (owner1 == c.rank)
+          hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(w1 * nb, 256)), dim3(256), 0, sa, X, ld, w1, (int)w, (int)nb, Pn);
+        GDML_TRY(comm_broadcast_on(ctx, Pn, nb * nb, owner1, sa));
+        // ---- sn: the whole panel (block rows only; the rhs row is nobody's column)
+        int64_t m_pad = 0;
+        for (int r = 0; r < c.W; ++r) {
+          const int64_t mr = c.local_rows(r) - c.lb0(r, k) * nb;
+          if (mr > m_pad) m_pad = mr;
+        }
+        const int64_t ck = m_pad * nb;
+        const bool bulk = n - t0 - w1 > 0;  // columns right of block k+1 exist
+        if (bulk) {
+          HIP_CHECK(ctx, hipStreamWaitEvent(sn, ev_x[par], 0));
+          if (have_b[par]) HIP_CHECK(ctx, hipStreamWaitEvent(sn, ev_b[par], 0));  // buffers of panel k-2 are free
+          if (m_blk > 0)
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(m_blk * nb, 256)), dim3(256), 0, sn, X, ld, m_blk, (int)w, (int)nb,
+                               Gb[par] + (int64_t)c.rank * ck);
+          GDML_TRY(comm_allgather_inplace_on(ctx, Gb[par], ck, sn));
+          hipLaunchKernelGGL(unpack_panel_kernel, dim3(ceil_div((n - t0) * nb, 256)), dim3(256), 0, sn, Gb[par], ck, c, k, t0, Pb[par]);
+          HIP_CHECK(ctx, hipEventRecord(ev_p[par], sn));
+        }
+        // ---- sa: update of the next panel's columns [t0, t0 + w1) of my rows; they took panel k-1's bulk update
+        if (have_b[par ^ 1]) HIP_CHECK(ctx, hipStreamWaitEvent(sa, ev_b[par ^ 1], 0));
+        CyclicLower cl;
+        cl.W = c.W; cl.rank = c.rank; cl.lb0 = lb0; cl.nb = nb; cl.col0 = t0; cl.block_rows = m_blk;
+        GDML_TRY(launch_gemm_nt_sub_cyclic(ctx, sa, X, ld, Pn, nb, A + r_below * ld + t0, ld, m_all, w1, w, cl));
+        // ---- sa: diagonal block k+1 is complete on its owner
+        GDML_TRY(factor_and_bcast(k + 1));
+        // ---- sb: everything right of block k+1
+        if (bulk) {
+          HIP_CHECK(ctx, hipStreamWaitEvent(sb, ev_p[par], 0));
+          cl.col0 = t0 + w1;
+          GDML_TRY(launch_gemm_nt_sub_cyclic(ctx, sb, X, ld, Pb[par] + w1 * nb, nb, A + r_below * ld + t0 + w1, ld, m_all,
+                                             n - t0 - w1, w, cl));
+          HIP_CHECK(ctx, hipEventRecord(ev_b[par], sb));
+          have_b[par] = true;
+        }
+        HIP_CHECK(ctx, hipGetLastError());
       }
-      if (t0 >= n) break;
-      // gather the panel rows of all ranks (block rows only; the rhs row is nobody's column)
-      int64_t m_pad = 0;
-      for (int r = 0; r < c.W; ++r) {
-        const int64_t mr = c.local_rows(r) - c.lb0(r, k) * nb;
-        if (mr > m_pad) m_pad = mr;
-      }
-      const int64_t ck = m_pad * nb;
-      if (m_blk > 0)
-        hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(m_blk * nb, 256)), dim3(256), 0, st, X, ld, m_blk, (int)w, (int)nb,
-                           G + (int64_t)c.rank * ck);
-      GDML_TRY(comm_allgather_inplace(ctx, G, ck));
-      hipLaunchKernelGGL(unpack_panel_kernel, dim3(ceil_div((n - t0) * nb, 256)), dim3(256), 0, st, G, ck, c, k, t0, P);
-      // trailing update of my rows: C[my rows, t0:n] -= X_mine P^T, lower tiles of the cyclic layout only
-      CyclicLower cl;
-      cl.W = c.W; cl.rank = c.rank; cl.lb0 = lb0; cl.nb = nb; cl.col0 = t0; cl.block_rows = m_blk;
-      GDML_TRY(launch_gemm_nt_sub_cyclic(ctx, st, X, ld, P, nb, A + r_below * ld + t0, ld, m_all, n - t0, w, cl));
-      HIP_CHECK(ctx, hipGetLastError());
+      return GDML_OK;
+    };
+    const int rc_loop = loop();
+    (void)hipStreamSynchronize(sn);
+    (void)hipStreamSynchronize(sb);
+    (void)hipStreamSynchronize(sa);
+    for (int e = 0; e < 2; ++e) {
+      (void)hipEventDestroy(ev_x[e]);
+      (void)hipEventDestroy(ev_p[e]);
+      (void)hipEventDestroy(ev_b[e]);
     }
+    (void)hipStreamDestroy(sn);
+    GDML_TRY(rc_loop);
     GDML_TRY(phase_end(ctx, "factor"));
     // first failing pivot over all ranks (0 = none): every rank reports its own in slot `rank` of a summed vector
     {

@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out_path, n_atoms, n_train, nb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    backend = sys.argv[5] if len(sys.argv) > 5 else 'host'  # 'rccl': one GPU per rank, collectives inside the library
     import torch.distributed as dist
 
     dist.init_process_group('gloo')
@@ -22,8 +23,8 @@ def main():
 
     ds = orc.synth_dataset(n_atoms, n_train, seed=9, jitter=0.3)
     y = ds['F'].ravel() / np.std(ds['F'])
-    ctx = _lib.Context(0)
-    init_comm_from_torch_distributed(ctx, backend='host')
+    ctx = _lib.Context(0 if backend == 'host' else int(os.environ.get('LOCAL_RANK', rank)))
+    init_comm_from_torch_distributed(ctx, backend=backend)
     ctx.set_option('dist.nb', nb)
     xd, gd = ctx.desc_from_R(ds['R'].reshape(n_train, -1), n_atoms)
     ctx.train_upload(xd, gd, np.arange(n_atoms * (n_atoms - 1) // 2, dtype=np.int64)[None])

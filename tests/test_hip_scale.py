@@ -392,7 +392,31 @@ def test_distributed_cholesky_processes_share_one_gpu(tmp_path, ctx, world, N, M
     assert np.abs(r['alphas'] - a_ref).max() <= 1e-5 * np.abs(a_ref).max()
     n = 3 * N * M
     nblk = -(-n // nb)
-    assert int(r['coll_calls']) >= 2 * nblk  # per panel: block broadcast + panel gather (+ backward substitution)
+    assert int(r['coll_calls']) >= 2 * nblk  # per panel: diagonal block + look-ahead block broadcasts, panel gather (+ backward substitution)
+
+
+def test_distributed_cholesky_rccl_one_gpu_per_rank(tmp_path, ctx):
+    """The same factorisation with RCCL (ncclBroadcast of the diagonal / look-ahead blocks, ncclAllGather of the panels from
+    the collective stream, all-reduces of the backward substitution) on two physical GPUs.  Skipped on a one-GPU box: until
+    a multi-GPU box has run this test the RCCL branch of csrc/dist_chol.hip counts as unverified (README, DESIGN)."""
+    from sgdml_amd import _lib
+
+    if _lib.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    N, M, nb, world = 21, 60, 128, 2
+    out = str(tmp_path / 'dchol_rccl.npz')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = 29400 + (os.getpid() % 300)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', '_dist_chol_worker.py'), out, str(N), str(M), str(nb), 'rccl']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r = dict(np.load(out))
+    a_ref, Kop = _reference_solve(ctx, r['R'], r['y'], N, 20.0, 1e-10)
+    res = Kop(-r['alphas']) + r['y']
+    assert np.linalg.norm(res) <= 1e-9 * np.linalg.norm(r['y'])
+    assert np.abs(r['alphas'] - a_ref).max() <= 1e-4 * np.abs(a_ref).max()
 
 
 def test_dropin_train_distributed_analytic(tmp_path):
