@@ -42,6 +42,7 @@ struct PtsArgs {
   int n_g, pg_eff;      // permutation groups per row point, permutations per group
   int o_img, o_gjs, o_xjs, o_vb, o_tr, o_perm;  // LDS offsets in doubles
   int nt_store;         // non-temporal stores of K (asm.pts_nt)
+  int xcd_map, n_strips; // XCD-contiguous strip order (asm.pts_xcd)
   int dbg;              // timing-only ablation (asm.pts_debug): 1 no stores, 2 no producer tasks, 4 no O phase
   double* K;
   int64_t ld;
@@ -67,7 +68,7 @@ __device__ __forceinline__ double pts_seg_scan(double v, int pos) {  // inclusiv
 // PG: permutations per step (1, 2, 4).  A group that has fewer (the last one, or P = 3) repeats its first permutation in the
 // unused slots with zero Matern scalars: no branch depends on the group size.
 template <int PG, int NA>
-__global__ void __launch_bounds__(NA == 2 ? 1024 : 768) assemble_pts_kernel(PtsArgs A) {
+__global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using VBL = PtsVB<PG>;
   const int N = A.N, N3 = 3 * N, NN = N * N, P = A.P, PPS = A.PPS, NO = A.NO, NV = A.NV;
@@ -84,7 +85,13 @@ __global__ void __launch_bounds__(NA == 2 ? 1024 : 768) assemble_pts_kernel(PtsA
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = w >= NO;
   const int vw = w - NO;  // producer index
-  const int jv0 = (int)blockIdx.x * PPS;  // first (virtual) column point of the strip
+  // blockIdx.x -> strip: workgroup x runs on XCD x % 8 (gridDim.x is a multiple of 8), and XCD q takes the q-th eighth of
+  // the strips, so that the workgroups resident on one XCD own ADJACENT strips and walk the same rows together: the cache
+  // lines that straddle two strips (rows are 3 N PPS doubles, not a multiple of 16) meet in one L2 and leave it whole
+  const int spx = (int)gridDim.x >> 3;
+  const int strip = A.xcd_map ? ((int)blockIdx.x & 7) * spx + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  if (strip >= A.n_strips) return;
+  const int jv0 = strip * PPS;  // first (virtual) column point of the strip
   const int ql = lane / N;
   const bool lane_in = ql < PPS;  // lanes past the strip's last point idle (their loads are clamped to lane 0's data)
   const int q = lane_in ? ql : 0;
@@ -495,23 +502,26 @@ int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_
   A.n_g = (P + 3) / 4;
   A.pg_eff = (P + A.n_g - 1) / A.n_g;  // equal groups of at most four
   const int PG = A.pg_eff >= 3 ? 4 : A.pg_eff;
-  // two row atoms per consumer and 16 wavefronts (128 VGPRs) where the LDS holds the extra row buffers, else three and 12
-  int NA = ctx_opt_i(ctx, "asm.pts_na", 0);
-  const int nv_opt = ctx_opt_i(ctx, "asm.pts_nv", 0);
-  for (int na = (NA == 2 ? 2 : 3); na <= 3; ++na) {  // default three: the 128-VGPR shape spills (measured slower)
-    const int waves = na == 2 ? 16 : 12;
+  // row atoms per consumer wavefront: three (asm.pts_na forces 1 or 2: more consumers, fewer producers -- measured slower
+  // or equal at N = 9 .. 21, the producers being the critical path: profiles/r03_assemble_pts.txt)
+  int NA = -1;
+  const int na_opt = ctx_opt_i(ctx, "asm.pts_na", 0), nv_opt = ctx_opt_i(ctx, "asm.pts_nv", 0);
+  size_t lds = 0;
+  auto dispatch = [&](int na, dim3 g, size_t* lds_out) {
+#define PTS_GO(pg) do { if (na == 1) pts_launch_t<pg, 1>(ctx, A, g, lds_out); else if (na == 2) pts_launch_t<pg, 2>(ctx, A, g, lds_out); \
+                        else pts_launch_t<pg, 3>(ctx, A, g, lds_out); } while (0)
+    if (PG == 1) PTS_GO(1); else if (PG == 2) PTS_GO(2); else PTS_GO(4);
+#undef PTS_GO
+  };
+  for (int na = (na_opt >= 1 && na_opt <= 3) ? na_opt : 3; na <= 3; ++na) {
     A.NO = (N + na - 1) / na;
-    A.NV = waves - A.NO < 1 + PG ? waves - A.NO : 1 + PG;
-    if (nv_opt >= 1 && nv_opt <= waves - A.NO) A.NV = nv_opt;
-    while (A.NO + A.NV < waves && 4 * NN > 64 * A.NV * 9) ++A.NV;  // the image hand-over needs 4 N^2 / 9 producer lanes
-    size_t lds = 0;
-    dim3 g0(1);
-    if (A.NV >= 1 && 4 * NN <= 64 * A.NV * 9) {
-      if (na == 2) { if (PG == 1) pts_launch_t<1, 2>(ctx, A, g0, &lds); else if (PG == 2) pts_launch_t<2, 2>(ctx, A, g0, &lds); else pts_launch_t<4, 2>(ctx, A, g0, &lds); }
-      else { if (PG == 1) pts_launch_t<1, 3>(ctx, A, g0, &lds); else if (PG == 2) pts_launch_t<2, 3>(ctx, A, g0, &lds); else pts_launch_t<4, 3>(ctx, A, g0, &lds); }
-      if (lds <= 160 * 1024) { NA = na; break; }
-    }
-    NA = -1;
+    const int nv_want = 1 + PG < 3 ? 1 + PG : (na == 3 ? 1 + PG : 3);
+    A.NV = 12 - A.NO < 1 + PG ? 12 - A.NO : 1 + PG;
+    if (nv_opt >= 1 && nv_opt <= 12 - A.NO) A.NV = nv_opt;
+    if (A.NV < 1 || (A.NV < nv_want && na < 3 && nv_opt < 1)) continue;
+    if (4 * NN > 64 * A.NV * 9) continue;  // the image hand-over needs 4 N^2 / 9 producer lanes
+    dispatch(na, dim3(1), &lds);
+    if (lds <= 160 * 1024) { NA = na; break; }
   }
   if (NA < 0) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_pts: no LDS layout for N=%d P=%d", N, P);
   const int64_t n_strips = (n_j + A.PPS - 1) / A.PPS;
@@ -519,10 +529,11 @@ int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_
   int i_chunk = ctx_opt_i(ctx, "asm.pts_i_chunk", 8);
   while (i_chunk > 4 && n_strips * ((n_i + i_chunk - 1) / i_chunk) < 1024) i_chunk >>= 1;
   A.i_chunk = i_chunk;
-  dim3 grid((unsigned)n_strips, (unsigned)((n_i + i_chunk - 1) / i_chunk));
+  A.xcd_map = ctx_opt_i(ctx, "asm.pts_xcd", 1);
+  A.n_strips = (int)n_strips;
+  dim3 grid((unsigned)((n_strips + 7) / 8 * 8), (unsigned)((n_i + i_chunk - 1) / i_chunk));
   const int slot = ktime_begin(ctx);
-  if (NA == 2) { if (PG == 1) pts_launch_t<1, 2>(ctx, A, grid); else if (PG == 2) pts_launch_t<2, 2>(ctx, A, grid); else pts_launch_t<4, 2>(ctx, A, grid); }
-  else { if (PG == 1) pts_launch_t<1, 3>(ctx, A, grid); else if (PG == 2) pts_launch_t<2, 3>(ctx, A, grid); else pts_launch_t<4, 3>(ctx, A, grid); }
+  dispatch(NA, grid, nullptr);
   const double blocks = A.lower ? 0.5 * (double)n_i * (double)(n_i + 1) : (double)n_i * (double)n_j;
   ktime_end(ctx, slot, "assemble", 8.0 * blocks * 9.0 * N * N);
   ctx->launch_counter++;
