@@ -15,10 +15,12 @@
 //   * the workgroup is split by ROLE.  Consumer wavefront w owns the row atoms 3 w .. 3 w + 2 (27 accumulators per lane),
 //     runs the O phase of step t and writes its 9 rows; the producer wavefronts compute v_p, |d_p|^2 -> Matern scalars,
 //     u_p, dg_p of step t + 1 into the other half of a double-buffered LDS area meanwhile.  A step is (row point i, group
-//     of <= 4 permutations); one barrier per step, a second one per row point behind the image hand-over;
+//     of <= 4 permutations); one barrier per step;
 //   * 12 wavefronts per CU at <= 168 VGPRs: three per SIMD instead of two, and roles with short live ranges;
-//   * the image of row point i + 2 travels through producer registers underneath step (i, .) and lands in the buffer that
-//     point i frees.
+//   * three rotating LDS images of row points: the image of point i + 2 is requested at the start of unit i with LDS-DMA
+//     (global_load_lds: no registers, no wait) into the buffer point i - 1 freed, and only has to have landed by the end
+//     of the unit (the register hand-over of the first version ended up in scratch with a wait at the top of the unit:
+//     a cache-hot image was worth 4.7 of 19 ms).
 // Stores: a row of a strip is 3 N PPS consecutive doubles (1512 bytes at N = 21); each row is transposed through a
 // 1.5 KB per-wavefront LDS buffer so that a store instruction writes 64 consecutive doubles.
 #include <type_traits>
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
   using VBL = PtsVB<PG>;
   const int N = A.N, N3 = 3 * N, NN = N * N, P = A.P, PPS = A.PPS, NO = A.NO, NV = A.NV;
   const int T = 64 * (NO + NV);
-  double* const IMG = smem + A.o_img;  // [2][ G: [m][b][c] (3 NN) | X: [m][b] (NN) ]
+  double* const IMG = smem + A.o_img;  // [3][ G: [m][b][c] (3 NN) | X: [m][b] (NN) ]: row point ti lives in buffer ti % 3
   double* const GjS = smem + A.o_gjs;  // [m][c][lane]  G_j(b,m)[c] of the lane's column atom
   double* const XjS = smem + A.o_xjs;  // [m][lane]     x_j[pair(b,m)]
   double* const VB = smem + A.o_vb;    // [2][ vs: [pl][c][lane=(q,a)] | ud: [pl][12][lane] | scal: [pl][q][4] ]
@@ -85,9 +87,12 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = w >= NO;
   const int vw = w - NO;  // producer index
-  // blockIdx.x -> strip: workgroup x runs on XCD x % 8 (gridDim.x is a multiple of 8), and XCD q takes the q-th eighth of
-  // the strips, so that the workgroups resident on one XCD own ADJACENT strips and walk the same rows together: the cache
-  // lines that straddle two strips (rows are 3 N PPS doubles, not a multiple of 16) meet in one L2 and leave it whole
+  // blockIdx.x -> strip: workgroup x runs on XCD x % 8 (gridDim.x is a multiple of 8).  Full form: XCD q takes the q-th eighth
+  // of the strips, so that the workgroups resident on one XCD own ADJACENT strips and walk the same rows together -- the
+  // cache lines that straddle two strips (rows are 3 N PPS doubles, not a multiple of 16) meet in one L2 and leave it whole
+  // (10.6 vs 10.9 ms).  Lower form: a strip's work falls linearly with its index, contiguous eighths would give XCD 0 twice
+  // the average (9.7 ms instead of 6.4): plain order there (groups of 8 adjacent strips dealt round-robin measured worse
+  // than either).
   const int spx = (int)gridDim.x >> 3;
   const int strip = A.xcd_map ? ((int)blockIdx.x & 7) * spx + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
   if (strip >= A.n_strips) return;
@@ -138,11 +143,11 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
   }
   __syncthreads();
 
-  // ---- producer side: the V results of step (row point i_lo + ti, group g) into half `par` of the V area
-  auto produce = [&](int ti, int g, int par) {
+  // ---- producer side: the V results of step (row point in image buffer b3, group g) into half `par` of the V area
+  auto produce = [&](int b3, int g, int par) {
     const int g0 = g * pg_eff;
     const int npg = (P - g0 < pg_eff) ? P - g0 : pg_eff;
-    const double* const SG = IMG + (ti & 1) * 4 * NN;
+    const double* const SG = IMG + b3 * 4 * NN;
     const double* const SX = SG + 3 * NN;
     double* const vs = VB + par * VBL::SIZE;
     double* const ud = vs + VBL::VS;
@@ -272,37 +277,33 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
   // The two roles run the same sequence of barriers (one per step, a second one behind every image hand-over) in separate
   // loops, so that neither carries the other's registers.
   if (producer) {
-    constexpr int NPF = 9;  // image doubles a producer lane carries: 4 N^2 <= 64 NV NPF (N <= 24, NV >= 4)
-    double pf[NPF];
-    const int ptid = tid - 64 * NO, PT = 64 * NV;
-    int par = 0;
-    for (int ti = 0; ti < n_i; ++ti) {
-      const bool more = ti + 2 < n_i;  // image of point i + 2 replaces the image of point i
-      if (more) {
-        const int64_t ip = (A.dbg & 8) ? i_lo : i_lo + ti + 2;  // ablation 8: a cache-hot image
-        const double* gi = A.GD + ip * (int64_t)NN * 3;
-        const double* xi = A.XF + ip * (int64_t)NN;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-          const int e = ptid + PT * k;
-          pf[k] = (e < 3 * NN) ? gi[e] : ((e < 4 * NN) ? xi[e - 3 * NN] : 0.0);
+    // image of row point i_lo + tp into buffer b3: 8 N^2 dwords, 64 per instruction, this wavefront's share
+    auto request = [&](int tp, int b3) {
+      const int64_t ip = (A.dbg & 8) ? i_lo : i_lo + tp;  // ablation 8: a cache-hot image
+      const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(A.GD + ip * (int64_t)NN * 3);
+      const uint32_t* xsrc = reinterpret_cast<const uint32_t*>(A.XF + ip * (int64_t)NN);
+      char* dst = reinterpret_cast<char*>(IMG + b3 * 4 * NN);
+      for (int e0 = vw * 64; e0 < 8 * NN; e0 += NV * 64) {
+        const int e = e0 + lane;
+        if (e < 8 * NN) {
+          const uint32_t* src = (e < 6 * NN) ? gsrc + e : xsrc + (e - 6 * NN);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(dst + e0 * 4), 4, 0, 0);
         }
       }
+    };
+    int par = 0, b_cur = 0;  // b_cur = ti % 3
+    for (int ti = 0; ti < n_i; ++ti) {
+      const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_nn = b_nxt == 2 ? 0 : b_nxt + 1;
+      if (ti + 2 < n_i) request(ti + 2, b_nn);
       for (int g = 0; g < n_g; ++g) {
         par ^= 1;
-        if (g + 1 < n_g) produce(ti, g + 1, par);
-        else if (ti + 1 < n_i) produce(ti + 1, 0, par);
+        if (g + 1 < n_g) produce(b_cur, g + 1, par);
+        else if (ti + 1 < n_i) produce(b_nxt, 0, par);
+        if (g == n_g - 1) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the requested image has landed
         __syncthreads();  // this step consumed, the next one produced
       }
-      if (more) {
-        double* im = IMG + (ti & 1) * 4 * NN;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-          const int e = ptid + PT * k;
-          if (e < 4 * NN) im[e] = pf[k];
-        }
-        __syncthreads();
-      }
+      b_cur = b_nxt;
     }
     return;
   }
@@ -327,10 +328,11 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
   double erow[3] = {0.0, 0.0, 0.0};
   const double* const gjl = GjS + lane;
 
-  int par = 0;
+  int par = 0, b_cur = 0;
   for (int ti = 0; ti < n_i; ++ti) {
     const int64_t i = i_lo + ti;
-    const double* const SG = IMG + (ti & 1) * 4 * NN;
+    const double* const SG = IMG + b_cur * 4 * NN;
+    b_cur = b_cur == 2 ? 0 : b_cur + 1;
 #pragma unroll
     for (int k = 0; k < NA; ++k)
 #pragma unroll
@@ -403,7 +405,6 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
       }
       __syncthreads();  // this step consumed, the next one produced
     }
-    if (ti + 2 < n_i) __syncthreads();  // image hand-over (the producers write between the two barriers)
     __builtin_amdgcn_sched_barrier(0);
     {
       // ---- the rows of this wavefront, underneath the producers' next step: one row per LDS round trip, stores of 64
@@ -468,7 +469,7 @@ template <int PG, int NA>
 static void pts_launch_t(gdml_ctx* ctx, PtsArgs& A, dim3 grid, size_t* lds_out = nullptr) {
   const int N = A.N, NN = N * N;
   int o = 0;
-  A.o_img = o; o += 2 * 4 * NN;
+  A.o_img = o; o += 3 * 4 * NN;
   A.o_gjs = o; o += N * 3 * 64;
   A.o_xjs = o; o += N * 64;
   A.o_vb = o; o += 2 * PtsVB<PG>::SIZE;
@@ -519,17 +520,16 @@ int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_
     A.NV = 12 - A.NO < 1 + PG ? 12 - A.NO : 1 + PG;
     if (nv_opt >= 1 && nv_opt <= 12 - A.NO) A.NV = nv_opt;
     if (A.NV < 1 || (A.NV < nv_want && na < 3 && nv_opt < 1)) continue;
-    if (4 * NN > 64 * A.NV * 9) continue;  // the image hand-over needs 4 N^2 / 9 producer lanes
     dispatch(na, dim3(1), &lds);
     if (lds <= 160 * 1024) { NA = na; break; }
   }
   if (NA < 0) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_pts: no LDS layout for N=%d P=%d", N, P);
   const int64_t n_strips = (n_j + A.PPS - 1) / A.PPS;
   const int64_t n_i = i_end - i_beg;
-  int i_chunk = ctx_opt_i(ctx, "asm.pts_i_chunk", 8);
+  int i_chunk = ctx_opt_i(ctx, "asm.pts_i_chunk", 64);
   while (i_chunk > 4 && n_strips * ((n_i + i_chunk - 1) / i_chunk) < 1024) i_chunk >>= 1;
   A.i_chunk = i_chunk;
-  A.xcd_map = ctx_opt_i(ctx, "asm.pts_xcd", 1);
+  A.xcd_map = ctx_opt_i(ctx, "asm.pts_xcd", 1) && !A.lower;
   A.n_strips = (int)n_strips;
   dim3 grid((unsigned)((n_strips + 7) / 8 * 8), (unsigned)((n_i + i_chunk - 1) / i_chunk));
   const int slot = ktime_begin(ctx);
