@@ -346,10 +346,20 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
       const double* const ud = vs + VBL::VS;
       const double* const scal = ud + VBL::UD;
       par ^= 1;
-      for (int pl = 0; pl < ((A.dbg & 4) ? 0 : npg); ++pl) {
-        const int p = g0 + pl;
-        const int ap = pinvS[p * N + b];
-        const int prow = permS[p * N + lrow];
+      // the permutation-table entries of the whole group in one batch of loads (one LDS latency instead of one per
+      // permutation); unused slots repeat the group's first permutation, their Matern scalars are zero
+      int ap_g[PG], prow_g[PG];
+#pragma unroll
+      for (int pl = 0; pl < PG; ++pl) {
+        const int p = g0 + (pl < npg ? pl : 0);
+        ap_g[pl] = pinvS[p * N + b];
+        prow_g[pl] = permS[p * N + lrow];
+      }
+#pragma unroll
+      for (int pl = 0; pl < PG; ++pl) {
+        if ((A.dbg & 4) || pl >= npg) break;
+        const int ap = ap_g[pl];
+        const int prow = prow_g[pl];
         const double* sc = scal + (pl * PTS_MAXQ + q) * 4;
         const double beta = sc[0], cn = sc[1];
         const double* udp = ud + pl * 12 * 64 + lane;
