@@ -97,6 +97,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *                         full-line stores, row points per workgroup
  *   asm.threads, asm.ib, asm.minw, asm.gj_global, asm.j_chunk, asm.debug   LDS-kernel shape / ablations
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
+ *   gemm.nt_c (0)         non-temporal loads / stores of the C tile; gemm.stagger (0) k-tiles by which neighbouring tiles offset
+ *                         the start of their k loop (both after rocBLAS's Tensile kernel for this shape: profiles/r03_vendor_kernels.txt)
  *   gemm.cacc (1)         fused GEMM launches: interior tiles accumulate into C loaded up front (0: load-subtract-store epilogue)
  *   gemm.pipe (0)         fused GEMM launches: operand reads one k-step ahead across the tile boundary
  *   gemm.commit_ks (12)   fused GEMM launches: 4 = A/B reference with the early LDS commit of the prefetched tile

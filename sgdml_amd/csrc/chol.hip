@@ -64,6 +64,8 @@ struct GemmArgs {
   int64_t diag_off; // global index of its first row (LAPACK info)
   int* diag_info;
   int dbg;          // option gemm.debug: ablation bits: 1 no epilogue, 2 no tile loads, 4 no LDS reads, 8 no barrier
+  int nt_c;         // option gemm.nt_c: non-temporal loads / stores of the C tile (it is streamed: keep the L2 for the panels)
+  int stagger;      // option gemm.stagger: tiles start their k loop at different offsets (wrapping), in steps of this many k-tiles
   // merged trailing update (lower): the first super-tile COLUMN (the next outer panel's own columns) is enumerated
   // first; the tiles of its leading ready_rows x ready_rows tile block (the diagonal block workgroup 0 is about to
   // factor) count themselves into *ready when their C tile is stored, workgroup 0 waits for ready_target
@@ -143,17 +145,26 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (CIN) {
+        if (g.nt_c) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = (Ct + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff + j * 16];
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_nontemporal_load((Ct + (int64_t)(i * 16 + 4 * r) * g.ldc) + coff + j * 16);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = (Ct + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff + j * 16];
+        }
       } else {
         acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
       }
     }
 
   const int64_t nk = (g.K + GBK - 1) / GBK;
+  // staggered start (full tiles only; the sum over k is order independent up to rounding): neighbouring tiles do not ask
+  // for the same k range of their panels at the same time
+  const int64_t kt0 = (FULL && g.stagger > 0) ? (((row0 / GT) * 5 + (col0 / GT) * 3) & 15) * g.stagger % nk : 0;
+  auto kofs = [&](int64_t kt) -> int64_t { const int64_t k = kt + kt0; return (k >= nk ? k - nk : k) * GBK; };
   d2 ra[4], rb[4];
-  gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, 0, g.K, tid, ra);
-  gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, 0, g.K, tid, rb);
+  gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(0), g.K, tid, ra);
+  gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(0), g.K, tid, rb);
   gemm_store_tile(lds[0][0], tid, ra);
   gemm_store_tile(lds[0][1], tid, rb);
   __syncthreads();
@@ -181,8 +192,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
     for (int64_t kt = 0; kt < nk; ++kt) {
       const int cur = (int)(kt & 1);
       if (kt + 1 < nk && !(dbg & 2)) {
-        gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
-        gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
+        gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(kt + 1), g.K, tid, ra);
+        gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(kt + 1), g.K, tid, rb);
       }
   #pragma unroll
       for (int ks = 0; ks < GBK; ks += 4) {
@@ -216,8 +227,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
     for (int64_t kt = 0; kt < nk; ++kt) {
       const int cur = (int)(kt & 1);
       if (kt + 1 < nk && !(dbg & 2)) {
-        gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, (kt + 1) * GBK, g.K, tid, ra);
-        gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, (kt + 1) * GBK, g.K, tid, rb);
+        gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(kt + 1), g.K, tid, ra);
+        gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(kt + 1), g.K, tid, rb);
       }
       const double* As = lds[cur][0] + (wm * 64 + li) * GPITCH + lk;
       const double* Bs = lds[cur][1] + (wn * 64 + li) * GPITCH + lk;
@@ -261,6 +272,15 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
     double* Ct2 = Ct;
     unsigned coff2 = coff;
     asm volatile("" : "+v"(Ct2), "+v"(coff2));
+    if (g.nt_c) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(acc[i][j][r], (Ct2 + (int64_t)(i * 16 + 4 * r) * g.ldc) + coff2 + j * 16);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -413,6 +433,8 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   g.A2 = g.B2 = nullptr; g.C2 = nullptr; g.M2 = g.N2 = g.K2 = 0; g.tiles2 = 0;
   if (cyc) { g.cyc_W = cyc->W; g.cyc_rank = cyc->rank; g.cyc_lb0 = cyc->lb0; g.cyc_nb = cyc->nb; g.cyc_col0 = cyc->col0; g.cyc_block_rows = cyc->block_rows; }
   g.dbg = ctx_opt_i(ctx, "gemm.debug", 0);
+  g.nt_c = ctx_opt_i(ctx, "gemm.nt_c", 0);
+  g.stagger = ctx_opt_i(ctx, "gemm.stagger", 0);
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
               (lda % 2 == 0) && (ldb % 2 == 0);
   g.tiles_m = (int)((M + GT - 1) / GT);

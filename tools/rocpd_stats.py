@@ -24,6 +24,11 @@ def main(path, out=None):
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lines.append('%-64s %8d %14.3f %12.2f %12.2f %12.2f %6.2f%%' % (
             k[:64], a[0], a[1] / 1e6, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / tot))
+    import os
+    if os.environ.get('FULL_NAMES'):  # kernel names in full (Tensile encodes its whole configuration there)
+        lines.append('')
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ['FULL_NAMES'])]:
+            lines.append('%10.3f ms  %s' % (a[1] / 1e6, k))
     txt = '\n'.join(lines)
     print(txt)
     if out:
