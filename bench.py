@@ -395,6 +395,13 @@ def main():
     if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) != args.gpus:
         sys.exit('bench.py: --gpus {} but the launcher started {} ranks'.format(args.gpus, os.environ['WORLD_SIZE']))
 
+    if int(os.environ.get('LOCAL_RANK', '0')) == 0 and 'GDML_BENCH_CHILD' not in os.environ:
+        try:  # a child process takes the first touch of the GPU (see sgdml_amd._lib.preflight)
+            from sgdml_amd import _lib as _pre
+
+            _pre.preflight()
+        except Exception as e:
+            sys.stderr.write('bench.py: GPU preflight: %r\n' % (e,))
     # stdout carries exactly one line (the JSON): libraries that print banners to fd 1 (gloo's rank
     # messages, RCCL's version block) are sent to stderr for the duration of the run
     sys.stdout.flush()

@@ -100,7 +100,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   gemm.nt_c (0)         non-temporal loads / stores of the C tile; gemm.stagger (0) k-tiles by which neighbouring tiles offset
  *                         the start of their k loop (both after rocBLAS's Tensile kernel for this shape: profiles/r03_vendor_kernels.txt)
  *   gemm.cacc (1)         fused GEMM launches: interior tiles accumulate into C loaded up front (0: load-subtract-store epilogue)
- *   gemm.pipe (0)         fused GEMM launches: operand reads one k-step ahead across the tile boundary
+ *   gemm.lds16 (2)        fused GEMM launches: 16-byte LDS layout (k pairs, XOR-swizzled rows): ds_write_b128 / ds_read_b128;
+ *                         2 = with the operand pairs of the next half k-tile requested 16 MFMAs ahead, 0 = the 8-byte layout
  *   gemm.commit_ks (12)   fused GEMM launches: 4 = A/B reference with the early LDS commit of the prefetched tile
  *   chol.nb (512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),
  *   chol.lookahead (1)    factorisation schedule (fused_diag = 0: the round-1 second-stream look-ahead schedule)

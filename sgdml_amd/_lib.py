@@ -97,6 +97,32 @@ def device_count():
     return n.value
 
 
+def preflight(attempts=3, timeout=180):
+    """First touch of the GPU in a CHILD process: create a context and run one tiny kernel.  On a freshly leased box the
+    very first kernel launch of a process has aborted inside the HIP runtime twice in ~40 runs (no message, before any of
+    our code ran on the device); an abort cannot be caught, so callers that must not die with it (the test session, the
+    benchmark, smoke) let a child take that first touch, and retry it.  Returns the number of attempts used (0: no GPU
+    visible, nothing to do); raises RuntimeError when every attempt failed."""
+    import subprocess
+    import sys
+
+    if device_count() < 1:
+        return 0
+    code = ('import numpy as np; from sgdml_amd import _lib; c = _lib.Context(0); '
+            'c.desc_from_R(np.arange(18.0).reshape(2, 9) ** 1.5, 3); c.close()')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    err = ''
+    for k in range(1, attempts + 1):
+        try:
+            p = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=timeout)
+            if p.returncode == 0:
+                return k
+            err = (p.stderr or '')[-400:]
+        except subprocess.TimeoutExpired:
+            err = 'timeout'
+    raise RuntimeError('GPU preflight failed %d times: %s' % (attempts, err))
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(_vp)
 

@@ -110,6 +110,22 @@ __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int
   }
 }
 
+// 16-byte layout (option gemm.lds16): element (row, kq = k / 2) is the pair (k, k + 1) of a row, stored at d2 index
+// kq * 128 + (row ^ kq).  One ds_write_b128 per chunk instead of two ds_write_b64, one ds_read_b128 per operand block and
+// PAIR of k-steps instead of two 8-byte reads; the XOR keeps both conflict free: a group of 8 store lanes holds one row and
+// kq = 0..7 (8 different bank quads), a 16-lane read group holds 16 different (row ^ kq) & 15 (searched by script, see
+// DESIGN 3.2).  The MFMA's k index is a label: lane group g = lane >> 4 feeds k = 4 g + s into k-step s (both operands), so
+// that a lane's four k of a tile are contiguous.
+__device__ __forceinline__ void gemm_store_tile16(double* __restrict__ S, int tid, const d2 (&r)[4]) {
+  d2* S2 = reinterpret_cast<d2*>(S);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int cidx = tid + 256 * s;
+    const int row = cidx >> 3, kq = cidx & 7;
+    S2[kq * 128 + (row ^ kq)] = r[s];
+  }
+}
+
 __device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid, const d2 (&r)[4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -134,6 +150,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   // operand tiles (their latency is paid once, together with the prologue's), the epilogue is stores only -- instead of
   // four load->store round trips after the last MFMA.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r.
   constexpr bool CIN = FULL && !ABL && CACC;
+  constexpr double SGN = PIPE ? -1.0 : 1.0;  // 16-byte layout: the accumulator holds -C + A B^T
   double* Cw = g.C + (row0 + wm * 64 + lk) * g.ldc + col0 + wn * 64 + li;
   // wave-uniform tile corner + 32-bit lane offset: the 64 row addresses stay in SGPRs (saddr form), no address VGPRs
   const int wu = __builtin_amdgcn_readfirstlane(wave);
@@ -147,10 +164,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
       if (CIN) {
         if (g.nt_c) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_nontemporal_load((Ct + (int64_t)(i * 16 + 4 * r) * g.ldc) + coff + j * 16);
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = SGN * __builtin_nontemporal_load((Ct + (int64_t)(i * 16 + 4 * r) * g.ldc) + coff + j * 16);
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] = (Ct + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff + j * 16];
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = SGN * (Ct + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff + j * 16];
         }
       } else {
         acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -165,63 +182,100 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   d2 ra[4], rb[4];
   gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(0), g.K, tid, ra);
   gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(0), g.K, tid, rb);
-  gemm_store_tile(lds[0][0], tid, ra);
-  gemm_store_tile(lds[0][1], tid, rb);
+  if constexpr (PIPE) {
+    gemm_store_tile16(lds[0][0], tid, ra);
+    gemm_store_tile16(lds[0][1], tid, rb);
+  } else {
+    gemm_store_tile(lds[0][0], tid, ra);
+    gemm_store_tile(lds[0][1], tid, rb);
+  }
   __syncthreads();
 
   if constexpr (PIPE) {
-    // Operand reads run one k-step (4 of the 16 k of a tile) ahead of the MFMAs that use them, ACROSS the tile boundary: the
-    // tile's single barrier sits after the reads of its last k-step have landed and before that step's 16 MFMAs, so the first
-    // reads of the next tile (other buffer, written at k-step GEMM_COMMIT_KS and published by this barrier) are issued under
-    // those MFMAs instead of right after a barrier with nothing to overlap them.
-    double a[4], bb[4];
-    auto read_ops = [&](double (&ra_)[4], double (&rb_)[4], int buf, int ks) {
-      const double* As = lds[buf][0] + (wm * 64 + li) * GPITCH + lk;
-      const double* Bs = lds[buf][1] + (wn * 64 + li) * GPITCH + lk;
-      if (dbg & 4) {
-  #pragma unroll
-        for (int i = 0; i < 4; ++i) ra_[i] = rb_[i] = (double)(lane + i + ks);
-      } else {
-  #pragma unroll
-        for (int i = 0; i < 4; ++i) ra_[i] = -As[i * 16 * GPITCH + ks];
-  #pragma unroll
-        for (int j = 0; j < 4; ++j) rb_[j] = Bs[j * 16 * GPITCH + ks];
+    // ---- 16-byte LDS layout (gemm_store_tile16): per k-tile two batches of 8 ds_read_b128 + 32 MFMAs.  The sign lives in
+    // the accumulator here (acc = -C, acc += A B^T, C = -acc): no negation of A operands in the loop.
+    const int c16 = lane & 15, gq = lane >> 4;
+    if constexpr (CKS == 4) {
+      // read-ahead form (gemm.lds16 = 2): the operand pairs of the NEXT half are requested while 16 MFMAs of the current
+      // one are still to issue, across the tile boundary (the barrier sits before the tile's last 16 MFMAs)
+      auto read_half = [&](d2 (&a_)[4], d2 (&b_)[4], int buf, int h) {
+        const int kq = 2 * gq + h;
+        const int cx = c16 ^ kq;
+        const d2* Ap = reinterpret_cast<const d2*>(lds[buf][0]) + kq * 128 + wm * 64 + cx;
+        const d2* Bp = reinterpret_cast<const d2*>(lds[buf][1]) + kq * 128 + wn * 64 + cx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_[i] = Ap[16 * i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_[j] = Bp[16 * j];
+      };
+      auto mfma16 = [&](const d2 (&a_)[4], const d2 (&b_)[4], int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(t ? a_[i].y : a_[i].x, t ? b_[j].y : b_[j].x, acc[i][j], 0, 0, 0);
+      };
+      d2 a0[4], b0[4], a1[4], b1[4];
+      read_half(a0, b0, 0, 0);
+      for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = (int)(kt & 1);
+        if (kt + 1 < nk) {
+          gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(kt + 1), g.K, tid, ra);
+          gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(kt + 1), g.K, tid, rb);
+        }
+        mfma16(a0, b0, 0);
+        read_half(a1, b1, cur, 1);
+        mfma16(a0, b0, 1);
+        mfma16(a1, b1, 0);
+        if (kt + 1 < nk) {
+          gemm_store_tile16(lds[cur ^ 1][0], tid, ra);
+          gemm_store_tile16(lds[cur ^ 1][1], tid, rb);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) read_half(a0, b0, cur ^ 1, 0);
+        mfma16(a1, b1, 1);
       }
-    };
-    read_ops(a, bb, 0, 0);
+    } else
     for (int64_t kt = 0; kt < nk; ++kt) {
       const int cur = (int)(kt & 1);
       if (kt + 1 < nk && !(dbg & 2)) {
         gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(kt + 1), g.K, tid, ra);
         gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(kt + 1), g.K, tid, rb);
       }
-  #pragma unroll
-      for (int ks = 0; ks < GBK; ks += 4) {
-        double an[4], bn[4];
-        if (ks + 4 < GBK) {
-          read_ops(an, bn, cur, ks + 4);
+      const d2* Ad = reinterpret_cast<const d2*>(lds[cur][0]);
+      const d2* Bd = reinterpret_cast<const d2*>(lds[cur][1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kq = 2 * gq + h;
+        const int cx = c16 ^ kq;
+        const d2* Ap = Ad + kq * 128 + wm * 64 + cx;
+        const d2* Bp = Bd + kq * 128 + wn * 64 + cx;
+        d2 a[4], bb[4];
+        if (dbg & 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = bb[i] = (d2){(double)(lane + i + h), (double)(lane - i)};
         } else {
-          // last k-step of the tile: its operands are in registers; publish / wait for the other buffer, then fetch the next
-          // tile's first operands under this step's MFMAs
-          if (!(dbg & 8)) __syncthreads();
-          if (kt + 1 < nk) read_ops(an, bn, cur ^ 1, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = Ap[16 * i];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bb[j] = Bp[16 * j];
         }
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < 4; ++i)
-  #pragma unroll
+#pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-        if (ks == (CKS > 8 ? 8 : CKS) && kt + 1 < nk && !(dbg & 2)) {
-          // the next tile's global loads were issued ~32 MFMAs ago: write them to the other LDS
-          // buffer now so that the stores drain under the remaining MFMAs of this tile
-          gemm_store_tile(lds[cur ^ 1][0], tid, ra);
-          gemm_store_tile(lds[cur ^ 1][1], tid, rb);
-        }
-        if (ks + 4 < GBK || kt + 1 < nk) {
-  #pragma unroll
-          for (int i = 0; i < 4; ++i) { a[i] = an[i]; bb[i] = bn[i]; }
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, bb[j].y, acc[i][j], 0, 0, 0);
+        if (h == (CKS >= 8 ? 1 : 0) && kt + 1 < nk && !(dbg & 2)) {
+          gemm_store_tile16(lds[cur ^ 1][0], tid, ra);
+          gemm_store_tile16(lds[cur ^ 1][1], tid, rb);
         }
       }
+      if (!(dbg & 8)) __syncthreads();
     }
   } else {
     for (int64_t kt = 0; kt < nk; ++kt) {
@@ -278,7 +332,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(acc[i][j][r], (Ct2 + (int64_t)(i * 16 + 4 * r) * g.ldc) + coff2 + j * 16);
+          for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(SGN * acc[i][j][r], (Ct2 + (int64_t)(i * 16 + 4 * r) * g.ldc) + coff2 + j * 16);
       return;
     }
 #pragma unroll
@@ -286,7 +340,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) (Ct2 + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff2 + j * 16] = acc[i][j][r];
+        for (int r = 0; r < 4; ++r) (Ct2 + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff2 + j * 16] = SGN * acc[i][j][r];
     return;
   }
 #pragma unroll
@@ -300,7 +354,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[i][r] + acc[i][j][r];
+        for (int r = 0; r < 4; ++r) Cw[(i * 16 + 4 * r) * g.ldc + j * 16] = cv[i][r] + SGN * acc[i][j][r];
     } else {
       const int64_t gc = col0 + wn * 64 + j * 16 + li;
       const bool cok = gc < g.N;
@@ -319,7 +373,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
-          if (cok && gr < g.M) g.C[gr * g.ldc + gc] = cv[i][r] + acc[i][j][r];
+          if (cok && gr < g.M) g.C[gr * g.ldc + gc] = cv[i][r] + SGN * acc[i][j][r];
         }
     }
   }
@@ -460,9 +514,10 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
       g.tiles2 = (int)(ceil_div(g.M2, GT) * ceil_div(g.N2, GT));
     }
     const dim3 grid((unsigned)(blocks + 1 + g.tiles2));
-    const int pipe = ctx_opt_i(ctx, "gemm.pipe", 0), cacc = ctx_opt_i(ctx, "gemm.cacc", 1);
+    const int pipe = ctx_opt_i(ctx, "gemm.lds16", 2), cacc = ctx_opt_i(ctx, "gemm.cacc", 1);  // pipe = the 16-byte LDS layout
     const int cks = ctx_opt_i(ctx, "gemm.commit_ks", GEMM_COMMIT_KS);
     if (!pipe && cacc && cks == 4) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, true, 4>), grid, dim3(256), 0, st, g);
+    else if (pipe == 2 && cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 4>), grid, dim3(256), 0, st, g);
     else if (pipe && cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true>), grid, dim3(256), 0, st, g);
     else if (pipe) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, false>), grid, dim3(256), 0, st, g);
     else if (cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, true>), grid, dim3(256), 0, st, g);
