@@ -451,7 +451,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
 template <bool ABL>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
-  gemm_block<ABL>(g, lds, blockIdx.x);
+  // production instantiation: the 16-byte LDS layout with read-ahead of the fused kernel (gemm.lds16 = 2); the ablation
+  // instantiation keeps the 8-byte layout its masks were written for
+  gemm_block<ABL, !ABL, true, ABL ? GEMM_COMMIT_KS : 4>(g, lds, blockIdx.x);
 }
 
 
