@@ -1,5 +1,7 @@
-// Kernel-matrix assembly for SMALL molecules with a permutation group (N <= 24, any P; also P = 1 where the register-
-// resident kernels do not apply): strips of WHOLE column points, producer / consumer wavefronts, everything in LDS.
+// Kernel-matrix assembly for SMALL molecules with a permutation group (8 <= N <= 21 in practice: three row-point images,
+// the strip's tables and two V-result areas have to fit the 160 KB of LDS; larger N and P = 1 go to assemble_perm.hip):
+// strips of WHOLE column points, producer / consumer wavefronts, everything in LDS.
+// N = 21, P = 4, M = 1000: 10.6 ms = 0.37 of HBM (assemble_perm.hip 19.5, the round-2 LDS kernel 61.3).
 //
 // Reference: sgdml/train.py:97-302 (_assemble_kernel_mat_wkr).  Math and tables as in assemble_perm.hip:
 //   K_ij = sum_p [ 5 b_p v_p u_p^T - c_p J_i^T J_j^p ],   d_p = x_i - P_p x_j
