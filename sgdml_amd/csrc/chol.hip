@@ -116,6 +116,21 @@ __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int
 // kq = 0..7 (8 different bank quads), a 16-lane read group holds 16 different (row ^ kq) & 15 (searched by script, see
 // DESIGN 3.2).  The MFMA's k index is a label: lane group g = lane >> 4 feeds k = 4 g + s into k-step s (both operands), so
 // that a lane's four k of a tile are contiguous.
+// Full tiles, 16-byte aligned: wave-uniform base (tile corner + k offset: SGPRs) + the thread's constant 32-bit byte offsets
+// (row * ld + kc of its four chunks; a tile spans < 2^31 bytes): saddr-form loads, no 64-bit address arithmetic per k-tile.
+__device__ __forceinline__ void gemm_load_tile_u(const double* __restrict__ base, const unsigned (&off)[4], d2 (&r)[4]) {
+  // the base IS wave uniform; say so (the divergence analysis does not see it through the tile arithmetic) and keep the
+  // pointer in the global address space (a generic pointer rebuilt from integers becomes FLAT loads, which also count on
+  // lgkmcnt): scalar base + 32-bit lane offset = saddr-form global_load_dwordx4
+  typedef const __attribute__((address_space(1))) char* gcptr;
+  typedef const __attribute__((address_space(1))) d2* gd2ptr;
+  const uint64_t p = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+  gcptr b = (gcptr)(((uint64_t)hi << 32) | lo);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) r[s] = *(gd2ptr)(b + off[s]);
+}
+
 __device__ __forceinline__ void gemm_store_tile16(double* __restrict__ S, int tid, const d2 (&r)[4]) {
   d2* S2 = reinterpret_cast<d2*>(S);
 #pragma unroll
@@ -195,6 +210,26 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
     // ---- 16-byte LDS layout (gemm_store_tile16): per k-tile two batches of 8 ds_read_b128 + 32 MFMAs.  The sign lives in
     // the accumulator here (acc = -C, acc += A B^T, C = -acc): no negation of A operands in the loop.
     const int c16 = lane & 15, gq = lane >> 4;
+    // full tiles: saddr-form loads (wave-uniform tile corner + the thread's four constant 32-bit byte offsets)
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int cidx = tid + 256 * s4;
+      offA[s4] = (unsigned)(((int64_t)(cidx >> 3) * g.lda + (cidx & 7) * 2) * 8);
+      offB[s4] = (unsigned)(((int64_t)(cidx >> 3) * g.ldb + (cidx & 7) * 2) * 8);
+    }
+    const double* const Abase = g.A + row0 * g.lda;
+    const double* const Bbase = g.B + col0 * g.ldb;
+    auto load_ab = [&](int64_t kt_, d2 (&ra_)[4], d2 (&rb_)[4]) {
+      if constexpr (FULL) {
+        const int64_t ko = kofs(kt_);
+        gemm_load_tile_u(Abase + ko, offA, ra_);
+        gemm_load_tile_u(Bbase + ko, offB, rb_);
+      } else {
+        gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(kt_), g.K, tid, ra_);
+        gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(kt_), g.K, tid, rb_);
+      }
+    };
     if constexpr (CKS == 4) {
       // read-ahead form (gemm.lds16 = 2): the operand pairs of the NEXT half are requested while 16 MFMAs of the current
       // one are still to issue, across the tile boundary (the barrier sits before the tile's last 16 MFMAs)
@@ -219,10 +254,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
       read_half(a0, b0, 0, 0);
       for (int64_t kt = 0; kt < nk; ++kt) {
         const int cur = (int)(kt & 1);
-        if (kt + 1 < nk) {
-          gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(kt + 1), g.K, tid, ra);
-          gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(kt + 1), g.K, tid, rb);
-        }
+        if (kt + 1 < nk) load_ab(kt + 1, ra, rb);
         mfma16(a0, b0, 0);
         read_half(a1, b1, cur, 1);
         mfma16(a0, b0, 1);
@@ -323,9 +355,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   if (CIN) {
     // recompute the store addresses from laundered copies: the compiler otherwise keeps the prologue's 32 load addresses
     // alive across the main loop (spilled to scratch)
-    double* Ct2 = Ct;
+    double* Ct2g = Ct;
     unsigned coff2 = coff;
-    asm volatile("" : "+v"(Ct2), "+v"(coff2));
+    asm volatile("" : "+v"(Ct2g), "+v"(coff2));
+    // (the laundered pointer is generic: back to the global address space, or the 64 stores are FLAT stores)
+    __attribute__((address_space(1))) double* Ct2 = (__attribute__((address_space(1))) double*)Ct2g;
     if (g.nt_c) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
