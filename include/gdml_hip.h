@@ -97,8 +97,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *                         full-line stores, row points per workgroup
  *   asm.threads, asm.ib, asm.minw, asm.gj_global, asm.j_chunk, asm.debug   LDS-kernel shape / ablations
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
- *   gemm.nt_c (0)         non-temporal loads / stores of the C tile; gemm.stagger (0) k-tiles by which neighbouring tiles offset
- *                         the start of their k loop (both after rocBLAS's Tensile kernel for this shape: profiles/r03_vendor_kernels.txt)
+ *   gemm.nt_c (0)         non-temporal loads / stores of the C tile (after rocBLAS's Tensile kernel for this shape:
+ *                         profiles/r03_vendor_kernels.txt; no gain measured)
  *   gemm.cacc (1)         fused GEMM launches: interior tiles accumulate into C loaded up front (0: load-subtract-store epilogue)
  *   gemm.lds16 (2)        fused GEMM launches: 16-byte LDS layout (k pairs, XOR-swizzled rows): ds_write_b128 / ds_read_b128;
  *                         2 = with the operand pairs of the next half k-tile requested 16 MFMAs ahead, 0 = the 8-byte layout

@@ -65,7 +65,6 @@ struct GemmArgs {
   int* diag_info;
   int dbg;          // option gemm.debug: ablation bits: 1 no epilogue, 2 no tile loads, 4 no LDS reads, 8 no barrier
   int nt_c;         // option gemm.nt_c: non-temporal loads / stores of the C tile (it is streamed: keep the L2 for the panels)
-  int stagger;      // option gemm.stagger: tiles start their k loop at different offsets (wrapping), in steps of this many k-tiles
   // merged trailing update (lower): the first super-tile COLUMN (the next outer panel's own columns) is enumerated
   // first; the tiles of its leading ready_rows x ready_rows tile block (the diagonal block workgroup 0 is about to
   // factor) count themselves into *ready when their C tile is stored, workgroup 0 waits for ready_target
@@ -190,10 +189,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
     }
 
   const int64_t nk = (g.K + GBK - 1) / GBK;
-  // staggered start (full tiles only; the sum over k is order independent up to rounding): neighbouring tiles do not ask
-  // for the same k range of their panels at the same time
-  const int64_t kt0 = (FULL && g.stagger > 0) ? (((row0 / GT) * 5 + (col0 / GT) * 3) & 15) * g.stagger % nk : 0;
-  auto kofs = [&](int64_t kt) -> int64_t { const int64_t k = kt + kt0; return (k >= nk ? k - nk : k) * GBK; };
+  // (a staggered k start per tile, after Tensile's StaggerU, was tried and cost 1.5 %: profiles/r03_gemm_ntc_stagger_ab.txt;
+  //  its 64-bit wrap-around compare in the loop head is gone with it)
+  auto kofs = [&](int64_t kt) -> int64_t { return kt * GBK; };
   d2 ra[4], rb[4];
   gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(0), g.K, tid, ra);
   gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(0), g.K, tid, rb);
@@ -252,19 +250,20 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
       };
       d2 a0[4], b0[4], a1[4], b1[4];
       read_half(a0, b0, 0, 0);
-      for (int64_t kt = 0; kt < nk; ++kt) {
-        const int cur = (int)(kt & 1);
-        if (kt + 1 < nk) load_ab(kt + 1, ra, rb);
+      const int nk32 = (int)nk;
+      for (int kt = 0; kt < nk32; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk32) load_ab(kt + 1, ra, rb);
         mfma16(a0, b0, 0);
         read_half(a1, b1, cur, 1);
         mfma16(a0, b0, 1);
         mfma16(a1, b1, 0);
-        if (kt + 1 < nk) {
+        if (kt + 1 < nk32) {
           gemm_store_tile16(lds[cur ^ 1][0], tid, ra);
           gemm_store_tile16(lds[cur ^ 1][1], tid, rb);
         }
         __syncthreads();
-        if (kt + 1 < nk) read_half(a0, b0, cur ^ 1, 0);
+        if (kt + 1 < nk32) read_half(a0, b0, cur ^ 1, 0);
         mfma16(a1, b1, 1);
       }
     } else
@@ -524,7 +523,6 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   if (cyc) { g.cyc_W = cyc->W; g.cyc_rank = cyc->rank; g.cyc_lb0 = cyc->lb0; g.cyc_nb = cyc->nb; g.cyc_col0 = cyc->col0; g.cyc_block_rows = cyc->block_rows; }
   g.dbg = ctx_opt_i(ctx, "gemm.debug", 0);
   g.nt_c = ctx_opt_i(ctx, "gemm.nt_c", 0);
-  g.stagger = ctx_opt_i(ctx, "gemm.stagger", 0);
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
               (lda % 2 == 0) && (ldb % 2 == 0);
   g.tiles_m = (int)((M + GT - 1) / GT);
