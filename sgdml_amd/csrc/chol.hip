@@ -251,9 +251,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
       d2 a0[4], b0[4], a1[4], b1[4];
       read_half(a0, b0, 0, 0);
       const int nk32 = (int)nk;
-      if (nk32 > 1) load_ab(1, ra, rb);
       for (int kt = 0; kt < nk32; ++kt) {
         const int cur = kt & 1;
+        if (kt + 1 < nk32) load_ab(kt + 1, ra, rb);
         mfma16(a0, b0, 0);
         read_half(a1, b1, cur, 1);
         mfma16(a0, b0, 1);
@@ -261,8 +261,6 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
         if (kt + 1 < nk32) {
           gemm_store_tile16(lds[cur ^ 1][0], tid, ra);
           gemm_store_tile16(lds[cur ^ 1][1], tid, rb);
-          // the staging registers are free again: request tile kt + 2 now, 16 MFMAs before the top of the next tile
-          if (kt + 2 < nk32) load_ab(kt + 2, ra, rb);
         }
         __syncthreads();
         if (kt + 1 < nk32) read_half(a0, b0, cur ^ 1, 0);
