@@ -103,7 +103,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   gemm.lds16 (2)        fused GEMM launches: 16-byte LDS layout (k pairs, XOR-swizzled rows): ds_write_b128 / ds_read_b128;
  *                         2 = with the operand pairs of the next half k-tile requested 16 MFMAs ahead, 0 = the 8-byte layout
  *   gemm.commit_ks (12)   fused GEMM launches: 4 = A/B reference with the early LDS commit of the prefetched tile
- *   chol.nb (512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),
+ *   chol.nb (512: a multiple of 64 up to 512, anything else falls back to 512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),
  *   chol.lookahead (1)    factorisation schedule (fused_diag = 0: the round-1 second-stream look-ahead schedule)
  *   chol.outer (1024)     panel pairs: K = 2 nb trailing update in two launches (= chol.nb: single panels only)
  *   chol.outer_min_rows (16384)  trailing rows below which new panels are single again

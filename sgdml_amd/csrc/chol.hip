@@ -1294,7 +1294,7 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
   if (n_rows < n) n_rows = n;
   HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   int64_t NB = (int64_t)ctx_opt(ctx, "chol.nb", 512);  // outer panel width (multiple of 64)
-  if (NB < 64 || NB % 64) NB = 512;
+  if (NB < 64 || NB % 64 || NB > 512) NB = 512;  // the diagonal-block role and the row-local solve hold at most 8 x 64 columns
   const bool lookahead = ctx_opt_i(ctx, "chol.lookahead", 1) != 0;
   // ---- default schedule: ONE stream.  Per panel k:  GEMM1 (columns of panel k+1)  ->  SYRK of the rest, whose
   // workgroup 0 factors the diagonal block of panel k+1 meanwhile  ->  row-local solve of panel k+1's rows.
