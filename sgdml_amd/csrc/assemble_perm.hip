@@ -626,6 +626,7 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   const int64_t n_strips = (n_j * N + 63) / 64;
   const int64_t n_i = i_end - i_beg;
   int i_chunk = ctx_opt_i(ctx, "asm.perm_i_chunk", 16);
+  if (i_chunk < 1) i_chunk = 1;
   while (i_chunk > 2 && n_strips * ((n_i + i_chunk - 1) / i_chunk) < 2048) i_chunk >>= 1;
   A.i_chunk = i_chunk;
   dim3 grid((unsigned)n_strips, (unsigned)((n_i + i_chunk - 1) / i_chunk));

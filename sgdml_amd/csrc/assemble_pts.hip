@@ -539,6 +539,7 @@ int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_
   const int64_t n_strips = (n_j + A.PPS - 1) / A.PPS;
   const int64_t n_i = i_end - i_beg;
   int i_chunk = ctx_opt_i(ctx, "asm.pts_i_chunk", 64);
+  if (i_chunk < 1) i_chunk = 1;
   while (i_chunk > 4 && n_strips * ((n_i + i_chunk - 1) / i_chunk) < 1024) i_chunk >>= 1;
   A.i_chunk = i_chunk;
   A.xcd_map = ctx_opt_i(ctx, "asm.pts_xcd", 1) && !A.lower;
