@@ -325,3 +325,74 @@ def test_configs2_trajectory_workload_vs_reference():
         assert np.abs(F[0] * float(g['y_std']) - g['F_test']).max() <= 1e-8 * np.abs(g['F_test']).max()
     finally:
         c.close()
+
+
+def _group(n_atoms, gens):
+    idt = tuple(range(n_atoms))
+    G, frontier = {idt}, [idt]
+    while frontier:
+        nxt = []
+        for g in frontier:
+            for h in gens:
+                c = tuple(g[i] for i in h)
+                if c not in G:
+                    G.add(c)
+                    nxt.append(c)
+        frontier = nxt
+    rest = sorted(G - {idt})
+    return np.array([idt] + rest)
+
+
+@pytest.mark.parametrize('n_atoms,n_train,n_gen', [(21, 7, 2), (12, 8, 3), (9, 10, 2), (16, 5, 1), (8, 11, 2)])
+def test_assemble_pts_kernel_vs_oracle(n_atoms, n_train, n_gen):
+    """assemble_pts.hip (8 <= N <= 21 with a permutation group: whole-point strips, producer / consumer wavefronts, LDS-DMA row
+    images) against the oracle in every dense mode it serves: full K, full K with the energy-constraint rows and columns,
+    the lower form A = -K + lam I of the analytic solver, a range of column points; n_train is not a multiple of the points
+    per strip, groups of 2, 4, 6 and 27 permutations (one and several steps per row point).  1e-12 of max|K|."""
+    from sgdml_amd import _lib
+
+    N, M = n_atoms, n_train
+    idt = list(range(N))
+
+    def swap(a):
+        p = idt[:]
+        p[a], p[a + 1] = p[a + 1], p[a]
+        return tuple(p)
+
+    def rot3(a):
+        p = idt[:]
+        p[a], p[a + 1], p[a + 2] = p[a + 1], p[a + 2], p[a]
+        return tuple(p)
+
+    gens = {1: [swap(0)], 2: [swap(0), swap(N - 2)], 3: [rot3(0), rot3(3), rot3(N - 3)]}[n_gen]
+    perms = _group(N, gens)
+    ds = orc.synth_dataset(N, M, seed=5, jitter=0.3)
+    xo, go = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(perms)
+    lin = orc.tril_perms_lin_from_tril_perms(tp)
+    sig, lam = 13.0, 1e-7
+    Ko = orc.assemble_K(xo, go, lin, sig)
+    KoE = orc.assemble_K(xo, go, lin, sig, use_E_cstr=True)
+    scale = np.abs(Ko).max()
+    n, N3 = M * 3 * N, 3 * N
+    c = _lib.Context()
+    try:
+        c.set_option('asm.pts', 2)
+        c.train_upload(xo, go, tp)
+        K = c.assemble_K(sig, False, to_host=True)
+        assert np.abs(K - Ko).max() <= 1e-12 * scale
+        KE = c.assemble_K(sig, True, to_host=True)
+        assert np.abs(KE - KoE).max() <= 1e-12 * np.abs(KoE).max()
+        c.assemble_K(sig, False, alloc_extra_rows=1, for_cholesky=lam)
+        A = c.K_to_host()[:n]
+        low = np.kron(np.tril(np.ones((M, M))), np.ones((N3, N3))).astype(bool)
+        assert np.abs((A - (-Ko + lam * np.eye(n)))[low]).max() <= 1e-12 * scale
+        p0, p1 = M // 3, M // 3 + max(1, M // 2)
+        Kp = c.assemble_K(sig, False, points=(p0, p1), to_host=True)
+        assert np.abs(Kp - Ko[:, p0 * N3:p1 * N3]).max() <= 1e-12 * scale
+        # the same through the general kernel: the two agree to rounding
+        c.set_option('asm.pts', 0)
+        K2 = c.assemble_K(sig, False, to_host=True)
+        assert np.abs(K2 - K).max() <= 1e-13 * scale
+    finally:
+        c.close()
