@@ -85,8 +85,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   asm.strip (1)         64-column-strip assembly kernel (full-line stores) for P = 1, 11 <= N <= 21, all columns
  *   asm.i_chunk (32)      row points walked by one wavefront of the strip kernel
  *   asm.pts (1; 2 = also for P = 1) small molecules (8 <= N <= 24) with a permutation group: whole-point strips, producer / consumer
- *                         wavefronts (csrc/assemble_pts.hip); asm.pts_nv (0 = automatic) producer wavefronts, asm.pts_na (0 = automatic:
- *                         3 row atoms per consumer wavefront; 1 or 2 trade producers for consumers), asm.pts_nt (1) non-temporal stores of K, asm.pts_xcd (1) adjacent strips on one XCD, asm.pts_i_chunk (64)
+ *                         wavefronts (csrc/assemble_pts.hip); asm.pts_nv (0 = automatic) producer wavefronts, asm.pts_nt (1) non-temporal stores of K, asm.pts_xcd (1) adjacent strips on one XCD, asm.pts_i_chunk (64)
  *                         row points per workgroup, asm.pts_debug (0) timing-only ablation mask (results are wrong when set)
  *   asm.perm (1)          general assembly kernel (any permutation group, any N): column-atom strips (0: the LDS kernel, N <= 64)
  *   asm.perm_level (-1 = automatic: 0 nothing, 1 row-point image, 2 + G_j strip, 3 + x_j tables resident in LDS),

@@ -1,7 +1,7 @@
 // Kernel-matrix assembly for SMALL molecules with a permutation group (8 <= N <= 21 in practice: three row-point images,
 // the strip's tables and two V-result areas have to fit the 160 KB of LDS; larger N and P = 1 go to assemble_perm.hip):
 // strips of WHOLE column points, producer / consumer wavefronts, everything in LDS.
-// N = 21, P = 4, M = 1000: 10.6 ms = 0.37 of HBM (assemble_perm.hip 19.5, the round-2 LDS kernel 61.3).
+// N = 21, P = 4, M = 1000: 10.0 ms = 0.40 of HBM (assemble_perm.hip 19.5, the round-2 LDS kernel 61.3).
 //
 // Reference: sgdml/train.py:97-302 (_assemble_kernel_mat_wkr).  Math and tables as in assemble_perm.hip:
 //   K_ij = sum_p [ 5 b_p v_p u_p^T - c_p J_i^T J_j^p ],   d_p = x_i - P_p x_j
@@ -71,7 +71,9 @@ __device__ __forceinline__ double pts_seg_scan(double v, int pos) {  // inclusiv
 
 // PG: permutations per step (1, 2, 4).  A group that has fewer (the last one, or P = 3) repeats its first permutation in the
 // unused slots with zero Matern scalars: no branch depends on the group size.
-template <int PG, int NA>
+// LOWER: the negated lower form of the analytic solver.  SPECIAL: energy-constraint rows, ablation masks, plain stores -- the
+// production instantiations carry none of these as run-time flags (one such flag inside the k loop cost the GEMM 3.6 %).
+template <int PG, int NA, bool LOWER, bool SPECIAL>
 __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using VBL = PtsVB<PG>;
@@ -106,7 +108,10 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
   const int lrow = lane < N ? lane : 0;  // lane that holds entry `lane` of a permutation row
   const int64_t jvq = (jv0 + q < A.n_j) ? jv0 + q : A.n_j - 1;
   const int64_t jpt = A.j0 + jvq;
-  const bool lower = A.lower != 0;
+  constexpr bool lower = LOWER;
+  const int dbg = SPECIAL ? A.dbg : 0;
+  const bool use_E = SPECIAL && A.use_E != 0;
+  const bool nt_store = SPECIAL ? A.nt_store != 0 : true;
 
   const int64_t i_lo = (lower ? A.j0 + jv0 : A.i_beg) + (int64_t)blockIdx.y * A.i_chunk;
   const int64_t i_top = lower ? A.M : A.i_end;
@@ -154,7 +159,7 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
     double* const vs = VB + par * VBL::SIZE;
     double* const ud = vs + VBL::VS;
     double* const scal = ud + VBL::UD;
-    if (A.dbg & 2) return;
+    if (dbg & 2) return;
     for (int tk = vw; tk < 1 + PG; tk += NV) {
       if (tk == 0) {
         // ---- row role: lane = (q, a = b): v_p, |d_p|^2 for every permutation of the group
@@ -281,7 +286,7 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
   if (producer) {
     // image of row point i_lo + tp into buffer b3: 8 N^2 dwords, 64 per instruction, this wavefront's share
     auto request = [&](int tp, int b3) {
-      const int64_t ip = (A.dbg & 8) ? i_lo : i_lo + tp;  // ablation 8: a cache-hot image
+      const int64_t ip = (dbg & 8) ? i_lo : i_lo + tp;  // ablation 8: a cache-hot image
       const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(A.GD + ip * (int64_t)NN * 3);
       const uint32_t* xsrc = reinterpret_cast<const uint32_t*>(A.XF + ip * (int64_t)NN);
       char* dst = reinterpret_cast<char*>(IMG + b3 * 4 * NN);
@@ -359,7 +364,7 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
       }
 #pragma unroll
       for (int pl = 0; pl < PG; ++pl) {
-        if ((A.dbg & 4) || pl >= npg) break;
+        if ((dbg & 4) || pl >= npg) break;
         const int ap = ap_g[pl];
         const int prow = prow_g[pl];
         const double* sc = scal + (pl * PTS_MAXQ + q) * 4;
@@ -386,7 +391,7 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
             }
           }
         }
-        if (A.use_E && w == 0) {
+        if (use_E && w == 0) {
           const double ce = sc[2];
           erow[0] = fma(ce, ur0, erow[0]); erow[1] = fma(ce, ur1, erow[1]); erow[2] = fma(ce, ur2, erow[2]);
         }
@@ -434,7 +439,7 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
         const int a = a_base + k;
-        if (a < N && (!(A.dbg & 1) || acc[k][0][0] == 1.2345e-300)) {
+        if (a < N && (!(dbg & 1) || acc[k][0][0] == 1.2345e-300)) {
 #pragma unroll
           for (int al = 0; al < 3; ++al) {
             const int rr = 3 * a + al;
@@ -450,7 +455,7 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
             for (int t3 = 0; t3 < 3; ++t3) {
               const double o = val[t3] + ((dcol[t3] == rr) ? lamv : 0.0);
               if (tok[t3]) {
-                if (A.nt_store) __builtin_nontemporal_store(o, dst + (unsigned)tcol[t3]);  // K is streamed out: keep the L2 for the images
+                if (nt_store) __builtin_nontemporal_store(o, dst + (unsigned)tcol[t3]);  // K is streamed out: keep the L2 for the images
                 else dst[(unsigned)tcol[t3]] = o;
               }
             }
@@ -458,7 +463,7 @@ __global__ void __launch_bounds__(768) assemble_pts_kernel(PtsArgs A) {
           }
         }
       }
-      if (A.use_E && w == 0 && lane_in && jv0 + q < A.n_j) {
+      if (use_E && w == 0 && lane_in && jv0 + q < A.n_j) {
         double* dst = A.K + (A.M * N3 + i) * A.ld + (int64_t)(jv0 + q) * N3 + 3 * b;
         dst[0] = erow[0]; dst[1] = erow[1]; dst[2] = erow[2];
       }
@@ -477,7 +482,7 @@ bool assemble_pts_applicable(const gdml_ctx* ctx) {
   return ts.N >= 8 && ts.N <= 24 && (opt == 2 || (opt == 1 && ts.P > 1));
 }
 
-template <int PG, int NA>
+template <int PG, int NA, bool LOWER, bool SPECIAL>
 static void pts_launch_t(gdml_ctx* ctx, PtsArgs& A, dim3 grid, size_t* lds_out = nullptr) {
   const int N = A.N, NN = N * N;
   int o = 0;
@@ -489,8 +494,8 @@ static void pts_launch_t(gdml_ctx* ctx, PtsArgs& A, dim3 grid, size_t* lds_out =
   A.o_perm = o; o += (2 * A.P * N + 1) / 2;
   const size_t lds = (size_t)o * 8;
   if (lds_out) { *lds_out = lds; return; }
-  (void)hipFuncSetAttribute((const void*)assemble_pts_kernel<PG, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((assemble_pts_kernel<PG, NA>), grid, dim3(64 * (A.NO + A.NV)), lds, ctx->stream, A);
+  (void)hipFuncSetAttribute((const void*)assemble_pts_kernel<PG, NA, LOWER, SPECIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((assemble_pts_kernel<PG, NA, LOWER, SPECIAL>), grid, dim3(64 * (A.NO + A.NV)), lds, ctx->stream, A);
 }
 
 // Column points [j0, j0 + n_j) (output columns from 0), row points [i_beg, i_end) (rows relative to i_beg).
@@ -499,7 +504,7 @@ int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_
   TrainSet& ts = ctx->ts;
   if (n_j <= 0 || i_end <= i_beg) return GDML_OK;
   GDML_TRY(build_dense_tables(ctx));
-  const int N = ts.N, P = ts.P, NN = N * N;
+  const int N = ts.N, P = ts.P;
   if (lower && (use_E || j0 != 0 || i_beg != 0 || n_j != ts.M || i_end != ts.M))
     return gdml_fail(ctx, GDML_ERR_INVALID, "assemble_pts: the lower form needs the dense full column range");
   if ((int64_t)P * N > 4096) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_pts: permutation tables of %d x %d entries", P, N);
@@ -515,18 +520,22 @@ int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_
   A.n_g = (P + 3) / 4;
   A.pg_eff = (P + A.n_g - 1) / A.n_g;  // equal groups of at most four
   const int PG = A.pg_eff >= 3 ? 4 : A.pg_eff;
-  // row atoms per consumer wavefront: three (asm.pts_na forces 1 or 2: more consumers, fewer producers -- measured slower
-  // or equal at N = 9 .. 21, the producers being the critical path: profiles/r03_assemble_pts.txt)
+  // row atoms per consumer wavefront: three (1 and 2 -- more consumers, fewer producers -- measured slower or equal at
+  // N = 9 .. 21, the producers being the critical path: profiles/r03_assemble_pts.txt)
   int NA = -1;
-  const int na_opt = ctx_opt_i(ctx, "asm.pts_na", 0), nv_opt = ctx_opt_i(ctx, "asm.pts_nv", 0);
+  const int nv_opt = ctx_opt_i(ctx, "asm.pts_nv", 0);
   size_t lds = 0;
-  auto dispatch = [&](int na, dim3 g, size_t* lds_out) {
-#define PTS_GO(pg) do { if (na == 1) pts_launch_t<pg, 1>(ctx, A, g, lds_out); else if (na == 2) pts_launch_t<pg, 2>(ctx, A, g, lds_out); \
-                        else pts_launch_t<pg, 3>(ctx, A, g, lds_out); } while (0)
+  const bool special = use_E || A.dbg != 0 || !A.nt_store;
+  auto dispatch = [&](int, dim3 g, size_t* lds_out) {  // three row atoms per consumer (1 and 2 were measured, not kept)
+#define PTS_GO(pg)                                                                         \
+  do {                                                                                     \
+    if (special) { if (A.lower) pts_launch_t<pg, 3, true, true>(ctx, A, g, lds_out); else pts_launch_t<pg, 3, false, true>(ctx, A, g, lds_out); } \
+    else { if (A.lower) pts_launch_t<pg, 3, true, false>(ctx, A, g, lds_out); else pts_launch_t<pg, 3, false, false>(ctx, A, g, lds_out); }      \
+  } while (0)
     if (PG == 1) PTS_GO(1); else if (PG == 2) PTS_GO(2); else PTS_GO(4);
 #undef PTS_GO
   };
-  for (int na = (na_opt >= 1 && na_opt <= 3) ? na_opt : 3; na <= 3; ++na) {
+  for (int na = 3; na <= 3; ++na) {
     A.NO = (N + na - 1) / na;
     const int nv_want = 1 + PG < 3 ? 1 + PG : (na == 3 ? 1 + PG : 3);
     A.NV = 12 - A.NO < 1 + PG ? 12 - A.NO : 1 + PG;

@@ -14,7 +14,7 @@ if mode == 'check':
     for N, M, kind in [(9, 9, 'c3xc2'), (12, 8, 'c3^3'), (21, 7, 'c2xc2'), (21, 5, 'id'), (24, 4, 'c3xc2'), (8, 11, 'c2xc2'),
                        (16, 9, 'c3xc2'), (21, 3, 'c2xc2'), (21, 1, 'c2xc2'), (10, 20, 'c3^3')]:
         ok &= check_case(N, M, kind, dict(opts))
-    for o in [{'asm.pts_i_chunk': 2}, {'asm.pts_nv': 2}, {'asm.pts_nv': 3}]:
+    for o in [{'asm.pts_i_chunk': 2}, {'asm.pts_nv': 2}, {'asm.pts_nv': 3}, {'asm.pts_nt': 0}]:
         ok &= check_case(21, 7, 'c2xc2', dict(opts, **o))
         ok &= check_case(9, 9, 'c3xc2', dict(opts, **o))
     print('ALL OK' if ok else 'SOME FAILED')
