@@ -450,14 +450,14 @@ def run_sharded_cg(args, rank, world):
     import torch.distributed as dist
 
     from sgdml_amd import _lib
-    from sgdml_amd.dist import init_comm_from_torch_distributed
+    from sgdml_amd.dist import init_comm_from_torch_distributed, pick_backend
 
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist.init_process_group('gloo')
     n_dev = _lib.device_count()
     comm = args.comm
-    if comm == 'auto':
-        comm = 'rccl' if n_dev >= world else 'host'  # fewer GPUs than ranks: functional run, ranks share GPUs
+    if comm == 'auto':  # RCCL when every rank has a physical GPU of its own; ranks sharing a GPU: functional host-staged run
+        comm = pick_backend(local_rank % max(1, n_dev))
     ctx = _lib.Context(local_rank % max(1, n_dev))
     init_comm_from_torch_distributed(ctx, backend=comm)
 

@@ -50,6 +50,11 @@ int gdml_abi_version(void);
 /* Number of visible HIP devices (reference: torch.cuda.device_count(), train.py:1464). */
 int gdml_device_count(int* n_out);
 
+/* PCI bus id ("0000:c1:00.0") of visible device `device` into out[len >= 16]: the physical identity of a GPU, so that
+ * ranks whose launcher gave each of them a private one-device view can still tell whether they share a GPU (RCCL
+ * refuses duplicate devices).  No reference counterpart (the reference is single-process). */
+int gdml_device_pci_bus_id(int device, char* out, int len);
+
 /* Create / destroy the per-GPU context: owns one compute stream, one copy stream, all
  * device buffers and (after gdml_comm_init) the RCCL communicator. */
 int gdml_ctx_create(int device, gdml_ctx** ctx_out);

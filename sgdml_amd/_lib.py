@@ -21,6 +21,7 @@ HOST_COLL_CB = C.CFUNCTYPE(C.c_int, _dp, C.c_int64, _vp)  # gdml_host_allreduce 
 SIGNATURES = {
     'gdml_abi_version': (C.c_int, []),
     'gdml_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'gdml_device_pci_bus_id': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     'gdml_ctx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
     'gdml_ctx_destroy': (C.c_int, [_vp]),
     'gdml_last_error': (C.c_char_p, [_vp]),
@@ -95,6 +96,14 @@ def device_count():
     n = C.c_int(0)
     load().gdml_device_count(C.byref(n))
     return n.value
+
+
+def device_pci_bus_id(device):
+    """PCI bus id of visible device `device` (its physical identity), or None if the runtime cannot tell."""
+    buf = C.create_string_buffer(64)
+    if load().gdml_device_pci_bus_id(int(device), buf, 64) != 0:
+        return None
+    return buf.value.decode() or None
 
 
 def preflight(attempts=3, timeout=180):

@@ -83,6 +83,14 @@ extern "C" int gdml_device_count(int* n_out) {
   return GDML_OK;
 }
 
+extern "C" int gdml_device_pci_bus_id(int device, char* out, int len) {
+  if (!out || len < 16) return GDML_ERR_INVALID;
+  out[0] = 0;
+  hipError_t e = hipDeviceGetPCIBusId(out, len, device);
+  if (e != hipSuccess) return gdml_fail(nullptr, GDML_ERR_HIP, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e));
+  return GDML_OK;
+}
+
 extern "C" int gdml_ctx_create(int device, gdml_ctx** ctx_out) {
   if (!ctx_out) return GDML_ERR_INVALID;
   *ctx_out = nullptr;

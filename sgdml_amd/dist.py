@@ -18,6 +18,21 @@ def shard_range(rank, world, n_points):
     return a, b, per
 
 
+def pick_backend(device, group=None):
+    """'rccl' when every rank of the group sits on its own physical GPU, else 'host'.  Physical identity is the PCI
+    bus id of the rank's device, exchanged through the group, so the answer is right both when every rank sees all
+    GPUs and picks device LOCAL_RANK and when the launcher hands each rank a private one-device view
+    (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank); ranks that share a GPU get the host-staged collectives
+    because RCCL refuses duplicate devices."""
+    import torch.distributed as dist
+
+    from . import _lib
+
+    ids = [None] * dist.get_world_size(group)
+    dist.all_gather_object(ids, _lib.device_pci_bus_id(device), group=group)
+    return 'rccl' if all(i is not None for i in ids) and len(set(ids)) == len(ids) else 'host'
+
+
 def init_comm_from_torch_distributed(ctx, group=None, backend='rccl'):
     """Create the communicator of `ctx` from an initialised torch.distributed process group (any backend,
     it only ships the id / carries the host-staged collectives).  Returns (rank, world).

@@ -167,6 +167,28 @@ def test_shard_range_covers_points():
             assert seen == list(range(M))
 
 
+def _pick_backend_worker(rank, world, port, ids, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from sgdml_amd import _lib
+        from sgdml_amd.dist import pick_backend
+
+        _lib.device_pci_bus_id = lambda device: ids[rank]  # no GPU here: the bus ids a launcher layout would produce
+        with open(os.path.join(out_dir, 'r%d' % rank), 'w') as f:
+            f.write(pick_backend(0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('ids,expect', [(['0000:05:00.0', '0000:15:00.0'], 'rccl'),  # one GPU each (also with private views)
+                                        (['0000:05:00.0', '0000:05:00.0'], 'host'),  # ranks share a GPU: RCCL would refuse
+                                        (['0000:05:00.0', None], 'host')])           # a rank cannot tell: stay functional
+def test_pick_backend_by_physical_gpu(tmp_path, ids, expect):
+    mp.spawn(_pick_backend_worker, args=(2, _free_port(), ids, str(tmp_path)), nprocs=2, join=True)
+    assert [open(os.path.join(str(tmp_path), 'r%d' % r)).read() for r in range(2)] == [expect, expect]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Distributed Cholesky (csrc/dist_chol.hip): the block-row-cyclic algorithm with real multi-process collectives,
 # NumPy standing in for the per-rank kernels.
