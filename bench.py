@@ -450,7 +450,7 @@ def run_sharded_cg(args, rank, world):
     import torch.distributed as dist
 
     from sgdml_amd import _lib
-    from sgdml_amd.dist import init_comm_from_torch_distributed, pick_backend
+    from sgdml_amd.dist import init_comm_from_torch_distributed, pick_backend, probe_rccl
 
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist.init_process_group('gloo')
@@ -458,6 +458,14 @@ def run_sharded_cg(args, rank, world):
     comm = args.comm
     if comm == 'auto':  # RCCL when every rank has a physical GPU of its own; ranks sharing a GPU: functional host-staged run
         comm = pick_backend(local_rank % max(1, n_dev))
+    rccl_probe = None
+    if comm == 'rccl' and args.comm == 'auto':
+        # a toy sharded solve through RCCL in child processes, under a time limit, before the real ranks commit to it: a
+        # node where RCCL does not come up still gets its (slower) strong-scaling line through the host-staged collectives
+        ok, rccl_probe = probe_rccl(local_rank % max(1, n_dev))
+        if not ok:
+            comm = 'host'
+            sys.stderr.write('bench.py: RCCL probe failed ({}); using host-staged collectives\n'.format(rccl_probe))
     ctx = _lib.Context(local_rank % max(1, n_dev))
     init_comm_from_torch_distributed(ctx, backend=comm)
 
@@ -530,7 +538,7 @@ def run_sharded_cg(args, rank, world):
                    'n_atoms': N, 'n_train': M, 'n_inducing_points': k, 'matrix_n': wl['n'], 'precon_m': wl['m'],
                    'pcg_iterations_per_step': args.cg_iters, 'sig': args.sig, 'lam': args.lam,
                    'parallelism': 'row-sharded Nystroem factor + query-sharded mat-vec over {} ranks'.format(world),
-                   'collectives': comm},
+                   'collectives': comm, 'rccl_probe': rccl_probe},
         'phases_ms': {'assemble': asm_ms, 'precon': pre_ms, 'pcg': pcg_ms},
         'ms_per_pcg_iteration': pcg_ms / args.cg_iters,
         'collectives_per_step': res['collectives_per_step'],

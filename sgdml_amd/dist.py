@@ -33,6 +33,56 @@ def pick_backend(device, group=None):
     return 'rccl' if all(i is not None for i in ids) and len(set(ids)) == len(ids) else 'host'
 
 
+def probe_rccl(device, group=None, timeout=150):
+    """Does RCCL come up and finish its collectives across the ranks of `group` on this node?  Every rank runs
+    sgdml_amd._rccl_probe (a toy sharded solve through the library's RCCL path) in a CHILD process under `timeout`
+    seconds -- a hang inside ncclCommInitRank or a collective cannot be interrupted from within the process that
+    made the call, a child can be killed -- and the ranks compare the replicated result.  Returns (ok, detail) with
+    the same answer on every rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import torch.distributed as dist
+
+    from . import _lib
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    payload = [None]
+    if rank == 0:
+        try:
+            payload = [_lib.Context.comm_unique_id()]
+        except Exception as e:
+            payload = [repr(e)]
+    dist.broadcast_object_list(payload, src=0, group=group)
+    mine = {'ok': False}
+    if isinstance(payload[0], bytes):
+        cmd = [sys.executable, '-m', 'sgdml_amd._rccl_probe', str(device), str(rank), str(world), payload[0].hex()]
+        try:
+            r = subprocess.run(cmd, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=timeout,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)  # on timeout run() kills exactly this child
+            lines = [ln for ln in r.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
+            mine = json.loads(lines[-1]) if r.returncode == 0 and lines else \
+                {'ok': False, 'error': 'exit {}: {}'.format(r.returncode, r.stderr.decode(errors='replace')[-300:])}
+        except subprocess.TimeoutExpired:
+            mine = {'ok': False, 'error': 'no answer within {} s'.format(timeout)}
+        except Exception as e:
+            mine = {'ok': False, 'error': repr(e)}
+    else:
+        mine = {'ok': False, 'error': 'unique id: {}'.format(payload[0])}
+    every = [None] * world
+    dist.all_gather_object(every, mine, group=group)
+    ok = all(e.get('ok') for e in every)
+    if ok:
+        c = [e['checksum'] for e in every]
+        ok = max(c) - min(c) <= 1e-9 * max(1.0, max(abs(v) for v in c))
+        if not ok:
+            return False, {'error': 'replicated solution differs across ranks', 'checksums': c}
+        return True, {'collectives': every[0]['collectives'], 'checksum': c[0]}
+    return False, {'errors': {r: e.get('error', 'not ok') for r, e in enumerate(every) if not e.get('ok')}}
+
+
 def init_comm_from_torch_distributed(ctx, group=None, backend='rccl'):
     """Create the communicator of `ctx` from an initialised torch.distributed process group (any backend,
     it only ships the id / carries the host-staged collectives).  Returns (rank, world).

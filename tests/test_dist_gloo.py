@@ -189,6 +189,39 @@ def test_pick_backend_by_physical_gpu(tmp_path, ids, expect):
     assert [open(os.path.join(str(tmp_path), 'r%d' % r)).read() for r in range(2)] == [expect, expect]
 
 
+def _probe_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import json
+
+        from sgdml_amd.dist import probe_rccl
+
+        ok, detail = probe_rccl(0, timeout=120)
+        with open(os.path.join(out_dir, 'r%d' % rank), 'w') as f:
+            json.dump({'ok': ok, 'detail': detail}, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_probe_reports_failure_instead_of_hanging(tmp_path):
+    """Without a GPU the probe's child processes cannot bring RCCL up: every rank must get the same (False, reasons)
+    answer -- the branch bench.py takes to fall back to the host-staged collectives."""
+    import json
+
+    from sgdml_amd import _lib
+
+    try:
+        if _lib.device_count() > 0:
+            pytest.skip('a GPU is visible: the failing branch is not reachable (the working one is a gpu test)')
+    except OSError:
+        pytest.skip('libgdml_hip.so not built')
+    mp.spawn(_probe_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = [json.load(open(os.path.join(str(tmp_path), 'r%d' % r))) for r in range(2)]
+    assert got[0] == got[1] and got[0]['ok'] is False
+    assert set(got[0]['detail']['errors']) == {'0', '1'}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Distributed Cholesky (csrc/dist_chol.hip): the block-row-cyclic algorithm with real multi-process collectives,
 # NumPy standing in for the per-rank kernels.

@@ -190,6 +190,26 @@ def test_rccl_collectives_execute_with_one_rank(ctx):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * np.abs(a).max())
 
 
+def test_rccl_probe_child_process_one_rank():
+    """sgdml_amd._rccl_probe (the child bench.py runs on every rank before it commits to RCCL): a size-one communicator,
+    the toy sharded solve completes, its collectives are counted, and the answer equals the same solve without a
+    communicator."""
+    import json
+    import subprocess
+    import sys
+
+    from sgdml_amd import _lib
+
+    uid = _lib.Context.comm_unique_id()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'sgdml_amd._rccl_probe', '0', '0', '1', uid.hex()], cwd=root, timeout=300,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')][-1])
+    assert out['ok'] and out['collectives'] >= 3 + 3 * 5
+    assert _lib.device_pci_bus_id(0) and ':' in _lib.device_pci_bus_id(0)
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_sharded_iterative_processes_share_one_gpu(tmp_path, world):
     """The sharded iterative solver END TO END through GDMLTrain / Iterative / cg.hip / comm.hip: `world`
