@@ -421,6 +421,7 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
     return GDML_OK;
   };
   rc = body();
+  if (rc == GDML_ERR_HIP) comm_abort(ctx);  // a LOCAL failure (errors computed from replicated data hit every rank alike)
   if (rc == GDML_OK) {
     ctx->precon = X;
     ctx->precon_m = m;
@@ -612,6 +613,7 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
   };
   phase_begin(ctx);
   rc = body();
+  if (rc == GDML_ERR_HIP) comm_abort(ctx);  // a LOCAL failure (errors computed from replicated data hit every rank alike)
   if (rc == GDML_OK) rc = phase_end(ctx, "pcg");
   if (rc == GDML_OK) {
     hipError_t e = hipMemcpyAsync(x_out, x, n * 8, hipMemcpyDeviceToHost, ctx->stream);

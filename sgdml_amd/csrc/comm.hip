@@ -19,6 +19,7 @@ struct RcclApi {
   ncclResult_t_ (*GetUniqueId)(ncclUniqueId_*) = nullptr;
   ncclResult_t_ (*CommInitRank)(ncclComm_t_*, int, ncclUniqueId_, int) = nullptr;
   ncclResult_t_ (*CommDestroy)(ncclComm_t_) = nullptr;
+  ncclResult_t_ (*CommAbort)(ncclComm_t_) = nullptr;
   const char* (*GetErrorString)(ncclResult_t_) = nullptr;
   ncclResult_t_ (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
   ncclResult_t_ (*AllGather)(const void*, void*, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
@@ -45,6 +46,7 @@ static bool rccl_load(std::string* err) {
   a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.CommAbort = (decltype(a.CommAbort))dlsym(h, "ncclCommAbort");  // optional: comm_abort falls back to destroy
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
   a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
@@ -96,6 +98,7 @@ extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int wo
   ncclResult_t_ r = g_rccl.CommInitRank(&comm, world, id, rank);
   if (r != 0) return rccl_fail(ctx, "ncclCommInitRank", r);
   ctx->comm = comm;
+  ctx->comm_aborted = false;
   ctx->rank = rank;
   ctx->world = world;
   ctx->virtual_rank = false;
@@ -107,6 +110,16 @@ extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int wo
 void comm_destroy(gdml_ctx* ctx) {
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t_)ctx->comm);
   ctx->comm = nullptr;
+}
+
+void comm_abort(gdml_ctx* ctx) {
+  if (!comm_active(ctx) || ctx->world <= 1) return;
+  if (ctx->comm) {
+    if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t_)ctx->comm);
+    else if (g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t_)ctx->comm);
+    ctx->comm = nullptr;
+  }
+  ctx->comm_aborted = true;  // (host-staged backend: the peers' gloo collective times out on its own)
 }
 
 extern "C" int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out) {
@@ -171,6 +184,7 @@ int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk) { return c
 
 int comm_allgather_inplace_on(gdml_ctx* ctx, double* buf, int64_t chunk, hipStream_t st) {
   if (ctx->virtual_rank) return GDML_OK;
+  if (ctx->comm_aborted) return gdml_fail(ctx, GDML_ERR_COMM, "the communicator was aborted after a local failure on this rank");
   if (ctx->host_allgather) {
     const int64_t tot = chunk * ctx->world;
     GDML_TRY(host_stage(ctx, tot * 8));
@@ -195,6 +209,7 @@ int comm_allgather_inplace_on(gdml_ctx* ctx, double* buf, int64_t chunk, hipStre
 
 int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count) {
   if (ctx->virtual_rank) return GDML_OK;
+  if (ctx->comm_aborted) return gdml_fail(ctx, GDML_ERR_COMM, "the communicator was aborted after a local failure on this rank");
   if (!ctx->host_allreduce && !ctx->comm) return GDML_OK;
   // large buffers go in pieces of 2^27 doubles (1 GiB) to stay inside comfortable message sizes
   const int64_t piece = (int64_t)1 << 27;
@@ -223,6 +238,7 @@ int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count) {
 // callbacks only: all-reduce, all-gather): the other ranks contribute zeros to an all-reduce.
 int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipStream_t st) {
   if (ctx->virtual_rank) return GDML_OK;
+  if (ctx->comm_aborted) return gdml_fail(ctx, GDML_ERR_COMM, "the communicator was aborted after a local failure on this rank");
   if (ctx->host_allreduce) {
     GDML_TRY(host_stage(ctx, count * 8));
     if (ctx->rank == root) {

@@ -113,6 +113,7 @@ struct gdml_ctx {
   int rank = 0, world = 1;
   bool virtual_rank = false;   // shard arithmetic only, collectives skipped (tests)
   gdml_host_allreduce host_allreduce = nullptr;  // host-staged collectives (gdml_comm_init_host)
+  bool comm_aborted = false;  // comm_abort() ran: every later collective fails instead of acting like a single rank
   gdml_host_allgather host_allgather = nullptr;
   void* host_coll_user = nullptr;
   double* h_coll = nullptr;    // pinned staging buffer of the host-staged collectives
@@ -209,6 +210,10 @@ int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count);
 int comm_allgather_inplace_on(gdml_ctx* ctx, double* buf, int64_t chunk, hipStream_t st);
 int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipStream_t st);
 void comm_destroy(gdml_ctx* ctx);
+// A rank that fails locally between collectives (a launch error in a panel loop) must not leave its peers blocked in
+// the collective it will never join: RCCL communicators are aborted (ncclCommAbort: the peers' pending and later
+// operations end with an error), and this context refuses further collectives.
+void comm_abort(gdml_ctx* ctx);
 static inline bool comm_active(const gdml_ctx* ctx) { return (ctx->comm || ctx->host_allreduce) && !ctx->virtual_rank; }
 bool assemble_wave_applicable(const gdml_ctx* ctx);
 bool assemble_strip_applicable(const gdml_ctx* ctx);

@@ -280,6 +280,7 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
       (void)hipEventDestroy(ev_b[e]);
     }
     (void)hipStreamDestroy(sn);
+    if (rc_loop != GDML_OK) comm_abort(ctx);  // the peers are (or will be) inside a collective this rank never joins
     GDML_TRY(rc_loop);
     GDML_TRY(phase_end(ctx, "factor"));
     // first failing pivot over all ranks (0 = none): every rank reports its own in slot `rank` of a summed vector
