@@ -522,11 +522,8 @@ int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_
   const int PG = A.pg_eff >= 3 ? 4 : A.pg_eff;
   // row atoms per consumer wavefront: three (1 and 2 -- more consumers, fewer producers -- measured slower or equal at
   // N = 9 .. 21, the producers being the critical path: profiles/r03_assemble_pts.txt)
-  int NA = -1;
-  const int nv_opt = ctx_opt_i(ctx, "asm.pts_nv", 0);
-  size_t lds = 0;
   const bool special = use_E || A.dbg != 0 || !A.nt_store;
-  auto dispatch = [&](int, dim3 g, size_t* lds_out) {  // three row atoms per consumer (1 and 2 were measured, not kept)
+  auto dispatch = [&](dim3 g, size_t* lds_out) {
 #define PTS_GO(pg)                                                                         \
   do {                                                                                     \
     if (special) { if (A.lower) pts_launch_t<pg, 3, true, true>(ctx, A, g, lds_out); else pts_launch_t<pg, 3, false, true>(ctx, A, g, lds_out); } \
@@ -535,16 +532,15 @@ int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_
     if (PG == 1) PTS_GO(1); else if (PG == 2) PTS_GO(2); else PTS_GO(4);
 #undef PTS_GO
   };
-  for (int na = 3; na <= 3; ++na) {
-    A.NO = (N + na - 1) / na;
-    const int nv_want = 1 + PG < 3 ? 1 + PG : (na == 3 ? 1 + PG : 3);
-    A.NV = 12 - A.NO < 1 + PG ? 12 - A.NO : 1 + PG;
-    if (nv_opt >= 1 && nv_opt <= 12 - A.NO) A.NV = nv_opt;
-    if (A.NV < 1 || (A.NV < nv_want && na < 3 && nv_opt < 1)) continue;
-    dispatch(na, dim3(1), &lds);
-    if (lds <= 160 * 1024) { NA = na; break; }
-  }
-  if (NA < 0) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_pts: no LDS layout for N=%d P=%d", N, P);
+  // 12 wavefronts: ceil(N / 3) consumers, then one producer per task of a step (row role + one column role per permutation
+  // of the group) as far as they fit
+  A.NO = (N + 2) / 3;
+  A.NV = 12 - A.NO < 1 + PG ? 12 - A.NO : 1 + PG;
+  const int nv_opt = ctx_opt_i(ctx, "asm.pts_nv", 0);
+  if (nv_opt >= 1 && nv_opt <= 12 - A.NO) A.NV = nv_opt;
+  size_t lds = 0;
+  if (A.NV >= 1) dispatch(dim3(1), &lds);
+  if (A.NV < 1 || lds > 160 * 1024) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_pts: no LDS layout for N=%d P=%d", N, P);
   const int64_t n_strips = (n_j + A.PPS - 1) / A.PPS;
   const int64_t n_i = i_end - i_beg;
   int i_chunk = ctx_opt_i(ctx, "asm.pts_i_chunk", 64);
@@ -555,7 +551,7 @@ int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_
   A.n_strips = (int)n_strips;
   dim3 grid((unsigned)((n_strips + 7) / 8 * 8), (unsigned)((n_i + i_chunk - 1) / i_chunk));
   const int slot = ktime_begin(ctx);
-  dispatch(NA, grid, nullptr);
+  dispatch(grid, nullptr);
   const double blocks = A.lower ? 0.5 * (double)n_i * (double)(n_i + 1) : (double)n_i * (double)n_j;
   ktime_end(ctx, slot, "assemble", 8.0 * blocks * 9.0 * N * N);
   ctx->launch_counter++;
