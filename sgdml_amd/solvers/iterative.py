@@ -135,7 +135,9 @@ class Iterative(object):
         n = n_train * dim_i + (n_train if use_E_cstr else 0)
         _, free_b, _ = ctx.mem_info()
         budget = free_b if self._max_memory is None else min(free_b, int(self._max_memory) * 1024**3)
-        n_inducing_pts = min(n_train, Iterative.max_n_inducing_pts_device(n_train, n_atoms, 0.8 * budget))
+        sharded = getattr(ctx, '_bcast', None) is not None
+        world = ctx.comm_info()[1] if sharded else 1  # the rows of K_nm are split over the ranks, its m x m blocks are not
+        n_inducing_pts = min(n_train, Iterative.max_n_inducing_pts_device(n_train, n_atoms, 0.8 * budget, world))
         n_inducing_pts = max(1, n_inducing_pts)
         if getattr(self.gdml_train, '_force_n_inducing_pts', None):
             n_inducing_pts = min(n_train, int(self.gdml_train._force_n_inducing_pts))
@@ -182,8 +184,6 @@ class Iterative(object):
         state = {'num_iters': int(num_iters0), 'resid': 0.0, 'start': 0.0, 'avg_tt': 0.0, 'alpha_t': alpha_t}
         steps_hist = collections.deque(maxlen=CG_STEPS_HIST_LEN)
         maxiter = 3 * n_atoms * n_train * 10  # iterative.py:747-750
-
-        sharded = getattr(ctx, '_bcast', None) is not None
 
         def _cg_status(it, resid, xk):
             """Reference policy per iteration (iterative.py:614-735); returns True to stop for a restart."""
@@ -299,10 +299,11 @@ class Iterative(object):
         return est_bytes
 
     @staticmethod
-    def max_n_inducing_pts_device(n_train, n_atoms, budget_bytes):
-        """HBM model of this backend: the (n+m) x m matrix plus one m x m backup, n = 3N M, m = 3N k."""
+    def max_n_inducing_pts_device(n_train, n_atoms, budget_bytes, world=1):
+        """HBM model of this backend, per GPU: this rank's rows of the (n+m) x m matrix plus one m x m backup,
+        n = 3N M / world (contiguous point shards, csrc/comm.hip::shard_points), m = 3N k."""
         to_dof = (3 * n_atoms) ** 2 * 8
-        lin = n_train * to_dof  # n m 8 = M k (3N)^2 8
+        lin = -(-n_train // max(1, int(world))) * to_dof  # n_loc m 8 = ceil(M / W) k (3N)^2 8
         sq = 2 * to_dof  # 2 m^2 8
         k = (np.sqrt(lin**2 + 4.0 * sq * budget_bytes) - lin) / (2 * sq)
         return min(int(k), n_train)

@@ -320,3 +320,19 @@ def test_find_perms_matches_reference_on_the_cli_sweep_sample():
     fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cli_sweep.npz'))
     got = perm.find_perms(fx['R'][fx['idxs_train']], fx['z'])
     assert np.array_equal(got, fx['perms'])
+
+
+def test_inducing_point_memory_model_is_per_shard():
+    """Iterative.max_n_inducing_pts_device: the largest k whose footprint (this rank's rows of K_nm + the m x m block + its
+    backup) fits the budget; the row term shrinks with the number of ranks, the replicated m x m terms do not."""
+    from sgdml_amd.solvers.iterative import Iterative
+
+    M, N = 5000, 21
+    budget = 0.8 * 32 * 1024**3
+    ks = [Iterative.max_n_inducing_pts_device(M, N, budget, w) for w in (1, 2, 4, 8)]
+    assert ks == sorted(ks) and ks[-1] > ks[0]
+    for w, k in zip((1, 2, 4, 8), ks):
+        foot = lambda kk: (-(-M // w) * 3 * N + 2 * 3 * N * kk) * (3 * N * kk) * 8  # (n_loc + m) m + m^2 doubles
+        assert foot(k) <= budget < foot(k + 1)
+    assert Iterative.max_n_inducing_pts_device(M, N, budget) == ks[0]  # default: one GPU
+    assert Iterative.max_n_inducing_pts_device(10, 3, 1e15, 4) == 10  # never more than the training points
