@@ -121,6 +121,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   dist.nb (512)         row-block size of the distributed Cholesky (multiple of 128)
  *   nys.force_qr (0)      take the alternative (QR-equivalent) branch of the second Nystroem factorisation (tests)
  *   nys.force_fail (0)    treat the first k attempts of the jitter-stabilised Cholesky of K_mm as failed (tests)
+ *   pcg.depth (2)         PCG iterations queued ahead of the host's convergence test / callback (0 = synchronous)
  * Unknown keys return GDML_ERR_INVALID. */
 int gdml_set_option(gdml_ctx* ctx, const char* key, double value);
 int gdml_get_option(gdml_ctx* ctx, const char* key, double* value_out, int* is_set_out);
@@ -249,12 +250,16 @@ int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, const double* 
  *   shifted CholeskyQR3 on fp64 MFMA with the same R^T R up to rounding).
  * gdml_precon_apply: out = (L^T L v - v)/lam  (iterative.py:120-140).
  * gdml_pcg: preconditioned CG for (-K + lam I) x = y with scipy.sparse.linalg.cg semantics
- *   (iterative.py:740-752: rtol*||y||, atol = 0, x0 optional).  cb(iter, resid, x_host, user)
- *   is called every cb_every iterations (0 = never) with the iterate x_iter copied to the host and
- *   resid = ||y - A x_iter|| (the recurrence residual after the update, what the reference's callback reads from
- *   scipy's frame, iterative.py:626-632); a non-zero return stops the solve (used for CGRestartException, iterative.py:729).
+ *   (iterative.py:740-752: rtol*||y||, atol = 0, x0 optional).  Vectors and CG scalars stay on the device; the host
+ *   reads the residual of an iteration only when it queues the iteration `pcg.depth` (default 2) steps later, so the GPU
+ *   never waits for the host, and returns exactly the iterate scipy would (the iterates in flight live in a ring).
+ *   cb(iter, resid, user) is called every cb_every iterations (0 = never) with resid = ||y - A x_iter|| (the recurrence
+ *   residual after the update, what the reference's callback reads from scipy's frame, iterative.py:626-632); a non-zero
+ *   return stops the solve with x_iter (used for CGRestartException, iterative.py:729).  Inside the callback -- and only
+ *   there -- gdml_pcg_x copies x_iter to the host (checkpoints, iterative.py:675-735; restarts): the iterate does not
+ *   cross PCIe unless somebody asks for it.
  *   info_out: 0 converged, 1 maxiter reached, 2 stopped by callback. */
-typedef int (*gdml_pcg_cb)(int64_t iter, double resid, const double* x_host, void* user);
+typedef int (*gdml_pcg_cb)(int64_t iter, double resid, void* user);
 int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* idx, int64_t m,
                          double* lev_scores_out, double* LinvKmn_host_out, int* info);
 int gdml_precon_apply(gdml_ctx* ctx, double lam, const double* v, int64_t n, double* out);
@@ -262,6 +267,7 @@ int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const d
              int64_t n, double rtol, int64_t maxiter, int use_precon, gdml_pcg_cb cb,
              int64_t cb_every, void* user, double* x_out, int64_t* iters_out, double* resid_out,
              int* info_out);
+int gdml_pcg_x(gdml_ctx* ctx, double* x_host_out);
 
 /* ---- multi-GPU (new: the reference has no collective) ----------------------
  * One process per GPU.  Rank 0 calls gdml_comm_unique_id (128 bytes) and ships it to the

@@ -14,7 +14,7 @@ COLS_ALL, COLS_POINTS, COLS_INDEX = 0, 1, 2
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
 _vp = C.c_void_p
-PCG_CB = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, _dp, _vp)
+PCG_CB = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, _vp)
 HOST_COLL_CB = C.CFUNCTYPE(C.c_int, _dp, C.c_int64, _vp)  # gdml_host_allreduce / gdml_host_allgather
 
 # name -> (restype, argtypes).  Must list every symbol declared in include/gdml_hip.h.
@@ -50,6 +50,7 @@ SIGNATURES = {
     'gdml_precon_apply': (C.c_int, [_vp, C.c_double, _vp, C.c_int64, _vp]),
     'gdml_pcg': (C.c_int, [_vp, C.c_double, C.c_int, _vp, _vp, C.c_int64, C.c_double, C.c_int64, C.c_int,
                            PCG_CB, C.c_int64, _vp, _vp, _ip, _dp, C.POINTER(C.c_int)]),
+    'gdml_pcg_x': (C.c_int, [_vp, _vp]),
     'gdml_dist_chol_solve': (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int64, _vp, C.POINTER(C.c_int)]),
     'gdml_comm_unique_id': (C.c_int, [_vp]),
     'gdml_comm_init': (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
@@ -504,6 +505,9 @@ class Context(object):
 
     def pcg(self, lam, use_E_cstr, y, x0=None, rtol=1e-4, maxiter=1000, use_precon=True, callback=None,
             cb_every=1):
+        """Preconditioned CG on the device (gdml_pcg).  callback(it, resid, fetch_x) is called every cb_every iterations;
+        fetch_x() copies the iterate of THAT iteration to the host (the only way it crosses PCIe before the solve ends);
+        a true return value stops the solve with that iterate.  Returns (x, info, iterations, residual norm)."""
         y = f64(y).ravel()
         n = y.size
         x0 = f64(x0)
@@ -511,10 +515,14 @@ class Context(object):
         iters, resid, info = C.c_int64(), C.c_double(), C.c_int()
         exc = []
 
-        def _cb(it, res, xp, _user):
+        def _fetch_x():
+            xk = np.empty(n)
+            self._check(self._lib.gdml_pcg_x(self._h, _ptr(xk)))
+            return xk
+
+        def _cb(it, res, _user):
             try:
-                xk = np.ctypeslib.as_array(xp, shape=(n,))
-                return int(bool(callback(int(it), float(res), xk)))
+                return int(bool(callback(int(it), float(res), _fetch_x)))
             except BaseException as e:  # propagate after the C call returns
                 exc.append(e)
                 return 1

@@ -186,7 +186,10 @@ __global__ void __launch_bounds__(256) gemv_n_precon_kernel(const double* __rest
   if (lane == 0) out[r] = (s - v[r]) * inv_lam;
 }
 
-// ---- small vector kernels for the PCG loop
+// ---- vector kernels of the PCG loop.  The CG scalars (rho, p.Ap, ||r||^2) never leave the device: a dot product is
+// 256 per-workgroup partials, and every consumer sums them itself in one fixed order (same value in every workgroup and on
+// every rank), so an iteration is a chain of launches without a host round trip.
+#define PCG_PARTS 256
 __global__ void __launch_bounds__(256) dot_part_kernel(const double* __restrict__ a,
                                                        const double* __restrict__ b, int64_t n,
                                                        double* __restrict__ part) {
@@ -199,33 +202,90 @@ __global__ void __launch_bounds__(256) dot_part_kernel(const double* __restrict_
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// sum of PCG_PARTS partials, identical in every thread of every 256-thread workgroup that calls it
+template <bool COHERENT = false>
+__device__ __forceinline__ double sum_parts(const double* part, double* red /* LDS, 4 doubles */) {
+  // COHERENT: the partials were written by other workgroups of the SAME launch -> read them past the per-CU L1
+  const double v = COHERENT ? __hip_atomic_load(part + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : part[threadIdx.x];
+  const double s = wave_sum(v);
+  __syncthreads();  // red may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+// p = z + (rho / rho_prev) p        (first iteration: p = z)
+__global__ void __launch_bounds__(256) pcg_p_update_kernel(double* __restrict__ p, const double* __restrict__ z,
+                                                           const double* __restrict__ part_rho,
+                                                           const double* __restrict__ part_rho_prev, int first,
+                                                           int64_t n) {
+  __shared__ double red[4];
+  double beta = 0.0;
+  if (!first) {
+    const double rho = sum_parts(part_rho, red);
+    const double rho_prev = sum_parts(part_rho_prev, red);
+    beta = rho / rho_prev;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    p[i] = first ? z[i] : z[i] + beta * p[i];
+}
+// alpha = rho / (p.Ap), q = -(A p):  x_out = x_in + alpha p,  r += alpha q,  and ||r||^2 of the updated residual: the last
+// workgroup to finish sums the partials and publishes the value to the host-mapped slot `rr_host` (and to rr_dev).
+__global__ void __launch_bounds__(256) pcg_xr_update_kernel(const double* __restrict__ x_in, double* __restrict__ x_out,
+                                                            double* __restrict__ r, const double* __restrict__ p,
+                                                            const double* __restrict__ q,
+                                                            const double* __restrict__ part_rho,
+                                                            const double* __restrict__ part_pq,
+                                                            double* __restrict__ part_rr, unsigned* __restrict__ counter,
+                                                            double* __restrict__ rr_dev, volatile double* rr_host,
+                                                            int64_t n) {
+  __shared__ double red[4];
+  __shared__ unsigned ticket;
+  const double rho = sum_parts(part_rho, red);
+  const double pq = sum_parts(part_pq, red);
+  const double alpha = rho / (-pq);
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    x_out[i] = x_in[i] + alpha * p[i];
+    const double rv = r[i] + alpha * q[i];
+    r[i] = rv;
+    s += rv * rv;
+  }
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part_rr[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    __threadfence();
+    ticket = atomicAdd(counter, 1u);
+  }
+  __syncthreads();
+  if (ticket == gridDim.x - 1) {  // every partial is visible: one fixed-order sum
+    __threadfence();
+    const double rr = sum_parts<true>(part_rr, red);
+    if (threadIdx.x == 0) {
+      *rr_dev = rr;
+      *rr_host = rr;
+      __threadfence_system();
+      *counter = 0u;
+    }
+  }
+}
+// ||r||^2 of a residual that did not come out of pcg_xr_update_kernel (the start vector): partials -> slot
+__global__ void __launch_bounds__(256) pcg_publish_kernel(const double* __restrict__ part, double* __restrict__ rr_dev,
+                                                          volatile double* rr_host) {
+  __shared__ double red[4];
+  const double rr = sum_parts(part, red);
+  if (threadIdx.x == 0) {
+    *rr_dev = rr;
+    *rr_host = rr;
+    __threadfence_system();
+  }
+}
 __global__ void __launch_bounds__(256) vec_axpy_kernel(double* __restrict__ y, const double* __restrict__ x,
                                                        double a, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) y[i] += a * x[i];
-}
-__global__ void __launch_bounds__(256) vec_xpby_kernel(double* __restrict__ p, const double* __restrict__ z,
-                                                       double beta, int64_t n) {  // p = z + beta p
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = z[i] + beta * p[i];
-}
-__global__ void __launch_bounds__(256) vec_neg_kernel(double* __restrict__ y, const double* __restrict__ x,
-                                                      int64_t n) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) y[i] = -x[i];
-}
-
-static int dev_dot(gdml_ctx* ctx, const double* a, const double* b, int64_t n, double* d_part,
-                   double* out) {
-  const int nb = 256;
-  hipLaunchKernelGGL(dot_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, b, n, d_part);
-  double h[256];
-  HIP_CHECK(ctx, hipMemcpyAsync(h, d_part, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  double s = 0.0;
-  for (int i = 0; i < nb; ++i) s += h[i];
-  *out = s;
-  return GDML_OK;
 }
 
 // X[:, 0:m] <- X L^-T  for the n rows of X (L: m x m lower), blocked 512 / 64 like the Cholesky.
@@ -509,10 +569,40 @@ extern "C" int gdml_precon_apply(gdml_ctx* ctx, double lam, const double* v, int
   return rc != GDML_OK ? rc : rc2;
 }
 
-// Preconditioned CG for A x = y, A v = -(K v - lam v)  (iterative.py:740-752; scipy cg:
-// stop when ||r|| < rtol*||y||, atol = 0).  All vectors stay on the device (replicated on every
-// rank when sharded: the mat-vec and the preconditioner all-gather their row shards, dot products
-// are evaluated redundantly and identically); two scalars per iteration come back to the host.
+// Preconditioned CG for A x = y, A v = -(K v - lam v)  (iterative.py:740-752; scipy cg: stop when ||r|| < rtol*||y||,
+// atol = 0).  All vectors AND the CG scalars stay on the device (replicated on every rank when sharded: the mat-vec and the
+// preconditioner all-gather their row shards, dot products are evaluated redundantly and identically).
+//
+// The host never waits for the iteration it has just queued.  Every iteration ends by publishing ||r||^2 into a ring of
+// host-mapped slots; the host reads the residual of iteration s only when it is about to queue iteration s + DEPTH
+// (option pcg.depth, default 2), so DEPTH iterations are always in flight and the convergence test / callback of scipy's
+// loop are evaluated with that lag -- but with exactly scipy's semantics: the iterates x_s ... x_{s+DEPTH} live in a ring of
+// DEPTH + 1 device vectors, and when the test (or the callback) for iteration s says stop, x_s is what is returned; the
+// at most DEPTH iterations queued beyond it are discarded.  Decisions derive from replicated scalars, so every rank of a
+// sharded run queues the same sequence of collectives.
+struct PcgRun {
+  int64_t n = 0;
+  int depth = 0, ring = 0;
+  double* xring = nullptr;  // (depth + 1) x n_pad iterates
+  int64_t n_pad = 0;
+  int64_t cb_iter = -1;     // iteration the callback is reporting (gdml_pcg_x), -1 outside a callback
+};
+static thread_local PcgRun* g_pcg_run = nullptr;
+static thread_local gdml_ctx* g_pcg_ctx = nullptr;
+
+extern "C" int gdml_pcg_x(gdml_ctx* ctx, double* x_host_out) {
+  if (!ctx || !x_host_out) return GDML_ERR_INVALID;
+  PcgRun* run = g_pcg_run;
+  if (!run || g_pcg_ctx != ctx || run->cb_iter < 0)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_pcg_x: only valid inside the callback of a running gdml_pcg");
+  // x_s is complete (its residual has been read) and its slot is not rewritten before the callback returns: copy it on the
+  // second stream, past the iterations queued on the compute stream
+  const double* xs = run->xring + (run->cb_iter % (run->depth + 1)) * run->n_pad;
+  HIP_CHECK(ctx, hipMemcpyAsync(x_host_out, xs, run->n * 8, hipMemcpyDeviceToHost, ctx->stream2));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
+  return GDML_OK;
+}
+
 extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const double* x0,
                         int64_t n, double rtol, int64_t maxiter, int use_precon, gdml_pcg_cb cb,
                         int64_t cb_every, void* user, double* x_out, int64_t* iters_out,
@@ -533,93 +623,151 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
     shard_points(ctx, ctx->ts.M, &p0, &p1, &per);
     n_pad = per * 3 * ctx->ts.N * ctx->world;
   }
+  n_pad = (n_pad + 31) / 32 * 32;
+  int depth = ctx_opt_i(ctx, "pcg.depth", 2);
+  if (depth < 0) depth = 0;
+  if (depth > 14) depth = 14;
+  // the host-staged collectives synchronise the stream inside every mat-vec anyway: nothing to pipeline
+  if (ctx->host_allreduce) depth = 0;
+  const int XR = depth + 1, RING = depth + 2;
+  // device: [x ring | r | z | p | q | b | partials rho[2], pq, rr | rr_dev | counter]
+  const int64_t n_vec = XR + 5;
+  const int64_t tail = 4 * PCG_PARTS + 64;
   void* buf = nullptr;
-  GDML_TRY(ctx_alloc(ctx, &buf, (6 * n_pad + 256) * 8));
-  double* x = (double*)buf;
-  double* r = x + n_pad;
+  GDML_TRY(ctx_alloc(ctx, &buf, (n_vec * n_pad + tail) * 8));
+  double* xring = (double*)buf;
+  double* r = xring + XR * n_pad;
   double* z = r + n_pad;
   double* p = z + n_pad;
   double* q = p + n_pad;
   double* b = q + n_pad;
-  double* d_part = b + n_pad;
-  const int grid = ceil_div(n, 256);
-  std::vector<double> hx;
+  double* part_rho[2] = {b + n_pad, b + n_pad + PCG_PARTS};
+  double* part_pq = part_rho[1] + PCG_PARTS;
+  double* part_rr = part_pq + PCG_PARTS;
+  double* rr_dev = part_rr + PCG_PARTS;
+  unsigned* counter = (unsigned*)(rr_dev + 8);
+  // host-mapped residual ring + one event per slot
+  double* h_rr = nullptr;
+  std::vector<hipEvent_t> ev((size_t)RING, nullptr);
+  PcgRun run;
+  run.n = n; run.depth = depth; run.ring = RING; run.xring = xring; run.n_pad = n_pad;
   int rc = GDML_OK, info = 1;
   int64_t it = 0;
   double rn = 0.0;
+  const int64_t x_final_slot_none = -1;
+  int64_t x_final = x_final_slot_none;  // iterate index to return
+  auto xs = [&](int64_t s) { return xring + (s % XR) * n_pad; };
   auto body = [&]() -> int {
-    HIP_CHECK(ctx, hipMemsetAsync(buf, 0, (6 * n_pad + 256) * 8, ctx->stream));
-    HIP_CHECK(ctx, hipMemcpyAsync(b, y, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    double bb = 0.0;
-    GDML_TRY(dev_dot(ctx, b, b, n, d_part, &bb));
-    const double bnrm = sqrt(bb);
+    HIP_CHECK(ctx, hipHostMalloc((void**)&h_rr, RING * 8, hipHostMallocMapped));
+    double* h_rr_dev = nullptr;
+    HIP_CHECK(ctx, hipHostGetDevicePointer((void**)&h_rr_dev, h_rr, 0));
+    for (auto& e : ev) HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipStream_t st = ctx->stream;
+    HIP_CHECK(ctx, hipMemsetAsync(buf, 0, (n_vec * n_pad + tail) * 8, st));
+    HIP_CHECK(ctx, hipMemcpyAsync(b, y, n * 8, hipMemcpyHostToDevice, st));
+    // ||b||: the one synchronous read of the solve
+    hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, b, b, n, part_rr);
+    hipLaunchKernelGGL(pcg_publish_kernel, dim3(1), dim3(256), 0, st, part_rr, rr_dev, h_rr_dev);
+    HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const double bnrm = sqrt(h_rr[0]);
     if (bnrm == 0.0) {
       info = 0;
+      x_final = 0;  // x ring slot 0 is all zeros
       return GDML_OK;
     }
     const double atol = rtol * bnrm;
+    double* x = xs(0);
     if (x0) {
-      HIP_CHECK(ctx, hipMemcpyAsync(x, x0, n * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIP_CHECK(ctx, hipMemcpyAsync(x, x0, n * 8, hipMemcpyHostToDevice, st));
       GDML_TRY(matvec_device(ctx, lam, use_E_cstr, x, n, q));  // q = K x - lam x = -A x
-      HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-      hipLaunchKernelGGL(vec_axpy_kernel, dim3(grid), dim3(256), 0, ctx->stream, r, q, 1.0, n);  // r = b - A x
+      HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(vec_axpy_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, r, q, 1.0, n);  // r = b - A x
     } else {
-      HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, st));
     }
-    double rho_prev = 0.0;
-    double rr = 0.0;
-    GDML_TRY(dev_dot(ctx, r, r, n, d_part, &rr));
-    rn = sqrt(rr);
-    for (it = 0; it < maxiter; ++it) {
+    hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, r, r, n, part_rr);
+    hipLaunchKernelGGL(pcg_publish_kernel, dim3(1), dim3(256), 0, st, part_rr, rr_dev, h_rr_dev + 0);
+    HIP_CHECK(ctx, hipEventRecord(ev[0], st));
+
+    int64_t enq = 0, seen = 0;  // iterations queued; residuals ||r_0|| .. ||r_{seen-1}|| processed
+    // processes ||r_s||: callback of iteration s (s >= 1), then scipy's test at the top of iteration s.  Returns 1 = stop.
+    auto process = [&](int64_t s, int* stop) -> int {
+      HIP_CHECK(ctx, hipEventSynchronize(ev[s % RING]));
+      rn = sqrt(h_rr[s % RING]);
+      *stop = 0;
+      if (s >= 1 && cb && cb_every > 0 && (s % cb_every) == 0) {
+        run.cb_iter = s;
+        const int stop_cb = cb(s, rn, user);
+        run.cb_iter = -1;
+        if (stop_cb != 0) {
+          info = 2;
+          it = s;
+          x_final = s;
+          *stop = 1;
+          return GDML_OK;
+        }
+      }
       if (rn < atol) {
         info = 0;
+        it = s;
+        x_final = s;
+        *stop = 1;
+      }
+      return GDML_OK;
+    };
+    for (;;) {
+      int stop = 0;
+      while (seen <= enq - depth || (enq >= maxiter && seen <= enq)) {
+        GDML_TRY(process(seen, &stop));
+        if (stop) return GDML_OK;
+        ++seen;
+      }
+      if (enq >= maxiter) {  // every residual up to ||r_maxiter|| has been tested
+        info = 1;
+        it = maxiter;
+        x_final = maxiter;
         return GDML_OK;
       }
+      // ---- queue iteration enq: x_{enq} -> x_{enq+1}
+      const int cur = (int)(enq & 1);
       const double* zz = r;
       if (use_precon) {
         GDML_TRY(precon_apply_device(ctx, lam, r, z));
         zz = z;
       }
-      double rho = 0.0;
-      GDML_TRY(dev_dot(ctx, r, zz, n, d_part, &rho));
-      if (it == 0)
-        HIP_CHECK(ctx, hipMemcpyAsync(p, zz, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-      else
-        hipLaunchKernelGGL(vec_xpby_kernel, dim3(grid), dim3(256), 0, ctx->stream, p, zz, rho / rho_prev, n);
+      hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, r, zz, n, part_rho[cur]);
+      hipLaunchKernelGGL(pcg_p_update_kernel, dim3(PCG_PARTS), dim3(256), 0, st, p, zz, part_rho[cur], part_rho[cur ^ 1],
+                         enq == 0 ? 1 : 0, n);
       GDML_TRY(matvec_device(ctx, lam, use_E_cstr, p, n, q));  // q = -(A p)
-      double pq = 0.0;
-      GDML_TRY(dev_dot(ctx, p, q, n, d_part, &pq));
-      const double alpha = rho / (-pq);
-      hipLaunchKernelGGL(vec_axpy_kernel, dim3(grid), dim3(256), 0, ctx->stream, x, p, alpha, n);
-      hipLaunchKernelGGL(vec_axpy_kernel, dim3(grid), dim3(256), 0, ctx->stream, r, q, alpha, n);  // r -= alpha A p
-      rho_prev = rho;
-      // ||r_{it+1}||: tested at the top of the next iteration and handed to the callback together with x_{it+1} -- the
-      // pair scipy's callback sees after its update (the reference reads `r` from cg's frame, iterative.py:626-632)
-      GDML_TRY(dev_dot(ctx, r, r, n, d_part, &rr));
-      rn = sqrt(rr);
-      if (cb && cb_every > 0 && ((it + 1) % cb_every) == 0) {
-        hx.resize((size_t)n);
-        HIP_CHECK(ctx, hipMemcpyAsync(hx.data(), x, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (cb(it + 1, rn, hx.data(), user) != 0) {
-          info = 2;
-          ++it;
-          return GDML_OK;
-        }
-      }
+      hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, p, q, n, part_pq);
+      hipLaunchKernelGGL(pcg_xr_update_kernel, dim3(PCG_PARTS), dim3(256), 0, st, xs(enq), xs(enq + 1), r, p, q,
+                         part_rho[cur], part_pq, part_rr, counter, rr_dev, h_rr_dev + ((enq + 1) % RING), n);
+      ctx->launch_counter += 4;
+      HIP_CHECK(ctx, hipGetLastError());
+      HIP_CHECK(ctx, hipEventRecord(ev[(enq + 1) % RING], st));
+      ++enq;
     }
-    info = rn < atol ? 0 : 1;
-    return GDML_OK;
   };
   phase_begin(ctx);
+  g_pcg_run = &run;
+  g_pcg_ctx = ctx;
   rc = body();
+  g_pcg_run = nullptr;
+  g_pcg_ctx = nullptr;
   if (rc == GDML_ERR_HIP) comm_abort(ctx);  // a LOCAL failure (errors computed from replicated data hit every rank alike)
   if (rc == GDML_OK) rc = phase_end(ctx, "pcg");
   if (rc == GDML_OK) {
-    hipError_t e = hipMemcpyAsync(x_out, x, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    // the iterations queued beyond x_final are discarded; they still have to drain before the buffers go away
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(x_out, xs(x_final < 0 ? 0 : x_final), n * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
   }
+  for (auto e : ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h_rr) (void)hipHostFree(h_rr);
   if (iters_out) *iters_out = it;
   if (resid_out) *resid_out = rn;
   if (info_out) *info_out = info;

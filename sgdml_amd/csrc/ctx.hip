@@ -18,7 +18,7 @@ int gdml_fail(gdml_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int gdml_abi_version(void) { return 2; }
+extern "C" int gdml_abi_version(void) { return 3; }
 
 // ---- options --------------------------------------------------------------------------------
 // Every tuning / ablation switch of the library is a (key, value) pair of the context, read at the
@@ -31,7 +31,7 @@ static const char* kKnownOptions[] = {
     "gemm.debug", "gemm.nt_c", "gemm.lds16", "gemm.cacc", "gemm.commit_ks", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
     "chol.fused_min_rows", "chol.outer", "chol.outer_min_rows", "chol.merge_gemm1", "chol.tail_lookahead", "trsm.debug",
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
-    "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb"};
+    "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb", "pcg.depth"};
 
 double ctx_opt(const gdml_ctx* ctx, const char* key, double dflt) {
   auto it = ctx->opts.find(key);

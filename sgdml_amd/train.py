@@ -35,6 +35,9 @@ class GDMLTrain(object):
         self._ctx = None
         self._force_solver = None  # testing hook: 'analytic' or 'cg' overrides the memory-based choice
         self._force_n_inducing_pts = None  # testing hook: inducing points of the iterative solver (else memory model)
+        # testing hook: spend the np.random draws the reference's CPU path spends on its worker benchmark
+        # (solvers/iterative.py::_spend_reference_benchmark_draw); off: the caller's global stream is left alone
+        self._emulate_ref_rng = False
 
     def __del__(self):
         global _instance_alive

@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
     lib = _lib.load()
     for name in _header_functions():
         assert hasattr(lib, name), name
-    assert lib.gdml_abi_version() == 2
+    assert lib.gdml_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -282,7 +282,7 @@ def test_documented_options_match_the_library():
     known = set(re.findall(r'"([a-z_]+\.[a-z0-9_]+)"', blk))
     hdr = open(os.path.join(root, 'include', 'gdml_hip.h')).read()
     doc = hdr[hdr.index('Tuning / ablation options of a context'):hdr.index('Unknown keys return GDML_ERR_INVALID')]
-    documented = set(re.findall(r'\b((?:asm|gemm|chol|trsm|trsv|predict|lu|comm|dist|nys)\.[a-z0-9_]+)', doc))
+    documented = set(re.findall(r'\b((?:asm|gemm|chol|trsm|trsv|predict|lu|comm|dist|nys|pcg|mem)\.[a-z0-9_]+)', doc))
     assert known == documented, (sorted(known - documented), sorted(documented - known))
     used = set()
     csrc = os.path.join(root, 'sgdml_amd', 'csrc')

@@ -339,15 +339,44 @@ def test_pcg_solves_system(golden, ctx):
                              np.zeros(M) if use_E else None)
     seen = []
     x, info, iters, resid = ctx.pcg(lam, use_E, g['y'], rtol=1e-6, maxiter=5000,
-                                    callback=lambda it, r, xk: seen.append((it, r)) or False)
+                                    callback=lambda it, r, fetch_x: seen.append((it, r)) or False)
     assert info == 0 and iters == len(seen)
     A = -g['K'] + lam * np.eye(g['K'].shape[0])
     assert np.linalg.norm(A @ x - g['y']) <= 2e-6 * np.linalg.norm(g['y'])
     # warm start from the solution converges immediately; a stopping callback reports info = 2
     x2, info2, iters2, _ = ctx.pcg(lam, use_E, g['y'], x0=x, rtol=1e-5, maxiter=50)
     assert info2 == 0 and iters2 <= 1
-    _, info3, iters3, _ = ctx.pcg(lam, use_E, g['y'], rtol=1e-12, maxiter=50, callback=lambda it, r, xk: it >= 2)
+    x3, info3, iters3, _ = ctx.pcg(lam, use_E, g['y'], rtol=1e-12, maxiter=50, callback=lambda it, r, fetch_x: it >= 2)
     assert info3 == 2 and iters3 == 2
+    # The loop is pipelined (iterations are queued `pcg.depth` ahead of the host's tests) -- with scipy's semantics all the
+    # same: every depth returns the same iterate after the same number of iterations with the same residual history, the
+    # iterate fetched inside callback k is x_k (its true residual is the reported one), and a stop at k returns x_k.
+    runs = {}
+    for depth in (0, 1, 2, 5):
+        ctx.set_option('pcg.depth', depth)
+        hist, snaps = [], {}
+
+        def cb(it, r, fetch_x):
+            hist.append(r)
+            if it in (1, 3):
+                snaps[it] = fetch_x()
+            return False
+
+        xd_, info_d, iters_d, resid_d = ctx.pcg(lam, use_E, g['y'], rtol=1e-6, maxiter=5000, callback=cb)
+        runs[depth] = (xd_, info_d, iters_d, resid_d, np.array(hist), snaps)
+        xs_, info_s, iters_s, _ = ctx.pcg(lam, use_E, g['y'], rtol=1e-12, maxiter=50, callback=lambda it, r, f: it >= 3)
+        assert info_s == 2 and iters_s == 3 and np.array_equal(xs_, snaps[3])
+        x1_, info_1, iters_1, _ = ctx.pcg(lam, use_E, g['y'], rtol=1e-12, maxiter=1)
+        assert info_1 == 1 and iters_1 == 1 and np.array_equal(x1_, snaps[1])
+    ctx.set_option('pcg.depth', 2)
+    ref_run = runs[0]
+    assert np.array_equal(ref_run[0], x) and ref_run[2] == iters
+    for depth in (1, 2, 5):
+        r_ = runs[depth]
+        assert np.array_equal(r_[0], ref_run[0]) and r_[1:4] == ref_run[1:4] and np.array_equal(r_[4], ref_run[4])
+    for k_, xk_ in ref_run[5].items():
+        true_res = np.linalg.norm(A @ xk_ - g['y'])
+        assert abs(true_res - ref_run[4][k_ - 1]) <= 1e-6 * np.linalg.norm(g['y'])
 
 
 def test_dropin_train_iterative(golden):

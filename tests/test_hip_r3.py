@@ -79,13 +79,14 @@ def test_iterative_restart_and_checkpoints_follow_reference(monkeypatch):
     try:
         tr._force_solver = 'cg'
         tr._force_n_inducing_pts = int(fx['k0'])
+        tr._emulate_ref_rng = True  # replay of a freshly installed reference: the restart's inducing columns depend on it
         ctx = tr._context()
         orig_pcg = ctx.pcg
 
         def spy_pcg(*a, **kw):
             cg_starts.append(len(hist))
             cb = kw['callback']
-            kw['callback'] = lambda it, r, xk: (hist.append(r), cb(it, r, xk))[1]
+            kw['callback'] = lambda it, r, fetch_x: (hist.append(r), cb(it, r, fetch_x))[1]
             return orig_pcg(*a, **kw)
 
         ctx.pcg = spy_pcg
@@ -307,15 +308,17 @@ def test_configs2_trajectory_workload_vs_reference():
         c.nystroem_factor(lam, idx)
         c.predict_upload_model(xd, np.zeros_like(xd), tp, sig, None)
         hist = []
-        x, info, iters, resid = c.pcg(lam, False, y, rtol=1e-4, maxiter=5000, callback=lambda it, r, xk: hist.append(r) or False)
+        x, info, iters, resid = c.pcg(lam, False, y, rtol=1e-4, maxiter=5000, callback=lambda it, r, fetch_x: hist.append(r) or False)
         assert info == 0
         n_ref = int(g['n_iters'])
         assert abs(iters - n_ref) <= max(2, n_ref // 10), (iters, n_ref)
         ref = g['resid_hist']
         ours = np.array(hist)
         np.testing.assert_allclose(ours[:8], ref[:8], rtol=1e-6)
-        k = min(len(ours), len(ref))
-        np.testing.assert_allclose(ours[:k], ref[:k], rtol=0.25)
+        # beyond the first steps two correct PCG runs on this cond ~ 1e10 system decorrelate pointwise (a different
+        # summation order in a dot product is enough): compare WHEN the residual first passes each level instead
+        from _pcg_compare import assert_same_convergence
+        assert_same_convergence(ours, ref, np.linalg.norm(y))
         d = Desc(N)
         F = []
         for coeffs in (g['alphas'], -x):

@@ -129,7 +129,7 @@ def test_pcg_history_vs_reference(ctx):
     ctx.predict_upload_model(xd, np.zeros_like(xd), tp, sig, None)
     hist = []
     x, info, iters, resid = ctx.pcg(lam, False, y, rtol=1e-4, maxiter=5000,
-                                    callback=lambda it, r, xk: hist.append(r) or False)
+                                    callback=lambda it, r, fetch_x: hist.append(r) or False)
     ref = g['resid_hist']
     assert info == 0
     n_ref = int(g['n_iters'])
@@ -180,7 +180,9 @@ def test_rccl_collectives_execute_with_one_rank(ctx):
             if with_comm:
                 assert n0 == 3  # two all-reduces of the m x m blocks + the all-gather of the leverage scores
                 assert n1 - n0 == 1 and n2 - n1 == 2  # mat-vec: all-gather; preconditioner: all-reduce + all-gather
-                assert n3 - n2 == 3 * iters and nbytes > 0  # per iteration: preconditioner (2) + mat-vec (1)
+                # per iteration: preconditioner (2) + mat-vec (1); the pipelined loop has queued up to pcg.depth = 2 iterations beyond
+                # the one that met the tolerance
+                assert 3 * iters <= n3 - n2 <= 3 * (iters + 2) and nbytes > 0
             else:
                 assert n3 == 0
             res.append((lev, Kv, Pv, x))

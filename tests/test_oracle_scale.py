@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import gdml_oracle as orc
+from _pcg_compare import assert_same_convergence
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -146,3 +147,39 @@ def test_restart_fixture_first_stage_history():
     assert eff_after(ref[:100]) <= 0
     second = ref[100:]
     assert all(eff_after(second[k - 100:k]) > 0 for k in range(100, len(second), 50))
+
+
+def test_column_modes_n24_p6_fixture():
+    """Round 4: the reference's index-list and point-slice assembly on N = 24 with a 6-element group (make_golden_r4.py)."""
+    g = load('cols_n24_p6')
+    M, N, xd, gd, tp, lin = setup_case(g)
+    sig, scale = float(g['sig']), float(g['K_absmax'])
+    Ki = orc.assemble_K(xd, gd, lin, sig, col_idxs=g['col_idxs'])
+    assert np.abs(Ki[g['rows']] - g['K_idx_sample']).max() <= 1e-12 * scale
+    assert abs(np.linalg.norm(Ki) - float(g['K_idx_fro'])) <= 1e-11 * float(g['K_idx_fro'])
+    p0, p1 = [int(v) for v in g['points']]
+    Kp = orc.assemble_K(xd, gd, lin, sig, col_idxs=np.s_[p0 * 3 * N:p1 * 3 * N])
+    assert np.abs(Kp[g['rows']] - g['K_pts_sample']).max() <= 1e-12 * scale
+    assert abs(np.linalg.norm(Kp) - float(g['K_pts_fro'])) <= 1e-11 * float(g['K_pts_fro'])
+
+
+def test_pcg_with_permutation_group_matches_reference():
+    """Round 4: the reference's Iterative.solve with P = 6 (N = 12, M = 200, k = 40): the oracle reproduces the K_nm it
+    assembled for its inducing columns and, preconditioned with them, its residual history and iteration count."""
+    g = load('pcg_n12_p6_m200')
+    M, N, xd, gd, tp, lin = setup_case(g)
+    sig, lam, y, idx = float(g['sig']), float(g['lam']), g['y'], g['inducing_pts_idxs']
+    K_nm = orc.assemble_K(xd, gd, lin, sig, col_idxs=idx)
+    assert np.abs(K_nm[g['K_nm_rows']] - g['K_nm_sample']).max() <= 1e-12 * float(g['K_nm_absmax'])
+    assert abs(np.linalg.norm(K_nm) - float(g['K_nm_fro'])) <= 1e-11 * float(g['K_nm_fro'])
+    fac = orc.nystroem_factor(xd, gd, lin, sig, lam, idx)
+    r_hist = []
+    x, info, iters, resid = orc.pcg(lambda v: -orc.kernel_matvec(xd, gd, tp, sig, lam, v), y,
+                                    M_mv=lambda r: (r_hist.append(np.linalg.norm(r)), orc.precon_apply(fac, lam, r))[1],
+                                    rtol=1e-4, maxiter=5000)
+    assert info == 0
+    n_ref = int(g['n_iters'])
+    assert abs(iters - n_ref) <= max(2, n_ref // 10), (iters, n_ref)
+    ours, ref = np.array(r_hist[1:] + [resid]), g['resid_hist']
+    np.testing.assert_allclose(ours[:8], ref[:8], rtol=1e-6)
+    assert_same_convergence(ours, ref, np.linalg.norm(y))

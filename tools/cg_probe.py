@@ -30,7 +30,7 @@ def run(N, M, k_ind, sig=20.0, tol=1e-4):
     it._init_kernel_operator(task, xd, gd, lin, 1e-10, n)
     hist = []
     t3 = time.time()
-    x, info, iters, resid = ctx.pcg(1e-10, False, y, rtol=tol, maxiter=3000, callback=lambda i, r, xk: hist.append(r) or False, cb_every=25)
+    x, info, iters, resid = ctx.pcg(1e-10, False, y, rtol=tol, maxiter=3000, callback=lambda i, r, fetch_x: hist.append(r) or False, cb_every=25)
     t4 = time.time()
     pcg_ms = ctx.phase_ms('pcg')[0]
     print('N=%d M=%d n=%d k=%d: lev %.2fs, precon build %.2fs (assemble %.0f ms, factor %.0f ms), pcg %d iters info=%d in %.2fs (%.1f ms/iter) resid/|y| %.2e' % (

@@ -5,6 +5,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import bench
 from sgdml_amd import _lib
 
+if os.environ.get('GDML_HIP_LIB'):  # an older build of the library (before/after traces): bind only what it exports
+    import ctypes
+    _old = ctypes.CDLL(os.environ['GDML_HIP_LIB'])
+    for _name in list(_lib.SIGNATURES):
+        if not hasattr(_old, _name):
+            del _lib.SIGNATURES[_name]
+
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ctx = _lib.Context(0)
 wl = bench.make_cg_workload(ctx, 21, 5000, 200, 20.0, 1e-10)
