@@ -69,6 +69,14 @@ int gdml_sync(gdml_ctx* ctx);
 /* Device memory currently held by the context, and free/total HBM of its device (bytes). */
 int gdml_mem_info(gdml_ctx* ctx, int64_t* held, int64_t* free_b, int64_t* total_b);
 
+/* Process-level device arena: reserve ONE block of `bytes` on the context's device and keep it until the process ends
+ * (or until gdml_mem_reserve(ctx, 0, ...)).  The large buffers of any context on that device -- the kernel matrix, the
+ * Nystroem matrix -- are carved from it instead of hipMalloc / hipFree, which cost seconds per call beyond ~128 GB on this
+ * driver; the block survives gdml_ctx_destroy.  One large buffer at a time; a request that does not fit, or arrives while the
+ * block is taken, goes to hipMalloc.  gdml_mem_info counts the idle part of the arena as free.  reserved_out: bytes now held.
+ * (The reference sizes its work to host RAM, sgdml/train.py:949-964; there is nothing to mirror here.) */
+int gdml_mem_reserve(gdml_ctx* ctx, int64_t bytes, int64_t* reserved_out);
+
 /* Elapsed milliseconds (HIP events on the compute stream) of the most recent call of the
  * named phase: "desc", "assemble", "factor", "solve", "predict", "matvec", "precon".
  * Also returns how many kernel launches the phase issued. */
@@ -85,21 +93,21 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
 /* Tuning / ablation options of a context (all have built-in defaults; nothing here changes results beyond
  * rounding).  Read at the point of use, so a value set between two calls applies to the next call.  The
  * library reads no environment variables except GDML_OPTIONS="key=value,..." (applied at gdml_ctx_create).
- *   asm.wave (1)          register-resident assembly kernel for P = 1, N <= 21 (0: LDS kernel)
+ *   asm.wave (1)          register-resident assembly kernel for P = 1, N <= 21 (0: the general kernel); asm.j_chunk its
+ *                         column points per workgroup
  *   asm.lower (1)         analytic path: assemble only blocks on/below the diagonal, as -K + lam I
  *   asm.strip (1)         64-column-strip assembly kernel (full-line stores) for P = 1, 11 <= N <= 21, all columns
  *   asm.i_chunk (32)      row points walked by one wavefront of the strip kernel
  *   asm.pts (1; 2 = also for P = 1) small molecules (8 <= N <= 24) with a permutation group: whole-point strips, producer / consumer
  *                         wavefronts (csrc/assemble_pts.hip); asm.pts_nv (0 = automatic) producer wavefronts, asm.pts_nt (1) non-temporal stores of K, asm.pts_xcd (1) adjacent strips on one XCD, asm.pts_i_chunk (64)
  *                         row points per workgroup, asm.pts_debug (0) timing-only ablation mask (results are wrong when set)
- *   asm.perm (1)          general assembly kernel (any permutation group, any N): column-atom strips (0: the LDS kernel, N <= 64)
+ *   general assembly kernel (any permutation group, any N: column-atom strips, csrc/assemble_perm.hip):
  *   asm.perm_level (-1 = automatic: 0 nothing, 1 row-point image, 2 + G_j strip, 3 + x_j tables resident in LDS),
  *   asm.perm_debug (0)    timing-only ablation mask of that kernel (results are wrong when set)
  *   asm.perm_w (0 = automatic: 4 wavefronts per workgroup for N <= 24, else 8), asm.perm_lds_kb (80: per workgroup of 4),
  *   asm.perm_nimg (0 = automatic), asm.perm_pg (0 = automatic), asm.perm_na (0 = automatic), asm.perm_fast_store (1),
  *   asm.perm_i_chunk (16) its shape: image buffers, permutations per group, row atoms per wavefront, transposed
  *                         full-line stores, row points per workgroup
- *   asm.threads, asm.ib, asm.minw, asm.gj_global, asm.j_chunk, asm.debug   LDS-kernel shape / ablations
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
  *   gemm.nt_c (0)         non-temporal loads / stores of the C tile (after rocBLAS's Tensile kernel for this shape:
  *                         profiles/r03_vendor_kernels.txt; no gain measured)
@@ -119,6 +127,9 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   lu.nb (64)            panel width of the LU fallback
  *   comm.force_collectives (0)  issue collectives even for world == 1 without a communicator (tests)
  *   dist.nb (512)         row-block size of the distributed Cholesky (multiple of 128)
+ *   dist.lookahead (0)    distributed Cholesky: 1 = one panel of look-ahead over three streams (block broadcasts on a second
+ *                         communicator); 0 = every step in order on the compute stream.  Off until the three-stream RCCL
+ *                         schedule has run on more than one physical GPU
  *   nys.force_qr (0)      take the alternative (QR-equivalent) branch of the second Nystroem factorisation (tests)
  *   nys.force_fail (0)    treat the first k attempts of the jitter-stabilised Cholesky of K_mm as failed (tests)
  *   pcg.depth (2)         PCG iterations queued ahead of the host's convergence test / callback (0 = synchronous)
@@ -284,6 +295,11 @@ int gdml_pcg_x(gdml_ctx* ctx, double* x_host_out);
 int gdml_comm_unique_id(void* id128_out);
 int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world);
 int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out);
+/* gdml_comm_suspend(ctx, 1) parks the communicator: until gdml_comm_suspend(ctx, 0) the context behaves like a single GPU
+ * without one (rank 0 of 1: unsharded assembly, local Cholesky / LU / PCG, no collective).  For work every rank performs
+ * redundantly on its own GPU because the sharded solvers do not carry it: energy constraints (train.py:235-300) and the LU
+ * branch of a matrix that is not positive definite (analytic.py:101-114). */
+int gdml_comm_suspend(gdml_ctx* ctx, int suspend);
 
 /* Distributed analytic solve (new; Analytic.solve, analytic.py:65-99, for systems beyond one GPU -- BASELINE.json
  * configs[3], [4]): the system matrix A = -K + lam I is assembled block-ROW-cyclic over the ranks of the communicator

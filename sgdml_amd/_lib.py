@@ -27,6 +27,7 @@ SIGNATURES = {
     'gdml_last_error': (C.c_char_p, [_vp]),
     'gdml_sync': (C.c_int, [_vp]),
     'gdml_mem_info': (C.c_int, [_vp, _ip, _ip, _ip]),
+    'gdml_mem_reserve': (C.c_int, [_vp, C.c_int64, _ip]),
     'gdml_phase_ms': (C.c_int, [_vp, C.c_char_p, _dp, _ip]),
     'gdml_profile': (C.c_int, [_vp, C.c_int]),
     'gdml_kernel_stat': (C.c_int, [_vp, C.c_char_p, _dp, _ip, _dp]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     'gdml_comm_unique_id': (C.c_int, [_vp]),
     'gdml_comm_init': (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     'gdml_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'gdml_comm_suspend': (C.c_int, [_vp, C.c_int]),
     'gdml_comm_init_host': (C.c_int, [_vp, C.c_int, C.c_int, HOST_COLL_CB, HOST_COLL_CB, _vp]),
     'gdml_comm_stats': (C.c_int, [_vp, _ip, _dp]),
     'gdml_set_option': (C.c_int, [_vp, C.c_char_p, C.c_double]),
@@ -258,6 +260,21 @@ class Context(object):
         self._check(self._lib.gdml_comm_init_host(self._h, int(rank), int(world), self._coll_cbs[0],
                                                   self._coll_cbs[1], None))
 
+    def comm_suspended(self):
+        """Context manager: inside it this context behaves like a single GPU without a communicator
+        (gdml_comm_suspend) -- for solves every rank performs redundantly."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            self._check(self._lib.gdml_comm_suspend(self._h, 1))
+            try:
+                yield self
+            finally:
+                self._check(self._lib.gdml_comm_suspend(self._h, 0))
+
+        return _cm()
+
     def comm_stats(self):
         """(collectives issued, payload bytes handed to them by this rank)."""
         n, b = C.c_int64(), C.c_double()
@@ -283,6 +300,16 @@ class Context(object):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._lib.gdml_mem_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def mem_reserve(self, n_bytes=None):
+        """Reserve the process-level device arena (gdml_mem_reserve): one block the large matrices of every context on
+        this device are carved from, kept until the process ends.  n_bytes=None: 85 % of the memory that is free right
+        now; 0 releases it.  Returns the bytes held."""
+        if n_bytes is None:
+            n_bytes = int(0.85 * self.mem_info()[1]) // 2**30 * 2**30
+        got = C.c_int64()
+        self._check(self._lib.gdml_mem_reserve(self._h, int(n_bytes), C.byref(got)))
+        return got.value
 
     def phase_ms(self, name):
         ms, n = C.c_double(), C.c_int64()

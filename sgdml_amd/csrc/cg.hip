@@ -32,44 +32,138 @@ __global__ void __launch_bounds__(256) add_diag_kernel(double* __restrict__ A, i
 }
 
 // ------------------------------------------------------------------------------------------
-// C[m x m] (lower tiles) = X^T X, X is n x m row-major (K dimension = rows of X).  fp64 MFMA,
-// 128 x 128 tiles, BK = 16, LDS layout [k][128+16] (the operand read lane -> (i = l&15, k = l>>4)
-// touches 16 consecutive doubles per k: conflict-free), global loads are full 1 KiB rows.
+// C[m x m] (lower tiles) = X^T X, X is n x m row-major (the contraction runs over the ROWS of X: K_nm^T K_nm of the
+// Nystroem factor, iterative.py:293, and the Gram matrices of the CholeskyQR branch).  fp64 MFMA, 128 x 128 tiles, 16
+// rows of X per k-tile, double-buffered LDS.
+//
+// Both operand tiles of a k-tile are 16 x 128 blocks of X with contiguous rows, so everything moves in 16-byte pieces:
+// one check-free global_load_dwordx4 per chunk from a wave-uniform base (tile corner + k offset in SGPRs) plus the
+// thread's constant byte offset, one ds_write_b128 per chunk into an unpadded [k][128] image, and one ds_read_b128 per
+// PAIR of MFMA operand blocks: the 16 x 16 operand blocks of a wave's 64 tile columns are taken as column pairs
+// (block 2 h + e, lane index x  <->  tile column 32 h + 2 x + e), so that a lane's two operands of blocks 2h, 2h + 1 are
+// adjacent in LDS and the 8 lanes an LDS cycle serves read 128 contiguous bytes (no bank conflict, no padding).  The
+// relabelling only changes which tile column an accumulator belongs to (undone in the epilogue).  Tiles that reach past
+// m and the last, partial k-tile take guarded loads.  Round 3's kernel (8-byte bounds-checked loads inside the k loop,
+// 8-byte LDS layout, 222 VGPRs) ran at 0.73 of the fp64-MFMA peak.
 // ------------------------------------------------------------------------------------------
 #define TT 128
 #define TBK 16
-#define TP 144
 
-__device__ __forceinline__ void tn_load(const double* __restrict__ X, int64_t ld, int64_t n, int64_t m,
-                                        int64_t k0, int64_t c0, int tid, d2 (&r)[4]) {
-  // 16 rows x 128 cols = 1024 chunks of 2 doubles: chunk c -> row c/64, col pair c%64
+typedef const __attribute__((address_space(1))) char* tn_gcptr;
+typedef const __attribute__((address_space(1))) d2* tn_gd2ptr;
+
+template <bool FULL>
+__device__ __forceinline__ void tn_load(const double* __restrict__ X, int64_t ld, int64_t n, int64_t m, int64_t k0, int64_t c0,
+                                        int tid, const unsigned (&off)[4], d2 (&r)[4]) {
+  if (FULL) {  // interior tile, whole k-tile: wave-uniform base + 32-bit lane offsets
+    const uint64_t p = reinterpret_cast<uint64_t>(X + k0 * ld + c0);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    tn_gcptr b = (tn_gcptr)(((uint64_t)hi << 32) | lo);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int cidx = tid + 256 * s;
-    const int kr = cidx >> 6, cc = (cidx & 63) * 2;
-    const int64_t gk = k0 + kr, gc = c0 + cc;
-    d2 v = {0.0, 0.0};
-    if (gk < n) {
-      if (gc < m) v.x = X[gk * ld + gc];
-      if (gc + 1 < m) v.y = X[gk * ld + gc + 1];
+    for (int s = 0; s < 4; ++s) r[s] = *(tn_gd2ptr)(b + off[s]);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int cidx = tid + 256 * s;
+      const int kr = cidx >> 6, cc = (cidx & 63) * 2;
+      const int64_t gk = k0 + kr, gc = c0 + cc;
+      d2 v = {0.0, 0.0};
+      if (gk < n) {
+        if (gc < m) v.x = X[gk * ld + gc];
+        if (gc + 1 < m) v.y = X[gk * ld + gc + 1];
+      }
+      r[s] = v;
     }
-    r[s] = v;
   }
 }
 __device__ __forceinline__ void tn_store(double* __restrict__ S, int tid, const d2 (&r)[4]) {
+  d2* S2 = reinterpret_cast<d2*>(S);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) S2[tid + 256 * s] = r[s];  // chunk (kr, cc) sits at doubles kr * 128 + cc = 2 * cidx
+}
+
+template <bool FULL>
+__device__ __forceinline__ void syrk_tn_tile(const double* __restrict__ X, int64_t ldx, int64_t n, int64_t m,
+                                             double* __restrict__ C, int64_t ldc, int64_t row0, int64_t col0,
+                                             double (*lds)[2][TBK * TT]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lk = lane >> 4;
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  unsigned off[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int cidx = tid + 256 * s;
-    const int kr = cidx >> 6, cc = (cidx & 63) * 2;
-    S[kr * TP + cc] = r[s].x;
-    S[kr * TP + cc + 1] = r[s].y;
+    off[s] = (unsigned)(((int64_t)(cidx >> 6) * ldx + (cidx & 63) * 2) * 8);
   }
+  const int64_t nk_full = FULL ? n / TBK : 0;          // k-tiles loaded without checks
+  const int64_t nk = (n + TBK - 1) / TBK;
+  d2 ra[4], rb[4];
+  if (nk_full > 0) {
+    tn_load<true>(X, ldx, n, m, 0, row0, tid, off, ra);
+    tn_load<true>(X, ldx, n, m, 0, col0, tid, off, rb);
+  } else {
+    tn_load<false>(X, ldx, n, m, 0, row0, tid, off, ra);
+    tn_load<false>(X, ldx, n, m, 0, col0, tid, off, rb);
+  }
+  tn_store(lds[0][0], tid, ra);
+  tn_store(lds[0][1], tid, rb);
+  __syncthreads();
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    if (kt + 1 < nk) {
+      if (kt + 1 < nk_full) {
+        tn_load<true>(X, ldx, n, m, (kt + 1) * TBK, row0, tid, off, ra);
+        tn_load<true>(X, ldx, n, m, (kt + 1) * TBK, col0, tid, off, rb);
+      } else {
+        tn_load<false>(X, ldx, n, m, (kt + 1) * TBK, row0, tid, off, ra);
+        tn_load<false>(X, ldx, n, m, (kt + 1) * TBK, col0, tid, off, rb);
+      }
+    }
+    // operand pairs: d2 index of (k, column 32 h + 2 li) inside the wave's 64 columns
+    const d2* Ap = reinterpret_cast<const d2*>(lds[cur][0]) + lk * (TT / 2) + wm * 32 + li;
+    const d2* Bp = reinterpret_cast<const d2*>(lds[cur][1]) + lk * (TT / 2) + wn * 32 + li;
+#pragma unroll
+    for (int ks = 0; ks < TBK; ks += 4) {
+      const d2 a01 = Ap[ks * (TT / 2)], a23 = Ap[ks * (TT / 2) + 16];
+      const d2 b01 = Bp[ks * (TT / 2)], b23 = Bp[ks * (TT / 2) + 16];
+      const double a[4] = {a01.x, a01.y, a23.x, a23.y};
+      const double bb[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+      if (ks == 8 && kt + 1 < nk) {  // the next tile's loads were issued 48 MFMAs ago
+        tn_store(lds[cur ^ 1][0], tid, ra);
+        tn_store(lds[cur ^ 1][1], tid, rb);
+      }
+    }
+    __syncthreads();
+  }
+  // epilogue: accumulator (i, j), register r of lane (li, lk) is tile element
+  //   row = 64 wm + 32 (i >> 1) + 2 (lk + 4 r) + (i & 1),  column = 64 wn + 32 (j >> 1) + 2 li + (j & 1)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t gc = col0 + wn * 64 + 32 * (j >> 1) + 2 * li + (j & 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gr = row0 + wm * 64 + 32 * (i >> 1) + 2 * (lk + 4 * r) + (i & 1);
+        if (FULL || (gr < m && gc < m)) C[gr * ldc + gc] = acc[i][j][r];
+      }
+    }
 }
 
 __global__ void __launch_bounds__(256, 2) syrk_tn_kernel(const double* __restrict__ X, int64_t ldx,
                                                          int64_t n, int64_t m, double* __restrict__ C,
                                                          int64_t ldc, int tiles) {
-  __shared__ __attribute__((aligned(16))) double lds[2][2][TBK * TP];
+  __shared__ __attribute__((aligned(16))) double lds[2][2][TBK * TT];
   // linear block id -> lower-triangular tile (ti >= tj)
   const int64_t b = blockIdx.x;
   int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
@@ -78,61 +172,11 @@ __global__ void __launch_bounds__(256, 2) syrk_tn_kernel(const double* __restric
   const int64_t tj = b - ti * (ti + 1) / 2;
   if (ti >= tiles) return;
   const int64_t row0 = ti * TT, col0 = tj * TT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 15, lk = lane >> 4;
-
-  d4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  const int64_t nk = (n + TBK - 1) / TBK;
-  d2 ra[4], rb[4];
-  tn_load(X, ldx, n, m, 0, row0, tid, ra);
-  tn_load(X, ldx, n, m, 0, col0, tid, rb);
-  tn_store(lds[0][0], tid, ra);
-  tn_store(lds[0][1], tid, rb);
-  __syncthreads();
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    if (kt + 1 < nk) {
-      tn_load(X, ldx, n, m, (kt + 1) * TBK, row0, tid, ra);
-      tn_load(X, ldx, n, m, (kt + 1) * TBK, col0, tid, rb);
-    }
-    const double* As = lds[cur][0] + lk * TP + wm * 64 + li;
-    const double* Bs = lds[cur][1] + lk * TP + wn * 64 + li;
-#pragma unroll
-    for (int ks = 0; ks < TBK; ks += 4) {
-      double a[4], bb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[ks * TP + i * 16];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bb[j] = Bs[ks * TP + j * 16];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      tn_store(lds[cur ^ 1][0], tid, ra);
-      tn_store(lds[cur ^ 1][1], tid, rb);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t gc = col0 + wn * 64 + j * 16 + li;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
-        if (gr < m && gc < m) C[gr * ldc + gc] = acc[i][j][r];
-      }
-    }
+  const bool aligned = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx % 2 == 0);
+  if (aligned && row0 + TT <= m && col0 + TT <= m && 16 * ldx * 8 < ((int64_t)1 << 32))
+    syrk_tn_tile<true>(X, ldx, n, m, C, ldc, row0, col0, lds);
+  else
+    syrk_tn_tile<false>(X, ldx, n, m, C, ldc, row0, col0, lds);
 }
 
 // out[r] = sum_c X[r][c]^2   (leverage scores, iterative.py:107-109)

@@ -20,6 +20,7 @@ struct RcclApi {
   ncclResult_t_ (*CommInitRank)(ncclComm_t_*, int, ncclUniqueId_, int) = nullptr;
   ncclResult_t_ (*CommDestroy)(ncclComm_t_) = nullptr;
   ncclResult_t_ (*CommAbort)(ncclComm_t_) = nullptr;
+  ncclResult_t_ (*CommSplit)(ncclComm_t_, int, int, ncclComm_t_*, void*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t_) = nullptr;
   ncclResult_t_ (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
   ncclResult_t_ (*AllGather)(const void*, void*, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
@@ -47,6 +48,7 @@ static bool rccl_load(std::string* err) {
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
   a.CommAbort = (decltype(a.CommAbort))dlsym(h, "ncclCommAbort");  // optional: comm_abort falls back to destroy
+  a.CommSplit = (decltype(a.CommSplit))dlsym(h, "ncclCommSplit");  // optional: without it comm2 = comm
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
   a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
@@ -79,7 +81,7 @@ extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int wo
   if (!ctx) return GDML_ERR_INVALID;
   if (world < 1 || rank < 0 || rank >= world)
     return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_comm_init: rank %d / world %d", rank, world);
-  if (ctx->comm || ctx->host_allreduce)
+  if (ctx->comm || ctx->host_allreduce || ctx->parked.on)
     return gdml_fail(ctx, GDML_ERR_STATE, "gdml_comm_init: communicator already initialised");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (id128 == nullptr) {
@@ -98,6 +100,11 @@ extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int wo
   ncclResult_t_ r = g_rccl.CommInitRank(&comm, world, id, rank);
   if (r != 0) return rccl_fail(ctx, "ncclCommInitRank", r);
   ctx->comm = comm;
+  ctx->comm2 = nullptr;
+  if (world > 1 && g_rccl.CommSplit) {  // same ranks, same order: a second, independent channel
+    ncclComm_t_ c2 = nullptr;
+    if (g_rccl.CommSplit(comm, 0, rank, &c2, nullptr) == 0) ctx->comm2 = c2;
+  }
   ctx->comm_aborted = false;
   ctx->rank = rank;
   ctx->world = world;
@@ -108,17 +115,45 @@ extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int wo
 }
 
 void comm_destroy(gdml_ctx* ctx) {
+  if (ctx->parked.on) (void)gdml_comm_suspend(ctx, 0);
+  if (ctx->comm2 && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t_)ctx->comm2);
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t_)ctx->comm);
-  ctx->comm = nullptr;
+  ctx->comm = ctx->comm2 = nullptr;
+}
+
+// Park / restore the communicator: while suspended the context behaves like a single GPU without a communicator (every
+// entry point: unsharded assembly, local solves, no collective).  For work every rank does redundantly -- energy
+// constraints and the LU fallback, which the sharded solvers do not carry (sgdml/train.py:235-300, analytic.py:101-114).
+extern "C" int gdml_comm_suspend(gdml_ctx* ctx, int suspend) {
+  if (!ctx) return GDML_ERR_INVALID;
+  if (suspend && !ctx->parked.on) {
+    ctx->parked.on = true;
+    ctx->parked.comm = ctx->comm; ctx->parked.comm2 = ctx->comm2;
+    ctx->parked.rank = ctx->rank; ctx->parked.world = ctx->world;
+    ctx->parked.virtual_rank = ctx->virtual_rank;
+    ctx->parked.ar = ctx->host_allreduce; ctx->parked.ag = ctx->host_allgather;
+    ctx->comm = ctx->comm2 = nullptr;
+    ctx->rank = 0; ctx->world = 1;
+    ctx->virtual_rank = false;
+    ctx->host_allreduce = nullptr; ctx->host_allgather = nullptr;
+  } else if (!suspend && ctx->parked.on) {
+    ctx->comm = ctx->parked.comm; ctx->comm2 = ctx->parked.comm2;
+    ctx->rank = ctx->parked.rank; ctx->world = ctx->parked.world;
+    ctx->virtual_rank = ctx->parked.virtual_rank;
+    ctx->host_allreduce = ctx->parked.ar; ctx->host_allgather = ctx->parked.ag;
+    ctx->parked.on = false;
+  }
+  return GDML_OK;
 }
 
 void comm_abort(gdml_ctx* ctx) {
   if (!comm_active(ctx) || ctx->world <= 1) return;
-  if (ctx->comm) {
-    if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t_)ctx->comm);
-    else if (g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t_)ctx->comm);
-    ctx->comm = nullptr;
-  }
+  for (void** c : {&ctx->comm2, &ctx->comm})
+    if (*c) {
+      if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t_)*c);
+      else if (g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t_)*c);
+      *c = nullptr;
+    }
   ctx->comm_aborted = true;  // (host-staged backend: the peers' gloo collective times out on its own)
 }
 
@@ -236,7 +271,7 @@ int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count) {
 
 // buf (count doubles) of rank `root` to every rank, on stream st.  RCCL: ncclBroadcast.  Host-staged backend (two
 // callbacks only: all-reduce, all-gather): the other ranks contribute zeros to an all-reduce.
-int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipStream_t st) {
+int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipStream_t st, bool second_comm) {
   if (ctx->virtual_rank) return GDML_OK;
   if (ctx->comm_aborted) return gdml_fail(ctx, GDML_ERR_COMM, "the communicator was aborted after a local failure on this rank");
   if (ctx->host_allreduce) {
@@ -253,7 +288,8 @@ int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipSt
     if (ctx->rank != root) HIP_CHECK(ctx, hipMemcpyAsync(buf, ctx->h_coll, count * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(ctx, hipStreamSynchronize(st));
   } else if (ctx->comm) {
-    ncclResult_t_ r = g_rccl.Broadcast(buf, buf, (size_t)count, kNcclDouble, root, (ncclComm_t_)ctx->comm, st);
+    void* cm = (second_comm && ctx->comm2) ? ctx->comm2 : ctx->comm;
+    ncclResult_t_ r = g_rccl.Broadcast(buf, buf, (size_t)count, kNcclDouble, root, (ncclComm_t_)cm, st);
     if (r != 0) return rccl_fail(ctx, "ncclBroadcast", r);
   } else {
     return GDML_OK;

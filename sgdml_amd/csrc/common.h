@@ -110,7 +110,18 @@ struct gdml_ctx {
 
   // comm
   void* comm = nullptr;  // ncclComm_t
+  void* comm2 = nullptr; // second communicator over the same ranks (ncclCommSplit): latency-critical small broadcasts of the
+                         // distributed Cholesky, so that they do not queue behind the panel all-gather on `comm`
   int rank = 0, world = 1;
+  // gdml_comm_suspend: the communicator parked here while the context acts as a single GPU (redundant solves)
+  struct {
+    bool on = false;
+    void *comm = nullptr, *comm2 = nullptr;
+    int rank = 0, world = 1;
+    bool virtual_rank = false;
+    gdml_host_allreduce ar = nullptr;
+    gdml_host_allgather ag = nullptr;
+  } parked;
   bool virtual_rank = false;   // shard arithmetic only, collectives skipped (tests)
   gdml_host_allreduce host_allreduce = nullptr;  // host-staged collectives (gdml_comm_init_host)
   bool comm_aborted = false;  // comm_abort() ran: every later collective fails instead of acting like a single rank
@@ -208,7 +219,7 @@ void shard_points(const gdml_ctx* ctx, int64_t M, int64_t* p0, int64_t* p1, int6
 int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk);
 int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count);
 int comm_allgather_inplace_on(gdml_ctx* ctx, double* buf, int64_t chunk, hipStream_t st);
-int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipStream_t st);
+int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipStream_t st, bool second_comm = false);
 void comm_destroy(gdml_ctx* ctx);
 // A rank that fails locally between collectives (a launch error in a panel loop) must not leave its peers blocked in
 // the collective it will never join: RCCL communicators are aborted (ncclCommAbort: the peers' pending and later

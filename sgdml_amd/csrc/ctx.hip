@@ -26,12 +26,12 @@ extern "C" int gdml_abi_version(void) { return 3; }
 // environment variable the library looks at is GDML_OPTIONS="key=value,key=value", applied once when
 // a context is created (lab convenience for the probes under tools/).
 static const char* kKnownOptions[] = {
-    "asm.wave", "asm.threads", "asm.ib", "asm.minw", "asm.gj_global", "asm.j_chunk", "asm.debug", "asm.lower", "asm.strip", "asm.i_chunk",
-    "asm.pts", "asm.pts_nv", "asm.pts_nt", "asm.pts_xcd", "asm.pts_i_chunk", "asm.pts_debug", "asm.perm", "asm.perm_debug", "asm.perm_w", "asm.perm_lds_kb", "asm.perm_level", "asm.perm_nimg", "asm.perm_pg", "asm.perm_na", "asm.perm_fast_store", "asm.perm_i_chunk",
+    "asm.wave", "asm.j_chunk", "asm.lower", "asm.strip", "asm.i_chunk",
+    "asm.pts", "asm.pts_nv", "asm.pts_nt", "asm.pts_xcd", "asm.pts_i_chunk", "asm.pts_debug", "asm.perm_debug", "asm.perm_w", "asm.perm_lds_kb", "asm.perm_level", "asm.perm_nimg", "asm.perm_pg", "asm.perm_na", "asm.perm_fast_store", "asm.perm_i_chunk",
     "gemm.debug", "gemm.nt_c", "gemm.lds16", "gemm.cacc", "gemm.commit_ks", "chol.nb", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
     "chol.fused_min_rows", "chol.outer", "chol.outer_min_rows", "chol.merge_gemm1", "chol.tail_lookahead", "trsm.debug",
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
-    "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb", "pcg.depth"};
+    "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb", "dist.lookahead", "pcg.depth"};
 
 double ctx_opt(const gdml_ctx* ctx, const char* key, double dflt) {
   auto it = ctx->opts.find(key);
@@ -68,6 +68,32 @@ static void options_from_env(gdml_ctx* ctx) {
     const size_t eq = kv.find('=');
     if (eq != std::string::npos) (void)gdml_set_option(ctx, kv.substr(0, eq).c_str(), atof(kv.c_str() + eq + 1));
     pos = end + 1;
+  }
+}
+
+// ---- process-level device arena (gdml_mem_reserve) ------------------------------------------------------------------
+// hipMalloc of the large kernel matrices costs seconds on this driver once a request passes what the runtime has at hand
+// (3.5-6.5 s for 128-200 GB, erratic below: profiles/r03_malloc_probe.txt, r04_malloc_probe.txt -- hipMallocAsync pools and
+// hipMemCreate / hipMemMap pay the same per byte), and hipFree gives it back.  A long-lived process therefore reserves
+// ONE block per device once and keeps it: the context's large buffers (in practice the kernel matrix / the Nystroem
+// matrix) are carved from it, a buffer handed back is not freed, and the block survives contexts.  One tenant at a time:
+// a second large request while the arena is taken falls through to hipMalloc.
+struct DeviceArena {
+  void* base = nullptr;
+  int64_t bytes = 0;
+  gdml_ctx* owner = nullptr;  // context holding the block, or null
+  int64_t used = 0;
+};
+static DeviceArena g_arena[64];
+static const int64_t kArenaMinRequest = (int64_t)1 << 30;  // smaller buffers are cheap to allocate: hipMalloc
+
+static DeviceArena* arena_of(const gdml_ctx* ctx) { return (ctx->device >= 0 && ctx->device < 64) ? &g_arena[ctx->device] : nullptr; }
+
+static void arena_release_owner(gdml_ctx* ctx) {
+  DeviceArena* a = arena_of(ctx);
+  if (a && a->owner == ctx) {
+    a->owner = nullptr;
+    a->used = 0;
   }
 }
 
@@ -142,8 +168,13 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
     hipEventDestroy(t.e1);
   }
   for (auto e : ctx->event_pool) hipEventDestroy(e);
-  for (auto& kv : ctx->allocs) hipFree(kv.first);
-  ctx->allocs.clear();
+  {
+    DeviceArena* a = arena_of(ctx);
+    for (auto& kv : ctx->allocs)
+      if (!(a && a->base == kv.first && a->owner == ctx)) hipFree(kv.first);
+    ctx->allocs.clear();
+    arena_release_owner(ctx);  // the block itself stays with the process
+  }
   if (ctx->d_info) hipFree(ctx->d_info);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -175,8 +206,41 @@ extern "C" int gdml_mem_info(gdml_ctx* ctx, int64_t* held, int64_t* free_b, int6
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   HIP_CHECK(ctx, hipMemGetInfo(&f, &t));
   if (held) *held = ctx->held;
+  // what a large buffer of THIS context could get: driver-free memory plus the part of the process arena nobody uses
+  // (the context's own resident matrix is re-used in place by the next assembly: callers add it themselves)
+  {
+    const DeviceArena* a = arena_of(ctx);
+    if (a && a->base && (a->owner == nullptr || a->owner == ctx)) f += (size_t)(a->bytes - a->used);
+  }
   if (free_b) *free_b = (int64_t)f;
   if (total_b) *total_b = (int64_t)t;
+  return GDML_OK;
+}
+
+extern "C" int gdml_mem_reserve(gdml_ctx* ctx, int64_t bytes, int64_t* reserved_out) {
+  if (!ctx) return GDML_ERR_INVALID;
+  DeviceArena* a = arena_of(ctx);
+  if (!a) return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_mem_reserve: device index out of range");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (bytes != a->bytes || bytes == 0) {
+    if (a->owner) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_mem_reserve: the arena is in use (a context holds its kernel matrix)");
+    if (a->base) {
+      HIP_CHECK(ctx, hipFree(a->base));
+      a->base = nullptr;
+      a->bytes = 0;
+    }
+    if (bytes > 0) {
+      void* p = nullptr;
+      hipError_t e = hipMalloc(&p, (size_t)bytes);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return gdml_fail(ctx, GDML_ERR_OOM, "gdml_mem_reserve: hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
+      }
+      a->base = p;
+      a->bytes = bytes;
+    }
+  }
+  if (reserved_out) *reserved_out = a->bytes;
   return GDML_OK;
 }
 
@@ -184,7 +248,24 @@ int ctx_alloc(gdml_ctx* ctx, void** p, int64_t bytes) {
   *p = nullptr;
   if (bytes <= 0) bytes = 8;
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  DeviceArena* a = arena_of(ctx);
+  if (a && a->base && !a->owner && bytes >= kArenaMinRequest && bytes <= a->bytes) {
+    a->owner = ctx;
+    a->used = bytes;
+    *p = a->base;
+    ctx->allocs[*p] = bytes;
+    ctx->held += bytes;
+    return GDML_OK;
+  }
   hipError_t e = hipMalloc(p, (size_t)bytes);
+  if (e == hipErrorOutOfMemory && a && a->base && !a->owner) {
+    // an idle arena must not be the reason a larger request fails: give it back and try once more
+    (void)hipGetLastError();
+    (void)hipFree(a->base);
+    a->base = nullptr;
+    a->bytes = 0;
+    e = hipMalloc(p, (size_t)bytes);
+  }
   if (e != hipSuccess) {
     *p = nullptr;
     (void)hipGetLastError();
@@ -203,6 +284,11 @@ int ctx_free(gdml_ctx* ctx, void* p) {
   HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->held -= it->second;
   ctx->allocs.erase(it);
+  DeviceArena* a = arena_of(ctx);
+  if (a && a->base == p && a->owner == ctx) {  // back to the arena, not to the driver
+    arena_release_owner(ctx);
+    return GDML_OK;
+  }
   HIP_CHECK(ctx, hipFree(p));
   return GDML_OK;
 }

@@ -12,7 +12,8 @@
 // row-cyclic mode for everything else), so the matrix never exists in one place:
 // n^2 * 8 / W bytes per GPU.  Cyclic ownership balances the lower-triangular work (row b has b blocks).
 //
-// Per panel k (right-looking, one panel of look-ahead, three streams):
+// Per panel k (right-looking; with option dist.lookahead = 1 one panel of look-ahead over three streams, by default the
+// same steps in order on one stream):
 //   critical stream   1. every rank solves ITS rows of the panel: X <- X L_kk^-T          (panel_trsm_kernel, local)
 //                     2. owner(k+1) sends its solved rows of block k+1 to every rank   2 MB    ncclBroadcast
 //                     3. every rank updates the NEXT panel's columns of its rows          (K = 512 GEMM, 512 columns)
@@ -169,23 +170,33 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
     HIP_CHECK(ctx, hipStreamSynchronize(st));  // y is the caller's pageable array
     HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), st));
 
-    // ---- factorisation, one panel of look-ahead over three streams:
+    // ---- factorisation.  Option dist.lookahead = 1: one panel of look-ahead over three streams:
     //   sa (critical path)  panel solve k -> broadcast of the solved rows of block k+1 -> update of the NEXT panel's columns
-    //                       -> owner(k+1) factors diagonal block k+1 -> broadcast of it
+    //                       -> owner(k+1) factors diagonal block k+1 -> broadcast of it   (broadcasts: second communicator)
     //   sn (collective)     pack + all-gather + unpack of the whole panel k            (under the bulk update of panel k-1)
     //   sb (bulk)           update of the columns right of block k+1 by panel k         (under the critical path of k+1)
-    // All collectives are issued from this one host thread in the same order on every rank (RCCL's requirement for one
-    // communicator used from several streams); the host-staged backend runs them synchronously, same results.
+    // Default (dist.lookahead = 0): the same steps in the same order on ONE stream and one communicator -- the schedule
+    // that needs nothing from RCCL beyond in-order execution.  The three-stream schedule issues collectives of two
+    // communicators from two streams (always from this one host thread, in the same order on every rank); it has run with
+    // one rank and with host-staged collectives only, so it stays opt-in until it has run on several physical GPUs.
     phase_begin(ctx);
     HIP_CHECK(ctx, hipStreamSynchronize(st));  // assembly, right-hand side, info slot: visible to the other streams
-    hipStream_t sa = ctx->stream2, sb = st, sn = nullptr;  // stream2 is the high-priority one
-    HIP_CHECK(ctx, hipStreamCreateWithFlags(&sn, hipStreamNonBlocking));
+    const bool la = ctx_opt_i(ctx, "dist.lookahead", 0) != 0;
+    hipStream_t sa = la ? ctx->stream2 : st, sb = st, sn = st;  // stream2 is the high-priority one
+    hipStream_t sn_own = nullptr;
     hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_p[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
-    for (int e = 0; e < 2; ++e) {
-      HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_x[e], hipEventDisableTiming));
-      HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_p[e], hipEventDisableTiming));
-      HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_b[e], hipEventDisableTiming));
-    }
+    auto setup = [&]() -> int {  // a failure here must reach comm_abort below: the peers are about to enter a broadcast
+      if (la) {
+        HIP_CHECK(ctx, hipStreamCreateWithFlags(&sn_own, hipStreamNonBlocking));
+        sn = sn_own;
+      }
+      for (int e = 0; e < 2; ++e) {
+        HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_x[e], hipEventDisableTiming));
+        HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_p[e], hipEventDisableTiming));
+        HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_b[e], hipEventDisableTiming));
+      }
+      return GDML_OK;
+    };
     bool have_b[2] = {false, false};
     auto factor_and_bcast = [&](int64_t k) -> int {  // diagonal block k: owner factors, everybody gets it (Lbuf)
       const int64_t k0 = k * nb, w = c.rows_of(k);
@@ -198,7 +209,7 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
         hipLaunchKernelGGL(pack_diag_kernel, dim3(ceil_div(nb * nb, 256)), dim3(256), 0, sa, A + lr0 * ld + k0, ld, (int)w,
                            (int)nb, Lbuf, ctx->d_info);
       }
-      return comm_broadcast_on(ctx, Lbuf, nb * nb + 1, owner, sa);
+      return comm_broadcast_on(ctx, Lbuf, nb * nb + 1, owner, sa, la);
     };
     auto loop = [&]() -> int {
       GDML_TRY(factor_and_bcast(0));
@@ -231,7 +242,7 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
         // ---- sa: solved rows of block k+1 to everybody (they are the first rows below the panel on their owner)
         if (owner1 == c.rank)
           hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(w1 * nb, 256)), dim3(256), 0, sa, X, ld, w1, (int)w, (int)nb, Pn);
-        GDML_TRY(comm_broadcast_on(ctx, Pn, nb * nb, owner1, sa));
+        GDML_TRY(comm_broadcast_on(ctx, Pn, nb * nb, owner1, sa, la));
         // ---- sn: the whole panel (block rows only; the rhs row is nobody's column)
         int64_t m_pad = 0;
         for (int r = 0; r < c.W; ++r) {
@@ -270,16 +281,17 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
       }
       return GDML_OK;
     };
-    const int rc_loop = loop();
+    int rc_loop = setup();
+    if (rc_loop == GDML_OK) rc_loop = loop();
     (void)hipStreamSynchronize(sn);
     (void)hipStreamSynchronize(sb);
     (void)hipStreamSynchronize(sa);
     for (int e = 0; e < 2; ++e) {
-      (void)hipEventDestroy(ev_x[e]);
-      (void)hipEventDestroy(ev_p[e]);
-      (void)hipEventDestroy(ev_b[e]);
+      if (ev_x[e]) (void)hipEventDestroy(ev_x[e]);
+      if (ev_p[e]) (void)hipEventDestroy(ev_p[e]);
+      if (ev_b[e]) (void)hipEventDestroy(ev_b[e]);
     }
-    (void)hipStreamDestroy(sn);
+    if (sn_own) (void)hipStreamDestroy(sn_own);
     if (rc_loop != GDML_OK) comm_abort(ctx);  // the peers are (or will be) inside a collective this rank never joins
     GDML_TRY(rc_loop);
     GDML_TRY(phase_end(ctx, "factor"));

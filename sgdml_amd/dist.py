@@ -28,8 +28,12 @@ def pick_backend(device, group=None):
 
     from . import _lib
 
+    import socket
+
     ids = [None] * dist.get_world_size(group)
-    dist.all_gather_object(ids, _lib.device_pci_bus_id(device), group=group)
+    bus = _lib.device_pci_bus_id(device)
+    # bus ids repeat from node to node: a GPU is (host, bus id)
+    dist.all_gather_object(ids, None if bus is None else (socket.gethostname(), bus), group=group)
     return 'rccl' if all(i is not None for i in ids) and len(set(ids)) == len(ids) else 'host'
 
 

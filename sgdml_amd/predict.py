@@ -22,6 +22,7 @@ class GDMLPredict(object):
         max_processes=None,
         use_torch=False,
         log_level=None,
+        _borrow_ctx=None,
     ):
         self.log = logging.getLogger(__name__)
         if log_level is not None:
@@ -58,7 +59,10 @@ class GDMLPredict(object):
         self.bulk_mp, self.num_workers, self.chunk_size = False, 0, self.n_train
         self.pool = None
 
-        self._ctx = _lib.Context()
+        # _borrow_ctx (internal): evaluate on a context somebody else owns -- the trainer's, for the short-lived predictors of
+        # GDMLTrain._recov_int_const and sweep.sigma_sweep.  The model tables of a context belong to whoever uploaded last.
+        self._owns_ctx = _borrow_ctx is None
+        self._ctx = _lib.Context() if _borrow_ctx is None else _borrow_ctx
         self._ctx.predict_upload_model(
             R_desc_train,
             model['R_d_desc_alpha'],
@@ -70,7 +74,7 @@ class GDMLPredict(object):
 
     def __del__(self):
         ctx = getattr(self, '_ctx', None)
-        if ctx is not None:
+        if ctx is not None and getattr(self, '_owns_ctx', True):
             ctx.close()
 
     # ---- training-mode hooks (predict.py:510-601)

@@ -64,7 +64,7 @@ def sigma_sweep(gdml_train, dataset, n_train, n_valid, n_test, sigs=None, valid_
         t0 = timeit.default_timer()
         model = gdml_train.train(task, callback=callback)
         t1 = timeit.default_timer()
-        pred = GDMLPredict(model)
+        pred = GDMLPredict(model, _borrow_ctx=gdml_train._context())  # short-lived: the trainer's context serves it
         errs = pred.test_errors(R_valid, F_valid, E_valid)
         del pred
         # the reference shuffles the validation indices of every model before its online error loop (cli.py:1487-1488);
@@ -112,7 +112,7 @@ def sigma_sweep(gdml_train, dataset, n_train, n_valid, n_test, sigs=None, valid_
                 it = gdml_train.draw_strat_sample(test_dataset['E'], n_tested, excl_idxs=excl)
             else:
                 it = np.delete(np.arange(test_dataset['F'].shape[0]), excl)[:n_tested]
-            pred = GDMLPredict(best)
+            pred = GDMLPredict(best, _borrow_ctx=gdml_train._context())
             errs = pred.test_errors(test_dataset['R'][it].reshape(len(it), -1), test_dataset['F'][it].reshape(len(it), -1),
                                     test_dataset['E'][it] if (use_E and 'E' in test_dataset) else None)
             del pred

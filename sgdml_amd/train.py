@@ -62,6 +62,13 @@ class GDMLTrain(object):
 
         return _dist.init_comm_from_torch_distributed(self._context(), group=group, backend=backend)
 
+    def reserve_device_memory(self, gb=None):
+        """Reserve the process-level device arena once and keep it (gdml_mem_reserve): the kernel matrices of every later
+        train() call on this GPU are carved from it instead of being hipMalloc'ed and freed, which costs seconds per call
+        beyond ~128 GB on this driver.  gb=None: 85 % of the HBM that is free now.  Returns the bytes held.  No counterpart
+        in the reference (its matrices live in host RAM)."""
+        return self._context().mem_reserve(None if gb is None else int(gb * 2**30))
+
     def _device_budget_bytes(self):
         ctx = self._context()
         _, free_b, total_b = ctx.mem_info()
@@ -273,8 +280,16 @@ class GDMLTrain(object):
         """Train a model from a task (train.py:836-1088)."""
         task = dict(task)
         n_train, n_atoms = task['R_train'].shape[:2]
+        ctx = self._context()
+        if ctx.comm_info()[1] > 1 and task['use_E_cstr']:
+            # The sharded solvers carry force rows only (train.py:235-300 is not distributed).  After init_distributed()
+            # such a task is trained by every rank on its own GPU, redundantly and identically (random draws stay rank
+            # 0's): the communicator is parked for the duration of the call.
+            self.log.info('Energy constraints: training redundantly on every rank (single-GPU solvers)')
+            with ctx.comm_suspended():
+                return self.train(task, save_progr_callback=save_progr_callback, callback=callback)
         desc = Desc(n_atoms, max_processes=self._max_processes)
-        desc._ctx = self._context()
+        desc._ctx = ctx
 
         tril_perms = np.array([Desc.perm(p) for p in task['perms']])
         n_perms = tril_perms.shape[0]
@@ -320,17 +335,12 @@ class GDMLTrain(object):
         use_analytic_solver = est_analytic < 0.95 * budget
         if self._force_solver is not None:
             use_analytic_solver = self._force_solver == 'analytic'
-        if world > 1:
-            if task['use_E_cstr']:
-                raise ValueError(
-                    'Energy constraints (use_E_cstr) are not supported after init_distributed(): the sharded solvers '
-                    'carry force rows only. Train this task on a single GPU (a GDMLTrain without init_distributed).'
-                )
-            # free HBM differs between ranks (rank 0 usually holds more): every rank must take rank 0's branch, or one
-            # enters the distributed Cholesky's collectives while another builds a preconditioner
-            bcast = getattr(self._context(), '_bcast', None)
-            if bcast is not None:
-                use_analytic_solver = bool(np.asarray(bcast(np.array([int(use_analytic_solver)], dtype=np.int64)))[0])
+        # free HBM differs between ranks (rank 0 usually holds more): every rank must take rank 0's branch, or one enters
+        # the distributed Cholesky's collectives (or, with a parked communicator, rank 0's broadcasts of the iterative
+        # solver's random draws) while another does not
+        bcast = getattr(self._context(), '_bcast', None)
+        if bcast is not None:
+            use_analytic_solver = bool(np.asarray(bcast(np.array([int(use_analytic_solver)], dtype=np.int64)))[0])
         solver_keys = {}
 
         if use_analytic_solver:
@@ -380,8 +390,10 @@ class GDMLTrain(object):
 
     def _recov_int_const(self, model, task, R_desc=None, R_d_desc=None):
         """Integration constant + label sanity diagnostics (train.py:1090-1258)."""
+        # the predictor borrows the trainer's context: the training set is resident there already (content-hashed upload),
+        # and a context of its own would cost more than this whole prediction for a small system
         gdml_predict = GDMLPredict(model, max_memory=self._max_memory, max_processes=self._max_processes,
-                                   log_level=logging.CRITICAL)
+                                   log_level=logging.CRITICAL, _borrow_ctx=self._context())
         gdml_predict.set_R_desc(R_desc)
         gdml_predict.set_R_d_desc(R_d_desc)
         E_pred, _ = gdml_predict.predict()

@@ -22,15 +22,44 @@ def main():
 
     from sgdml_amd.train import GDMLTrain
 
-    g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'pcg_n9_m400.npz')))
+    # solver 'ecstr' / 'lu': what the sharded solvers do not carry, run by every rank redundantly (parked communicator)
+    fixture = {'ecstr': 'n5_p2_ecstr', 'lu': 'lu_branch'}.get(solver, 'pcg_n9_m400')
+    g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', fixture + '.npz')))
     M, N = g['R_train'].shape[:2]
     task = {
         'type': 't', 'code_version': '1.0.3', 'dataset_name': np.array('synth'), 'dataset_theory': np.array('pair'),
-        'z': g['z'], 'R_train': g['R_train'], 'F_train': g['F_train'], 'E_train': g['E_train'],
+        'z': g['z'] if 'z' in g else np.full(N, 6), 'R_train': g['R_train'], 'F_train': g['F_train'], 'E_train': g['E_train'],
         'idxs_train': np.arange(M), 'md5_train': 'x', 'idxs_valid': np.arange(0), 'md5_valid': 'x',
-        'sig': int(g['sig']), 'lam': float(g['lam']), 'use_E': True, 'use_E_cstr': False, 'use_sym': False,
-        'perms': g['perms'], 'inducing_pts_idxs': g['inducing_pts_idxs'],
+        'sig': int(g['sig']), 'lam': float(g['lam']), 'use_E': True, 'use_E_cstr': solver == 'ecstr',
+        'use_sym': g['perms'].shape[0] > 1, 'perms': g['perms'],
     }
+    if solver in ('ecstr', 'lu'):
+        from sgdml_amd.solvers.analytic import Analytic
+        took, orig = [], Analytic.solve
+
+        def spy(self, *a, **kw):
+            out = orig(self, *a, **kw)
+            took.append(bool(self.used_lu))
+            return out
+
+        Analytic.solve = spy
+        tr = GDMLTrain()
+        tr._force_solver = 'analytic'
+        tr.init_distributed(backend=backend)
+        model = tr.train(task)
+        assert tr._context().comm_info() == (rank, world)  # the communicator is back after the redundant solve
+        chk = [None] * world
+        dist.all_gather_object(chk, float(np.abs(model['alphas_F']).sum()))
+        assert len(set(chk)) == 1, chk
+        if rank == 0:  # what GDMLPredict reads from a model (predict.py:326-354)
+            keep = {k: model[k] for k in ('z', 'R_desc', 'R_d_desc_alpha', 'sig', 'c', 'std', 'perms', 'tril_perms_lin')}
+            if 'alphas_E' in model:
+                keep['alphas_E'] = model['alphas_E']
+            np.savez(out_path, used_lu=np.array(took), **keep)
+        tr.__del__()
+        dist.destroy_process_group()
+        return
+    task['inducing_pts_idxs'] = g['inducing_pts_idxs']
     # the memory model must pick the fixture's k so that the given inducing columns are used as they are
     k = len(g['inducing_pts_idxs']) // (3 * N)
     np.random.seed(100 + rank)  # deliberately different per rank: every draw has to come from rank 0

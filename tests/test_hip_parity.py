@@ -495,11 +495,11 @@ def test_K_large_molecule_global_table(ctx):
     assert np.abs(K - Ko).max() <= 1e-12 * np.abs(Ko).max()
 
 
-def test_K_global_table_path_with_perms(golden, ctx):
-    """Same code path forced on the small fixtures (covers permutations and E-constraint rows)."""
+def test_K_general_kernel_on_small_fixtures(golden, ctx):
+    """The general kernel (assemble_perm.hip) forced on the small reference fixtures (permutations, E-constraint rows)."""
     g = golden
-    ctx.set_option('asm.gj_global', 1)
     ctx.set_option('asm.wave', 0)
+    ctx.set_option('asm.pts', 0)
     ctx.train_upload(g['R_desc'], g['R_d_desc'], _tril_perms(g))
     K = ctx.assemble_K(float(g['sig']), bool(g['use_E_cstr']), to_host=True)
     assert np.abs(K - g['K']).max() <= 1e-12 * np.abs(g['K']).max()

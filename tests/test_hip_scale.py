@@ -465,3 +465,31 @@ def test_dropin_train_distributed_analytic(tmp_path):
         tr.__del__()
     assert np.abs(r['alphas'] - model['alphas_F']).max() <= 1e-5 * np.abs(model['alphas_F']).max()
     assert abs(float(r['c']) - model['c']) <= 1e-6 * max(1.0, abs(model['c']))
+
+
+@pytest.mark.parametrize('mode', ['ecstr', 'lu'])
+def test_distributed_mode_redundant_solves(tmp_path, mode):
+    """After init_distributed the sharded solvers carry force rows and positive definite systems only.  What they do not
+    carry is solved by every rank on its own GPU with the communicator parked (gdml_comm_suspend), like a single-GPU run:
+    energy constraints (train.py:235-300; fixture n5_p2_ecstr) and the LU branch of a system on which the (distributed)
+    Cholesky fails (analytic.py:101-114; fixture lu_branch).  Two processes sharing the GPU: the model equals the reference's."""
+    from sgdml_amd.predict import GDMLPredict
+
+    g = load('n5_p2_ecstr' if mode == 'ecstr' else 'lu_branch')
+    out = str(tmp_path / 'redundant.npz')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+    port = 29700 + (os.getpid() % 200) + (3 if mode == 'lu' else 0)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', '_sharded_worker.py'), out, 'host', mode]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r = dict(np.load(out))
+    assert list(r['used_lu']) == [mode == 'lu']
+    model = {k: r[k] for k in r if k != 'used_lu'}
+    model.update(type='m', sig=int(r['sig']), c=float(r['c']), std=float(r['std']))
+    nt = len(g['R_test'])
+    E, F = GDMLPredict(model).predict(g['R_test'].reshape(nt, -1))
+    tol = 1e-6 if mode == 'lu' else 2e-4  # as in the single-GPU tests of the two fixtures
+    assert np.abs(F - g['F_test']).max() <= tol * np.abs(g['F_test']).max()
+    assert np.abs(E - g['E_test']).max() <= tol * max(1.0, np.abs(g['E_test']).max())

@@ -1,6 +1,5 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_hip_r4.py::test_column_modes_n24_p6_vs_reference --deselect tests/test_hip_r4.py::test_iterative_solver_with_permutation_group_vs_reference 2>&1 | tail -40 > gpurun_out/r4a_pytest.log
-bash tools/pcg_trace.sh r4a build/libgdml_hip_r3.so
-timeout 400 python tools/cfg_solve_probe.py cg 42 2000 c3x3 64 20 traj > gpurun_out/r4a_cfg3.log 2>&1
-timeout 400 python tools/cfg_solve_probe.py cg 100 3000 - 128 20 traj > gpurun_out/r4a_cfg4.log 2>&1
-tail -5 gpurun_out/r4a_pytest.log; cat gpurun_out/r4a_pcg_host_gaps.txt | head -50; tail -2 gpurun_out/r4a_cfg3.log; tail -2 gpurun_out/r4a_cfg4.log
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -60 > gpurun_out/r4d_pytest.log
+timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/r4d_bench.json 2> gpurun_out/r4d_bench.err
+HIP_ENABLE_DEFERRED_LOADING=0 timeout 200 python tools/sweep_hostprof.py 2>/dev/null | grep "^sweep" > gpurun_out/r4d_sweep_eager_loading.txt
+tail -6 gpurun_out/r4d_pytest.log; tail -c 6000 gpurun_out/r4d_bench.json; tail -5 gpurun_out/r4d_bench.err; cat gpurun_out/r4d_sweep_eager_loading.txt

@@ -1,7 +1,7 @@
 """assemble_perm.hip on the GPU: parity against the oracle over its code paths (option sets), with a per-block error map
 when something is off, then timings at the shapes the round-2 review named.
     python tools/asm_perm_check.py check          # parity (small cases, all modes)
-    python tools/asm_perm_check.py time [quick]    # timings, old kernel (asm.perm=0) beside the new one where it exists
+    python tools/asm_perm_check.py time [quick]    # timings (the round-1 LDS kernel it was compared with is gone)
 """
 import os, sys, time
 import numpy as np
@@ -143,7 +143,6 @@ def do_time(quick):
               (100, 120, 'id'), (30, 400, 'id')]
     if quick: shapes = shapes[:4]
     for N, M, kind in shapes:
-        if N <= 64: time_case(N, M, kind, {'asm.perm': 0}, label='old')
         time_case(N, M, kind, {}, label='new')
     # variants at the two shapes of interest
     for N, M, kind in [(21, 1000, 'c2xc2'), (42, 300, 'c3^3')]:
@@ -151,7 +150,6 @@ def do_time(quick):
                      {'asm.perm_pg': 1}, {'asm.perm_na': 6}, {'asm.perm_fast_store': 0}, {'asm.perm_i_chunk': 32}, {'asm.perm_i_chunk': 4}]:
             time_case(N, M, kind, opts, label='new')
         time_case(N, M, kind, {}, lower=True, label='new')
-        time_case(N, M, kind, {'asm.perm': 0}, lower=True, label='old')
 
 
 if __name__ == '__main__':
