@@ -82,6 +82,10 @@ template <int W, int NA, bool IMG, bool GJS, bool JX, bool BIG>
 __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int T = 64 * W;
+#ifndef PERM_VU
+#define PERM_VU 3
+#endif
+  constexpr int VU = PERM_VU;  // iterations of the V-phase contractions whose loads are in flight together
   const int N = A.N, N3 = 3 * N, NN = N * N, P = A.P, NQ = A.NQ, PG = A.PG, npass = A.npass;
   const int SEG = BIG ? (N + 63) >> 6 : 1;  // 64-atom segments of a point (V12 passes of large molecules)
   const int ppp = BIG ? 1 : 64 / N;          // whole column points per V12 pass (N <= 64)
@@ -275,17 +279,45 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
               const double* xjg = A.XF + jq * NN + pa;  // x_j[pair(pi a, .)] (global; JX: the LDS copy)
               const double* xjl = Xq + qc * NN + pa;
               double v0 = 0.0, v1 = 0.0, v2 = 0.0, nn = 0.0;
-#pragma unroll 4
-              for (int m = 0; m < N; ++m) {
-                const int pm = perm_at<BIG>(pr0, pr1, m);
-                const double xi = IMG ? SX[m * N + ac] : XFi[m * N + ac];
-                const double xj = JX ? xjl[pm * N] : xjg[pm * N];
-                const double* g = IMG ? SG + (m * N + ac) * 3 : GDi + (m * N + ac) * 3;
-                const double d = xi - xj;
-                nn += d * d;
-                v0 += d * g[0];
-                v1 += d * g[1];
-                v2 += d * g[2];
+              // VU iterations at a time: all their operand loads are issued before the first multiply-add.  (The compiler
+              // refuses to unroll a loop with a run-time trip count around v_readlane -- a convergent operation rules out
+              // the remainder loop -- and then waits for every global x_j load before it issues the next one: 900 cycles
+              // per iteration, 80 % of the kernel at N = 42, P = 27: profiles/r04_assemble_perm_ablation.txt.)  The tail
+              // re-reads entry N - 1 and contributes zero.
+              // x_j is the one operand that may come from global memory (levels below 3): it runs two chunks ahead
+              double xa[VU], xb[VU], xc[VU];
+              auto ld_xj = [&](int m0, double (&dst)[VU]) {
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                  const int m = (m0 + u < N) ? m0 + u : N - 1;
+                  const int pm = perm_at<BIG>(pr0, pr1, m);
+                  dst[u] = JX ? xjl[pm * N] : xjg[pm * N];
+                }
+              };
+              ld_xj(0, xa);
+              ld_xj(VU, xb);
+              for (int m0 = 0; m0 < N; m0 += VU) {
+                double xi_[VU], g_[VU][3];
+                ld_xj(m0 + 2 * VU, xc);
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                  const int m = (m0 + u < N) ? m0 + u : N - 1;
+                  xi_[u] = IMG ? SX[m * N + ac] : XFi[m * N + ac];
+                  const double* g = IMG ? SG + (m * N + ac) * 3 : GDi + (m * N + ac) * 3;
+                  g_[u][0] = g[0];
+                  g_[u][1] = g[1];
+                  g_[u][2] = g[2];
+                }
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                  const double d = (m0 + u < N) ? xi_[u] - xa[u] : 0.0;
+                  nn += d * d;
+                  v0 += d * g_[u][0];
+                  v1 += d * g_[u][1];
+                  v2 += d * g_[u][2];
+                  xa[u] = xb[u];
+                  xb[u] = xc[u];
+                }
               }
               if (!ok) nn = 0.0;
               if (ok) {
@@ -319,20 +351,45 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
               const double* gdj = A.GD + ((int64_t)jpt * NN + b) * 3;
               double u0 = 0.0, u1 = 0.0, u2 = 0.0;
               double d00 = 0.0, d01 = 0.0, d02 = 0.0, d10 = 0.0, d11 = 0.0, d12 = 0.0, d20 = 0.0, d21 = 0.0, d22 = 0.0;
-#pragma unroll 4
-              for (int mp = 0; mp < N; ++mp) {
-                const int mi = perm_at<BIG>(pi0, pi1, mp);
-                const double xi = IMG ? SX[mi * N + ap] : XFi[mi * N + ap];
-                const double xj = JX ? XjS[mp * 64 + lane] : xfj[mp * N];
-                const double* rj = GJS ? GjS + (mp * 64 + lane) * 3 : gdj + mp * N3;
-                const double* gi = IMG ? SG + (mi * N + ap) * 3 : GDi + (mi * N + ap) * 3;
-                const double d = xi - xj;
-                const double r0 = rj[0], r1 = rj[1], r2 = rj[2];
-                const double g0v = gi[0], g1v = gi[1], g2v = gi[2];
-                u0 += d * r0; u1 += d * r1; u2 += d * r2;
-                d00 += g0v * r0; d01 += g0v * r1; d02 += g0v * r2;
-                d10 += g1v * r0; d11 += g1v * r1; d12 += g1v * r2;
-                d20 += g2v * r0; d21 += g2v * r1; d22 += g2v * r2;
+              double xa[VU], xb[VU], xc[VU];
+              auto ld_xj = [&](int m0, double (&dst)[VU]) {
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                  const int mp = (m0 + u < N) ? m0 + u : N - 1;
+                  dst[u] = JX ? XjS[mp * 64 + lane] : xfj[mp * N];
+                }
+              };
+              ld_xj(0, xa);
+              ld_xj(VU, xb);
+              for (int m0 = 0; m0 < N; m0 += VU) {
+                double xi_[VU], r_[VU][3], gi_[VU][3];
+                ld_xj(m0 + 2 * VU, xc);
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                  const int mp = (m0 + u < N) ? m0 + u : N - 1;
+                  const int mi = perm_at<BIG>(pi0, pi1, mp);
+                  xi_[u] = IMG ? SX[mi * N + ap] : XFi[mi * N + ap];
+                  const double* rj = GJS ? GjS + (mp * 64 + lane) * 3 : gdj + mp * N3;
+                  const double* gi = IMG ? SG + (mi * N + ap) * 3 : GDi + (mi * N + ap) * 3;
+#pragma unroll
+                  for (int c3 = 0; c3 < 3; ++c3) {
+                    r_[u][c3] = rj[c3];
+                    gi_[u][c3] = gi[c3];
+                  }
+                }
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                  const bool live = m0 + u < N;
+                  const double d = live ? xi_[u] - xa[u] : 0.0;
+                  const double r0 = r_[u][0], r1 = r_[u][1], r2 = r_[u][2];
+                  const double g0v = live ? gi_[u][0] : 0.0, g1v = live ? gi_[u][1] : 0.0, g2v = live ? gi_[u][2] : 0.0;
+                  u0 += d * r0; u1 += d * r1; u2 += d * r2;
+                  d00 += g0v * r0; d01 += g0v * r1; d02 += g0v * r2;
+                  d10 += g1v * r0; d11 += g1v * r1; d12 += g1v * r2;
+                  d20 += g2v * r0; d21 += g2v * r1; d22 += g2v * r2;
+                  xa[u] = xb[u];
+                  xb[u] = xc[u];
+                }
               }
               double* dst = ud + pl * 12 * 64 + lane;
               dst[0 * 64] = u0; dst[1 * 64] = u1; dst[2 * 64] = u2;
