@@ -423,6 +423,7 @@ def main():
     ap.add_argument('--cg-inducing', type=int, default=200)
     ap.add_argument('--cg-iters', type=int, default=50, help='PCG iterations per step of the configs[2] workload')
     ap.add_argument('--no-to-tol', action='store_true', help='N>1: skip the sharded run to solver_tol')
+    ap.add_argument('--to-tol-timeout', type=float, default=600.0, help='N>1: seconds the sharded run to solver_tol may take')
     ap.add_argument('--dist-chol', action='store_true', help='N>1: also time the configs[1] system through the distributed Cholesky')
     ap.add_argument('--comm', default='auto', help="N>1: 'rccl', 'host' (gloo-staged), or auto (rccl if every rank has a GPU)")
     args = ap.parse_args()
@@ -452,6 +453,9 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
+        if isinstance(out, dict) and isinstance(out.get('time_to_tol'), dict) and \
+                str(out['time_to_tol'].get('error', '')).startswith('no result within'):
+            os._exit(0)  # a worker thread is stuck inside a collective: do not wait for it at interpreter exit
 
 
 def self_launch(args):
@@ -553,26 +557,45 @@ def run_sharded_cg(args, rank, world):
     # the same workload as the 1-GPU configs[2] entry run to solver_tol through GDMLTrain.train, sharded over the ranks
     # (leverage-sampled inducing points, the reference's restart policy): what a SCALE record means as a SOLVE
     to_tol = None
+    hung = False
     if not args.no_to_tol:
-        try:
-            to_tol = solve_config('configs[2] to solver_tol 1e-4, sharded over {} ranks'.format(world), N, M, solver='cg',
-                                  max_memory=32, traj={'n_modes': 8, 'amp': 0.15, 'noise': 0.01}, sig=args.sig, lam=args.lam,
-                                  dist_backend=comm)
+        # in a worker thread under a time limit: this leg builds a second communicator and runs ~900 sharded iterations;
+        # should a collective ever hang on some node, the strong-scaling line above must still be printed (the main
+        # thread gives up waiting, reports it, and the process leaves through os._exit)
+        import threading
+
+        box = {}
+
+        def _run():
+            try:
+                box['r'] = solve_config('configs[2] to solver_tol 1e-4, sharded over {} ranks'.format(world), N, M, solver='cg',
+                                        max_memory=32, traj={'n_modes': 8, 'amp': 0.15, 'noise': 0.01}, sig=args.sig,
+                                        lam=args.lam, dist_backend=comm)
+            except Exception as e:
+                box['r'] = {'error': repr(e)}
+
+        th = threading.Thread(target=_run, daemon=True)
+        th.start()
+        th.join(timeout=args.to_tol_timeout)
+        hung = th.is_alive()
+        to_tol = {'error': 'no result within {} s'.format(args.to_tol_timeout)} if hung else box.get('r')
+        if not hung and to_tol is not None and 'train_wall_s' in to_tol:
             tw = torch.tensor([to_tol['train_wall_s']], dtype=torch.float64)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             to_tol['time_to_tol_s'] = to_tol['train_wall_s'] = float(tw[0])
-        except Exception as e:
-            to_tol = {'error': repr(e)}
 
     one_gpu = None
-    if rank == 0:  # the 1-GPU point of the curve, same run, same GPU as rank 0
+    if rank == 0 and not hung:  # the 1-GPU point of the curve, same run, same GPU as rank 0
         c1 = _lib.Context(local_rank % max(1, n_dev))
         wl1 = make_cg_workload(c1, N, M, k, args.sig, args.lam)
         one_gpu = time_cg(c1, wl1, args.cg_iters, 1, 1, c1.sync)
         c1.close()
-    dist.barrier()
-    dist.destroy_process_group()
+    if not hung:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
+        if hung:
+            os._exit(0)
         return None
     tot_bytes, iter_bytes = cg_algorithmic_bytes(wl, args.cg_iters, world)
     ach = iter_bytes / (pcg_ms / args.cg_iters * 1e-3) / 1e9

@@ -513,6 +513,9 @@ class Context(object):
         return out
 
     def nystroem_factor(self, lam, idx, want_factor=False):
+        """(leverage scores, factor or None, info).  info is a bit field (gdml_nystroem_factor): bit 0 = the second
+        Cholesky failed and the QR-equivalent branch ran (iterative.py:313-324); info >> 8 = jitter escalations of the
+        first one (iterative.py:442-463)."""
         idx = i64(idx)
         n_rows, _, _ = self.K_shape()  # rows held by this rank
         n_glob = self.n_train * 3 * self.n_atoms + (0 if n_rows % (3 * self.n_atoms) == 0 else self.n_train)

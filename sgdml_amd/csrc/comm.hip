@@ -100,17 +100,22 @@ extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int wo
   ncclResult_t_ r = g_rccl.CommInitRank(&comm, world, id, rank);
   if (r != 0) return rccl_fail(ctx, "ncclCommInitRank", r);
   ctx->comm = comm;
-  ctx->comm2 = nullptr;
-  if (world > 1 && g_rccl.CommSplit) {  // same ranks, same order: a second, independent channel
-    ncclComm_t_ c2 = nullptr;
-    if (g_rccl.CommSplit(comm, 0, rank, &c2, nullptr) == 0) ctx->comm2 = c2;
-  }
+  ctx->comm2 = nullptr;  // created on demand (comm_ensure_second): only the look-ahead distributed Cholesky wants it
   ctx->comm_aborted = false;
   ctx->rank = rank;
   ctx->world = world;
   ctx->virtual_rank = false;
   ctx->coll_calls = 0;
   ctx->coll_bytes = 0.0;
+  return GDML_OK;
+}
+
+// Second communicator over the same ranks (ncclCommSplit, a collective call: every rank must get here together).  Without
+// ncclCommSplit in the loaded librccl, or when the split fails, the callers keep using the first communicator.
+int comm_ensure_second(gdml_ctx* ctx) {
+  if (!ctx->comm || ctx->comm2 || ctx->world <= 1 || !g_rccl.CommSplit) return GDML_OK;
+  ncclComm_t_ c2 = nullptr;
+  if (g_rccl.CommSplit((ncclComm_t_)ctx->comm, 0, ctx->rank, &c2, nullptr) == 0) ctx->comm2 = c2;
   return GDML_OK;
 }
 

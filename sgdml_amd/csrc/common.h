@@ -221,6 +221,7 @@ int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count);
 int comm_allgather_inplace_on(gdml_ctx* ctx, double* buf, int64_t chunk, hipStream_t st);
 int comm_broadcast_on(gdml_ctx* ctx, double* buf, int64_t count, int root, hipStream_t st, bool second_comm = false);
 void comm_destroy(gdml_ctx* ctx);
+int comm_ensure_second(gdml_ctx* ctx);
 // A rank that fails locally between collectives (a launch error in a panel loop) must not leave its peers blocked in
 // the collective it will never join: RCCL communicators are aborted (ncclCommAbort: the peers' pending and later
 // operations end with an error), and this context refuses further collectives.

@@ -187,6 +187,7 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
     hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_p[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
     auto setup = [&]() -> int {  // a failure here must reach comm_abort below: the peers are about to enter a broadcast
       if (la) {
+        GDML_TRY(comm_ensure_second(ctx));  // block broadcasts on their own communicator (same option on every rank)
         HIP_CHECK(ctx, hipStreamCreateWithFlags(&sn_own, hipStreamNonBlocking));
         sn = sn_own;
       }

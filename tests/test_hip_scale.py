@@ -351,7 +351,7 @@ def test_nystroem_qr_branch_matches_reference(ctx):
         ctx.set_option('nys.force_qr', force)
         ctx.assemble_K(sig, False, idx=idx, alloc_extra_rows=len(idx))
         lev, fac, info = ctx.nystroem_factor(lam, idx, want_factor=True)
-        assert info == force
+        assert (info & 1) == force  # bit 0 = alternative (QR-equivalent) branch; bits 8.. = jitter escalations
         P = fac.T @ fac
         assert np.abs(P - P_ref).max() <= 1e-9 * np.abs(P_ref).max(), force
         np.testing.assert_allclose(lev, (ref**2).sum(0), rtol=1e-8)
@@ -391,7 +391,10 @@ def test_distributed_cholesky_single_rank(ctx, N, M, nb, perms):
     a = ctx.dist_chol_solve(20.0, 1e-10, y)
     r = Kop(-a) + y  # y - A x with A x = -(K x - lam x)
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(y)
-    # the two paths assemble with different kernels (rounding-level differences in K); lam = 1e-10 amplifies them
+    # alphas of two correct factorisations differ by about cond(A) * eps * |alphas|: the two paths assemble K with different
+    # kernels (entries equal to ~1e-16 relative), lam = 1e-10 against |K| ~ 1e0..1e1 gives cond(A) up to ~1e10-1e11, i.e. a
+    # relative difference up to ~1e-5 (observed 2e-5 on the 26-atom case): the residual above is the parity statement, this
+    # bound only catches a wrong solution
     assert np.abs(a - a_ref).max() <= 1e-4 * np.abs(a_ref).max()
 
 
