@@ -194,18 +194,39 @@ __global__ void __launch_bounds__(256) row_sqnorm_kernel(const double* __restric
   if (lane == 0) out[r] = s;
 }
 
-// t_part[rc][c] = sum_{r in chunk rc} X[r][c] v[r]
+// t_part[rc][c] = sum_{r in chunk rc} X[r][c] v[r].  HBM bound (X is read once per call): a thread owns two adjacent
+// columns (16-byte loads; rows are padded to a multiple of 16 doubles, so the pair of an odd last column stays inside the
+// row) and keeps eight rows in flight.
 __global__ void __launch_bounds__(256) gemv_t_part_kernel(const double* __restrict__ X, int64_t ld,
                                                           int64_t n, int64_t m,
                                                           const double* __restrict__ v, int rows_per,
                                                           double* __restrict__ part) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per;
   const int64_t r1 = (r0 + rows_per < n) ? r0 + rows_per : n;
   if (c >= m) return;
-  double s = 0.0;
-  for (int64_t r = r0; r < r1; ++r) s += X[r * ld + c] * v[r];
-  part[(int64_t)blockIdx.y * m + c] = s;
+  const double* col = X + c;
+  d2 s = {0.0, 0.0};
+  int64_t r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    d2 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const d2*>(col + (r + u) * ld);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double vr = v[r + u];
+      s.x += x[u].x * vr;
+      s.y += x[u].y * vr;
+    }
+  }
+  for (; r < r1; ++r) {
+    const d2 x = *reinterpret_cast<const d2*>(col + r * ld);
+    const double vr = v[r];
+    s.x += x.x * vr;
+    s.y += x.y * vr;
+  }
+  part[(int64_t)blockIdx.y * m + c] = s.x;
+  if (c + 1 < m) part[(int64_t)blockIdx.y * m + c + 1] = s.y;
 }
 __global__ void __launch_bounds__(256) reduce_parts_kernel(const double* __restrict__ part, int64_t m,
                                                            int nparts, double* __restrict__ out) {
@@ -215,7 +236,7 @@ __global__ void __launch_bounds__(256) reduce_parts_kernel(const double* __restr
   for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * m + c];
   out[c] = s;
 }
-// out[r] = (sum_c X[r][c] t[c] - v[r]) * inv_lam
+// out[r] = (sum_c X[r][c] t[c] - v[r]) * inv_lam.  One wavefront per row, 16-byte loads, four of them in flight per lane.
 __global__ void __launch_bounds__(256) gemv_n_precon_kernel(const double* __restrict__ X, int64_t ld,
                                                             int64_t n, int64_t m,
                                                             const double* __restrict__ t,
@@ -224,9 +245,31 @@ __global__ void __launch_bounds__(256) gemv_n_precon_kernel(const double* __rest
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
-  double s = 0.0;
-  for (int64_t c = lane; c < m; c += 64) s += X[r * ld + c] * t[c];
-  s = wave_sum(s);
+  const double* row = X + r * ld;
+  const int64_t m2 = m & ~(int64_t)1;  // even part: pairs; an odd last column is added by lane 0
+  double s0 = 0.0, s1 = 0.0;
+  int64_t c = 2 * lane;
+  for (; c + 3 * 128 < m2; c += 4 * 128) {
+    d2 x[4], tt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = *reinterpret_cast<const d2*>(row + c + 128 * u);
+      tt[u] = *reinterpret_cast<const d2*>(t + c + 128 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s0 += x[u].x * tt[u].x;
+      s1 += x[u].y * tt[u].y;
+    }
+  }
+  for (; c < m2; c += 128) {
+    const d2 x = *reinterpret_cast<const d2*>(row + c);
+    const d2 tt = *reinterpret_cast<const d2*>(t + c);
+    s0 += x.x * tt.x;
+    s1 += x.y * tt.y;
+  }
+  if (lane == 0 && m2 < m) s0 += row[m2] * t[m2];
+  const double s = wave_sum(s0 + s1);
   if (lane == 0) out[r] = (s - v[r]) * inv_lam;
 }
 
@@ -569,11 +612,11 @@ static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, dou
   int nparts = (int)((n_loc + rows_per - 1) / rows_per);
   if (nparts < 1) nparts = 1;
   double* buf;
-  GDML_TRY(ctx_slot(ctx, 3, ((int64_t)nparts * m + m) * 8, &buf));
+  GDML_TRY(ctx_slot(ctx, 3, ((int64_t)nparts * m + m + 2) * 8, &buf));
   double* part = buf;
-  double* t = buf + (int64_t)nparts * m;
+  double* t = buf + (((int64_t)nparts * m + 1) & ~(int64_t)1);  // 16-byte aligned: read in pairs
   if (n_loc > 0) {
-    hipLaunchKernelGGL(gemv_t_part_kernel, dim3(ceil_div(m, 256), nparts), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(gemv_t_part_kernel, dim3(ceil_div(m, 512), nparts), dim3(256), 0, ctx->stream,
                        ctx->precon, ld, n_loc, m, d_v + sg.row0, rows_per, part);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m,
                        nparts, t);

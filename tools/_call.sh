@@ -1,4 +1,6 @@
 mkdir -p gpurun_out
-timeout 600 python -m pytest -q -m gpu tests/test_hip_r4.py::test_assemble_perm_mode_matrix tests/test_hip_r4.py::test_column_modes_n24_p6_vs_reference "tests/test_hip_scale.py::test_K_samples_at_config_shapes" 2>&1 | tail -8 > gpurun_out/r4h_pytest.log
-{ echo "== x_j two chunks ahead; VU = 3 (library)"; timeout 300 python tools/asm_perm_ablate.py quick; echo "== VU = 2"; GDML_HIP_LIB=$PWD/build/libgdml_vu2.so timeout 300 python tools/asm_perm_ablate.py quick; echo "== VU = 4"; GDML_HIP_LIB=$PWD/build/libgdml_vu4.so timeout 300 python tools/asm_perm_ablate.py quick; } > gpurun_out/r4h_asm_perm_vu.txt 2>&1
-cat gpurun_out/r4h_pytest.log gpurun_out/r4h_asm_perm_vu.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/r4j_pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r4j_smoke.log 2>&1
+timeout 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/r4j_bench.json 2> gpurun_out/r4j_bench.err
+bash tools/profile_round.sh r4j > gpurun_out/r4j_profile_round.log 2>&1
+grep -E "passed|failed" gpurun_out/r4j_pytest.log; cat gpurun_out/r4j_smoke.log; head -c 1500 gpurun_out/r4j_bench.json; echo; tail -3 gpurun_out/r4j_bench.err; head -12 gpurun_out/r4j_kernel_stats.txt; cat gpurun_out/r4j_pmc_hbm_traffic.txt | head -20
