@@ -270,7 +270,8 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
       rc = assemble_wave_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, ctx->K, ld, i_beg, i_end,
                                 lower_A ? 1 : 0, lam);
     else
-      rc = assemble_perm_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, 0, ctx->K, ld, i_beg, i_end, 0, 0.0, 0, 0, 0);
+      rc = assemble_perm_launch(ctx, sig, use_E_cstr, d_jlist, d_colmap, j0, n_j, 0, ctx->K, ld, i_beg, i_end, 0, 0.0, 0, 0, 0,
+                                dense ? nullptr : colmap.data());
   }
   if (rc == GDML_OK && !e_pts.empty()) {
     if (N3 > 512) rc = gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "E-constraint columns need 3N <= 512");

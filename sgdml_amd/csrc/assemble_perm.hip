@@ -40,6 +40,10 @@ struct PermArgs {
   int use_E;             // also write the energy-constraint row K[3N M + i, .]  (train.py:235-248)
   const int32_t* jlist;  // virtual column point -> training point (null: j0 + v)
   const int32_t* colmap; // (n_j, 3N) output column or -1 (null: col0 + 3N v + c)
+  // compact index-list mode: strips are 64 REQUESTED column atoms (entry = virtual point * N + atom, -1 = idle lane) of at
+  // most NQ consecutive virtual points starting at strip_jv0[s]; null: strips of 64 consecutive column atoms
+  const int32_t* calist;
+  const int32_t* strip_jv0;
   int64_t j0, n_j, col0;
   int64_t i_beg, i_end;  // row points of this launch; rows are written relative to i_beg
   int i_chunk;
@@ -106,10 +110,16 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t s = blockIdx.x;
   const int64_t n_ca = A.n_j * N;  // column atoms of this launch
-  const int64_t gav = 64 * s + lane;
-  const bool cvalid = gav < n_ca;
-  const int jv0 = (int)((64 * s) / N);  // first (virtual) column point of the strip
-  const int jv = cvalid ? (int)(gav / N) : (int)A.n_j - 1;
+  int64_t gav = 64 * s + lane;
+  bool cvalid = gav < n_ca;
+  int jv0 = (int)((64 * s) / N);  // first (virtual) column point of the strip
+  if (A.calist) {  // compact list: this lane's requested column atom, or an idle lane
+    const int ent = A.calist[64 * s + lane];
+    jv0 = A.strip_jv0[s];
+    cvalid = ent >= 0;
+    gav = cvalid ? ent : (int64_t)jv0 * N;
+  }
+  const int jv = cvalid ? (int)(gav / N) : (A.calist ? jv0 : (int)A.n_j - 1);
   const int b = cvalid ? (int)(gav - (int64_t)jv * N) : 0;
   const int q = jv - jv0;
   const int jpt = A.jlist ? A.jlist[jv] : (int)A.j0 + jv;
@@ -573,9 +583,9 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
 int build_dense_tables(gdml_ctx* ctx);
 
 // LDS layout for one choice of what is resident; returns the byte size
-static size_t perm_layout(int N, int P, int W, int NA, int n_img, bool gjs, bool jx, int PG, PermArgs* A) {
+static size_t perm_layout(int N, int P, int W, int NA, int n_img, bool gjs, bool jx, int PG, PermArgs* A, int nq = 0) {
   const int NN = N * N;
-  const int NQ = (62 + N) / N + 1;
+  const int NQ = nq > 0 ? nq : (62 + N) / N + 1;
   const int SEG = (N + 63) / 64;
   int o = 0;
   A->o_IM = o; o += n_img * 4 * NN;
@@ -612,7 +622,7 @@ static void perm_launch_t(gdml_ctx* ctx, const PermArgs& A, dim3 grid, size_t ld
 // Launch over the column points [0, n_j) of (jlist | j0 + v) and the row points [i_beg, i_end).
 int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist, const int32_t* d_colmap, int64_t j0,
                          int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg, int64_t i_end, int lower, double lam,
-                         int cyc_W, int cyc_rank, int cyc_nb) {
+                         int cyc_W, int cyc_rank, int cyc_nb, const int32_t* h_colmap) {
   TrainSet& ts = ctx->ts;
   if (n_j <= 0 || i_end <= i_beg) return GDML_OK;
   // small molecules, whole column points, plain row layout: the producer / consumer kernel of assemble_pts.hip
@@ -677,10 +687,69 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   if (n_img == 1 && opt_nimg != 1 && perm_layout(N, P, W, NA, 2, level >= 2, level >= 3, PG, &tmp) <= budget) n_img = 2;
   while (PG < pg_max && perm_layout(N, P, W, NA, n_img, level >= 2, level >= 3, PG + 1, &tmp) <= budget) ++PG;
   PG = (P + (P + PG - 1) / PG - 1) / ((P + PG - 1) / PG);  // equal groups
-  const size_t lds = perm_layout(N, P, W, NA, n_img, level >= 2, level >= 3, PG, &A);
+
+  // ---- index-list columns: strips of REQUESTED column atoms.  The columns the iterative solver asks for are individual
+  // matrix columns (iterative.py:372-379, :401-411), a few per training point, and a strip of 64 consecutive column atoms
+  // computes all 3N columns of every point it touches -- a whole kernel matrix for one K_nm.  Here the atoms that own a
+  // requested column are packed 64 to a strip (at most nq consecutive points per strip: the V phase works per column point);
+  // taken when it at least halves the number of strips.
+  std::vector<int32_t> h_ca, h_jv0;
+  int nq_list = 0;
+  const int nq_dense = (62 + N) / N + 1;
+  if (h_colmap && d_colmap && !lower && cyc_W == 0 && ctx_opt_i(ctx, "asm.perm_compact", 1)) {
+    for (int nq : {16, 12, 8, 6, 4}) {
+      if (nq <= nq_dense) break;
+      if (perm_layout(N, P, W, NA, n_img, level >= 2, level >= 3, PG, &tmp, nq) <= budget) {
+        nq_list = nq;
+        break;
+      }
+    }
+    if (nq_list) {
+      int used = 0, npts = 0;
+      auto close = [&]() {
+        while (used < 64) {
+          h_ca.push_back(-1);
+          ++used;
+        }
+        used = 0;
+        npts = 0;
+      };
+      for (int64_t v = 0; v < n_j; ++v) {
+        const int32_t* cm = h_colmap + v * 3 * N;
+        bool first_of_point = true;
+        for (int b = 0; b < N; ++b) {
+          if (cm[3 * b] < 0 && cm[3 * b + 1] < 0 && cm[3 * b + 2] < 0) continue;
+          if (used == 64 || (first_of_point && used > 0 && npts == nq_list)) close();
+          if (used == 0) h_jv0.push_back((int32_t)v);
+          if (first_of_point || used == 0) ++npts;
+          first_of_point = false;
+          h_ca.push_back((int32_t)(v * N + b));
+          ++used;
+        }
+      }
+      if (used > 0) close();
+      const int64_t strips_dense = (n_j * N + 63) / 64;
+      if ((int64_t)h_jv0.size() * 2 > strips_dense) {  // does not pay: the dense strips
+        h_ca.clear();
+        h_jv0.clear();
+        nq_list = 0;
+      }
+    }
+  }
+  const size_t lds = perm_layout(N, P, W, NA, n_img, level >= 2, level >= 3, PG, &A, nq_list);
+  int32_t *d_ca = nullptr, *d_jv0 = nullptr;
+  if (nq_list) {
+    GDML_TRY(ctx_alloc(ctx, (void**)&d_ca, (int64_t)h_ca.size() * 4));
+    GDML_TRY(ctx_alloc(ctx, (void**)&d_jv0, (int64_t)h_jv0.size() * 4));
+    HIP_CHECK(ctx, hipMemcpyAsync(d_ca, h_ca.data(), h_ca.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(ctx, hipMemcpyAsync(d_jv0, h_jv0.data(), h_jv0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope with this call
+    A.calist = d_ca;
+    A.strip_jv0 = d_jv0;
+  }
 
   // ---- grid: strips x chunks of row points
-  const int64_t n_strips = (n_j * N + 63) / 64;
+  const int64_t n_strips = nq_list ? (int64_t)h_jv0.size() : (n_j * N + 63) / 64;
   const int64_t n_i = i_end - i_beg;
   int i_chunk = ctx_opt_i(ctx, "asm.perm_i_chunk", 16);
   if (i_chunk < 1) i_chunk = 1;
@@ -704,5 +773,7 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   ktime_end(ctx, slot, "assemble", 8.0 * blocks * 9.0 * N * N);
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
+  if (d_ca) GDML_TRY(ctx_free(ctx, d_ca));
+  if (d_jv0) GDML_TRY(ctx_free(ctx, d_jv0));
   return GDML_OK;
 }

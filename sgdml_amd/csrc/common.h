@@ -234,7 +234,7 @@ int assemble_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int
                            int cyc_nb);
 int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist, const int32_t* d_colmap, int64_t j0,
                          int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg, int64_t i_end, int lower, double lam,
-                         int cyc_W, int cyc_rank, int cyc_nb);
+                         int cyc_W, int cyc_rank, int cyc_nb, const int32_t* h_colmap = nullptr);
 bool assemble_pts_applicable(const gdml_ctx* ctx);
 int assemble_pts_launch(gdml_ctx* ctx, double sig, int use_E, int64_t j0, int64_t n_j, double* K, int64_t ld, int64_t i_beg,
                         int64_t i_end, int lower, double lam);

@@ -67,6 +67,10 @@ def _oracle_case(N, M, kind):
     return xo, go, tp, sig, Ko, KoE
 
 
+def _oracle_case_m(N, M, kind):
+    return _oracle_case(N, M, kind)
+
+
 M_OF_N = {24: 4, 42: 3, 65: 3, 100: 2}
 # residency levels of the row-point image / G_j strip / x_j tables in LDS (asm.perm_level), the automatic choice, and the
 # two workgroup shapes (4 / 8 wavefronts), one LDS image buffer, one permutation per group, the slow store path
@@ -245,3 +249,36 @@ def test_predict_big_kernels_vs_oracle(n_atoms, n_train, n_query, n_perms):
         c.close()
     assert np.abs(F - F_ref).max() <= 1e-10 * np.abs(F_ref).max()
     assert np.abs(E - E_ref).max() <= 1e-10 * max(1.0, np.abs(E_ref).max())
+
+
+@pytest.mark.parametrize('N,M,kind,n_cols', [(42, 10, 'c3^3', 40), (100, 6, 'id', 30), (24, 12, 'c3xc2', 25), (65, 5, 'c3xc2', 20),
+                                             (12, 40, 'c3xc2', 90), (42, 9, 'id', 3)])
+def test_assemble_perm_compact_column_lists(N, M, kind, n_cols):
+    """Sparse index lists -- a few columns per training point, what the iterative solver's leverage sampling asks for
+    (iterative.py:372-379, :401-411): the general kernel packs the REQUESTED column atoms 64 to a strip (asm.perm_compact)
+    instead of computing all 3N columns of every point it touches.  Against the oracle (1e-12 of max|K|), bit-identical to
+    the dense strips, with and without energy-constraint rows / columns, with extra rows."""
+    from sgdml_amd import _lib
+
+    xo, go, tp, sig, Ko, KoE = _oracle_case_m(N, M, kind)
+    n = M * 3 * N
+    scale = np.abs(Ko).max()
+    rng = np.random.default_rng(N + M)
+    idx = np.sort(rng.choice(n, size=n_cols, replace=False))
+    idxE = np.sort(np.concatenate([idx, n + rng.choice(M, size=min(3, M), replace=False)]))
+    out = {}
+    for compact in (1, 0):
+        c = _lib.Context()
+        try:
+            c.set_option('asm.wave', 0)
+            c.set_option('asm.strip', 0)
+            c.set_option('asm.perm_compact', compact)
+            c.train_upload(xo, go, tp)
+            Kc = c.assemble_K(sig, False, idx=idx, alloc_extra_rows=len(idx), to_host=True)
+            KcE = c.assemble_K(sig, True, idx=idxE, to_host=True)
+            out[compact] = (Kc[:n], KcE)
+        finally:
+            c.close()
+    assert np.abs(out[1][0] - Ko[:, idx]).max() <= 1e-12 * scale
+    assert np.abs(out[1][1] - KoE[:, idxE]).max() <= 1e-12 * np.abs(KoE).max()
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
