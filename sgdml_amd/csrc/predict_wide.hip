@@ -6,7 +6,7 @@
 //   1. S = X_p X_q^T,  T = JA_p X_q^T                 (MP x B each, K = D)      gemm_nt_sub (chol.hip)
 //   2. per pair: |d|^2 = |x_q|^2 + |X_r|^2 - 2 S (clamped), a = T - X_r.JA_r, the Matern scalars; S <- w1, T <- b2;
 //      column sums of w1 and of the energy terms                                matern_pairs_kernel
-//   3. F_x = x_q * sum_r w1 - W1^T X_p - B2^T JA_p     (B x D, K = MP)           gemm_tn_sub (here)
+//   3. F_x = x_q * sum_r w1 - W1^T X_p - B2^T JA_p     (B x D, K = MP)           gemm_tn_split_kernel + reduce_tn_kernel (here)
 //   4. F = J_x^T F_x, E                                                          predict_epilogue_kernel (JS = 1)
 // Algorithmic flops 8 MP B D on v_mfma_f64_16x16x4_f64 against ~10 MP B D on the VALU for the wave kernel; the pair
 // scalars cost 4 x 8 MP B bytes of HBM traffic per call (written and read once each), processed in query chunks so
@@ -52,14 +52,36 @@ __device__ __forceinline__ void w_store(double* __restrict__ S, int tid, const d
   }
 }
 
-// C[m x n] -= A^T B,  A: nk x m (lda), B: nk x n (ldb), all row-major.  128 x 128 tiles, BK = 16, fp64 MFMA; LDS
-// image [k][128 + 16]: the operand read lane -> (i = l & 15, k = l >> 4) touches 16 consecutive doubles per k.
-__global__ void __launch_bounds__(256, 2) gemm_tn_sub_kernel(const double* __restrict__ A, int64_t lda,
-                                                             const double* __restrict__ B, int64_t ldb,
-                                                             double* __restrict__ C, int64_t ldc, int64_t m, int64_t n,
-                                                             int64_t nk) {
-  __shared__ __attribute__((aligned(16))) double lds[2][2][WBK * WP];
-  const int64_t row0 = (int64_t)blockIdx.y * WT, col0 = (int64_t)blockIdx.x * WT;
+// P_z[m x n] = A^T B over this split's share of the nk rows;  A: nk x m (lda), B: nk x n (ldb), row-major.  128 x 128 tiles,
+// 16 rows of A / B per k-tile, fp64 MFMA.  Both operand tiles are 16 x 128 blocks with contiguous rows: interior tiles move
+// them in 16-byte pieces (check-free global_load_dwordx4 from a wave-uniform base, ds_write_b128 into an unpadded [k][128]
+// image, one ds_read_b128 per PAIR of operand blocks -- the column-pair relabelling of syrk_tn_kernel, cg.hip).
+//
+// SPLIT-K: the back contraction of the prediction has a short output (queries x D: 16 x 7 tiles at configs[3]) and a very
+// long contraction (the M P table rows: 54 000), so one workgroup per tile leaves most of the chip idle (112 workgroups
+// for 512 slots: 17.8 of the 41 ms of a configs[3] PCG iteration, profiles/r04_cg_shape_kernels.txt).  Each of gridDim.z
+// workgroups per tile takes a contiguous share of the k-tiles and writes its partial tile; reduce_tn_kernel subtracts the
+// partials from C in a fixed order (deterministic: no atomics).
+__device__ __forceinline__ void w_load_u(const double* __restrict__ X, int64_t ld, int64_t k0, int64_t c0, const unsigned (&off)[4],
+                                         d2 (&r)[4]) {
+  typedef const __attribute__((address_space(1))) char* gcptr;
+  typedef const __attribute__((address_space(1))) d2* gd2ptr;
+  const uint64_t p = reinterpret_cast<uint64_t>(X + k0 * ld + c0);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+  gcptr b = (gcptr)(((uint64_t)hi << 32) | lo);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) r[s] = *(gd2ptr)(b + off[s]);
+}
+__device__ __forceinline__ void w_store16(double* __restrict__ S, int tid, const d2 (&r)[4]) {
+  d2* S2 = reinterpret_cast<d2*>(S);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) S2[tid + 256 * s] = r[s];
+}
+
+template <bool FULL>
+__device__ __forceinline__ void gemm_tn_tile(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                             double* __restrict__ Pz, int64_t m, int64_t n, int64_t nk, int64_t kt0, int64_t kt1,
+                                             int64_t row0, int64_t col0, double (*lds)[2][WBK * WT]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
@@ -68,50 +90,90 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_sub_kernel(const double* __res
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  const int64_t nt = (nk + WBK - 1) / WBK;
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int cidx = tid + 256 * s;
+    offA[s] = (unsigned)(((int64_t)(cidx >> 6) * lda + (cidx & 63) * 2) * 8);
+    offB[s] = (unsigned)(((int64_t)(cidx >> 6) * ldb + (cidx & 63) * 2) * 8);
+  }
+  const int64_t kt_full = FULL ? nk / WBK : 0;  // k-tiles that can be loaded without checks
   d2 ra[4], rb[4];
-  w_load(A, lda, nk, m, 0, row0, tid, ra);
-  w_load(B, ldb, nk, n, 0, col0, tid, rb);
-  w_store(lds[0][0], tid, ra);
-  w_store(lds[0][1], tid, rb);
-  __syncthreads();
-  for (int64_t kt = 0; kt < nt; ++kt) {
-    const int cur = (int)(kt & 1);
-    if (kt + 1 < nt) {
-      w_load(A, lda, nk, m, (kt + 1) * WBK, row0, tid, ra);
-      w_load(B, ldb, nk, n, (kt + 1) * WBK, col0, tid, rb);
+  auto load = [&](int64_t kt) {
+    if (kt < kt_full) {
+      w_load_u(A, lda, kt * WBK, row0, offA, ra);
+      w_load_u(B, ldb, kt * WBK, col0, offB, rb);
+    } else {
+      w_load(A, lda, nk, m, kt * WBK, row0, tid, ra);
+      w_load(B, ldb, nk, n, kt * WBK, col0, tid, rb);
     }
-    const double* As = lds[cur][0] + lk * WP + wm * 64 + li;
-    const double* Bs = lds[cur][1] + lk * WP + wn * 64 + li;
+  };
+  if (kt0 < kt1) {
+    load(kt0);
+    w_store16(lds[0][0], tid, ra);
+    w_store16(lds[0][1], tid, rb);
+  }
+  __syncthreads();
+  for (int64_t kt = kt0; kt < kt1; ++kt) {
+    const int cur = (int)((kt - kt0) & 1);
+    if (kt + 1 < kt1) load(kt + 1);
+    const d2* Ap = reinterpret_cast<const d2*>(lds[cur][0]) + lk * (WT / 2) + wm * 32 + li;
+    const d2* Bp = reinterpret_cast<const d2*>(lds[cur][1]) + lk * (WT / 2) + wn * 32 + li;
 #pragma unroll
     for (int ks = 0; ks < WBK; ks += 4) {
-      double a[4], bb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[ks * WP + i * 16];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bb[j] = Bs[ks * WP + j * 16];
+      const d2 a01 = Ap[ks * (WT / 2)], a23 = Ap[ks * (WT / 2) + 16];
+      const d2 b01 = Bp[ks * (WT / 2)], b23 = Bp[ks * (WT / 2) + 16];
+      const double a[4] = {a01.x, a01.y, a23.x, a23.y};
+      const double bb[4] = {b01.x, b01.y, b23.x, b23.y};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nt) {
-      w_store(lds[cur ^ 1][0], tid, ra);
-      w_store(lds[cur ^ 1][1], tid, rb);
+      if (ks == 8 && kt + 1 < kt1) {
+        w_store16(lds[cur ^ 1][0], tid, ra);
+        w_store16(lds[cur ^ 1][1], tid, rb);
+      }
     }
     __syncthreads();
   }
+  // accumulator (i, j), register r of lane (li, lk): row = 64 wm + 32 (i >> 1) + 2 (lk + 4 r) + (i & 1), column likewise with li
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t gc = col0 + wn * 64 + j * 16 + li;
+      const int64_t gc = col0 + wn * 64 + 32 * (j >> 1) + 2 * li + (j & 1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
-        if (gr < m && gc < n) C[gr * ldc + gc] -= acc[i][j][r];
+        const int64_t gr = row0 + wm * 64 + 32 * (i >> 1) + 2 * (lk + 4 * r) + (i & 1);
+        if (gr < m && gc < n) Pz[gr * n + gc] = acc[i][j][r];
       }
     }
+}
+
+// b_cols: columns of B that may be READ (its rows are padded to that many doubles; >= n)
+__global__ void __launch_bounds__(256, 2) gemm_tn_split_kernel(const double* __restrict__ A, int64_t lda,
+                                                               const double* __restrict__ B, int64_t ldb, int64_t b_cols,
+                                                               double* __restrict__ P, int64_t m, int64_t n, int64_t nk) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][WBK * WT];
+  const int64_t row0 = (int64_t)blockIdx.y * WT, col0 = (int64_t)blockIdx.x * WT;
+  const int64_t nt = (nk + WBK - 1) / WBK;
+  const int64_t kt0 = nt * blockIdx.z / gridDim.z, kt1 = nt * (blockIdx.z + 1) / gridDim.z;
+  double* Pz = P + (int64_t)blockIdx.z * m * n;
+  const bool aligned = (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0) && (lda % 2 == 0) &&
+                       (ldb % 2 == 0) && 16 * lda * 8 < ((int64_t)1 << 32) && 16 * ldb * 8 < ((int64_t)1 << 32);
+  if (aligned && row0 + WT <= m && col0 + WT <= b_cols)
+    gemm_tn_tile<true>(A, lda, B, ldb, Pz, m, n, nk, kt0, kt1, row0, col0, lds);
+  else
+    gemm_tn_tile<false>(A, lda, B, ldb, Pz, m, n, nk, kt0, kt1, row0, col0, lds);
+}
+
+// C[e] -= sum_z P[z][e], z in ascending order
+__global__ void __launch_bounds__(256) reduce_tn_kernel(const double* __restrict__ P, int64_t mn, int nz, double* __restrict__ C) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= mn) return;
+  double s = 0.0;
+  for (int z = 0; z < nz; ++z) s += P[(int64_t)z * mn + e];
+  C[e] -= s;
 }
 
 // rows padded with zeros to a pitch that is a multiple of 16 doubles: the NT GEMM then takes its interior fast path
@@ -265,15 +327,26 @@ int predict_wide_device(gdml_ctx* ctx, const double* d_xq, int64_t B, double* pa
     hipLaunchKernelGGL(query_norm_kernel, dim3(ceil_div(bc, 4)), dim3(256), 0, st, xq, bc, D, nx);
     hipLaunchKernelGGL(pad_rows_kernel, dim3(ceil_div(bc * Dp, 256)), dim3(256), 0, st, xq, bc, D, Dp, Qpad);
     // S = -X_p X_q^T, T = -JA_p X_q^T  (zero padding contributes nothing)
-    GDML_TRY(launch_gemm_nt_sub(ctx, st, Xpad, Dp, Qpad, Dp, S, Bc, MP, bc, Dp, 0));
-    GDML_TRY(launch_gemm_nt_sub(ctx, st, Jpad, Dp, Qpad, Dp, T, Bc, MP, bc, Dp, 0));
+    // one launch for both: [Xpad; Jpad] and [S; T] are contiguous stacks of 2 MP rows
+    GDML_TRY(launch_gemm_nt_sub(ctx, st, Xpad, Dp, Qpad, Dp, S, Bc, 2 * MP, bc, Dp, 0));
     hipLaunchKernelGGL(matern_pairs_kernel, dim3(ceil_div(bc, 256), nparts), dim3(256), 0, st, S, T, Bc, MP, bc, nx, nX, cX,
                        md.has_aE ? md.aE : nullptr, md.sig, rows_per, pw, pe);
     double* Fx = part_F + q0 * D;
     hipLaunchKernelGGL(fx_init_kernel, dim3((unsigned)bc), dim3(256), 0, st, xq, bc, D, pw, pe, nparts, Fx, part_E + q0);
-    dim3 grid((unsigned)ceil_div(D, WT), (unsigned)ceil_div(bc, WT));
-    hipLaunchKernelGGL(gemm_tn_sub_kernel, grid, dim3(256), 0, st, S, Bc, md.xp, (int64_t)D, Fx, (int64_t)D, bc, (int64_t)D, MP);
-    hipLaunchKernelGGL(gemm_tn_sub_kernel, grid, dim3(256), 0, st, T, Bc, md.jap, (int64_t)D, Fx, (int64_t)D, bc, (int64_t)D, MP);
+    // F_x -= W1^T X_p + B2^T JA_p as ONE contraction over the 2 MP stacked rows ([S; T] and [Xpad; Jpad] are contiguous),
+    // split over the table rows so that the launch fills the chip
+    {
+      const int64_t tiles = (int64_t)ceil_div(D, WT) * ceil_div(bc, WT), nt = (2 * MP + WBK - 1) / WBK;
+      int nz = (int)((3 * 512 + tiles - 1) / tiles);
+      if (nz > 32) nz = 32;
+      if ((int64_t)nz * 64 > nt) nz = (int)(nt / 64);  // at least 64 k-tiles per split
+      if (nz < 1) nz = 1;
+      double* Pp;
+      GDML_TRY(ctx_slot(ctx, 9, (int64_t)nz * bc * D * 8, &Pp));
+      dim3 grid((unsigned)ceil_div(D, WT), (unsigned)ceil_div(bc, WT), (unsigned)nz);
+      hipLaunchKernelGGL(gemm_tn_split_kernel, grid, dim3(256), 0, st, S, Bc, Xpad, (int64_t)Dp, (int64_t)Dp, Pp, bc, (int64_t)D, 2 * MP);
+      hipLaunchKernelGGL(reduce_tn_kernel, dim3(ceil_div(bc * D, 256)), dim3(256), 0, st, Pp, bc * D, nz, Fx);
+    }
     ctx->launch_counter += 7;
     HIP_CHECK(ctx, hipGetLastError());
   }

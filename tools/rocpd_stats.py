@@ -12,7 +12,7 @@ def main(path, out=None):
     rows = cur.execute("select name, start, end from kernels").fetchall() if 'name' in cols else []
     agg = {}
     for name, s, e in rows:
-        short = name.split('(')[0]
+        short = name.replace('(anonymous namespace)::', '').split('(')[0]
         a = agg.setdefault(short, [0, 0, 10**18, 0])
         d = e - s
         a[0] += 1
