@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) pcg_p_update_kernel(double* __restrict__ 
 }
 // alpha = rho / (p.Ap), q = -(A p):  x_out = x_in + alpha p,  r += alpha q,  and ||r||^2 of the updated residual: the last
 // workgroup to finish sums the partials and publishes the value to the host-mapped slot `rr_host` (and to rr_dev).
-__global__ void __launch_bounds__(256) pcg_xr_update_kernel(const double* __restrict__ x_in, double* __restrict__ x_out,
+__global__ void __launch_bounds__(256) pcg_xr_update_kernel(const double* x_in, double* x_out,  // the same vector at depth 0
                                                             double* __restrict__ r, const double* __restrict__ p,
                                                             const double* __restrict__ q,
                                                             const double* __restrict__ part_rho,
