@@ -739,11 +739,16 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   const size_t lds = perm_layout(N, P, W, NA, n_img, level >= 2, level >= 3, PG, &A, nq_list);
   int32_t *d_ca = nullptr, *d_jv0 = nullptr;
   if (nq_list) {
-    GDML_TRY(ctx_alloc(ctx, (void**)&d_ca, (int64_t)h_ca.size() * 4));
-    GDML_TRY(ctx_alloc(ctx, (void**)&d_jv0, (int64_t)h_jv0.size() * 4));
-    HIP_CHECK(ctx, hipMemcpyAsync(d_ca, h_ca.data(), h_ca.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(ctx, hipMemcpyAsync(d_jv0, h_jv0.data(), h_jv0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope with this call
+    // one allocation for both lists (freed below, after the launch)
+    GDML_TRY(ctx_alloc(ctx, (void**)&d_ca, (int64_t)(h_ca.size() + h_jv0.size()) * 4));
+    d_jv0 = d_ca + h_ca.size();
+    hipError_t e = hipMemcpyAsync(d_ca, h_ca.data(), h_ca.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_jv0, h_jv0.data(), h_jv0.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host vectors go out of scope with this call
+    if (e != hipSuccess) {
+      (void)ctx_free(ctx, d_ca);
+      return gdml_fail(ctx, GDML_ERR_HIP, "assemble_perm: column-atom list upload: %s", hipGetErrorString(e));
+    }
     A.calist = d_ca;
     A.strip_jv0 = d_jv0;
   }
@@ -774,6 +779,5 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   ctx->launch_counter++;
   HIP_CHECK(ctx, hipGetLastError());
   if (d_ca) GDML_TRY(ctx_free(ctx, d_ca));
-  if (d_jv0) GDML_TRY(ctx_free(ctx, d_jv0));
   return GDML_OK;
 }

@@ -85,7 +85,8 @@ struct DeviceArena {
   int64_t used = 0;
 };
 static DeviceArena g_arena[64];
-static const int64_t kArenaMinRequest = (int64_t)1 << 30;  // smaller buffers are cheap to allocate: hipMalloc
+static const int64_t kArenaMinRequest = (int64_t)4 << 30;  // the matrices; work buffers (<= ~3 GB by construction) stay with hipMalloc,
+                                                          // so a cached work slot can never sit on the arena when a matrix needs it
 
 static DeviceArena* arena_of(const gdml_ctx* ctx) { return (ctx->device >= 0 && ctx->device < 64) ? &g_arena[ctx->device] : nullptr; }
 
