@@ -28,6 +28,7 @@
 // more than 8 NA row atoms take several rounds).  Permutation rows are held one entry per lane and read with
 // v_readlane (wave-uniform index), so no inner loop has an index load in its dependency chain.
 #include "common.h"
+#include <type_traits>
 
 struct PermArgs {
   const double* XF;   // (M,N,N)
@@ -68,6 +69,19 @@ __device__ __forceinline__ int perm_at(int row0, int row1, int m) {
   return (m < 64) ? lo : hi;
 }
 
+// Global load that stays where it is written.  A plain load carried across loop iterations in a register is rewritten by
+// LLVM into a load at the point of use (InstCombine folds a PHI of loads into a load of a PHI of addresses), which turns
+// every software-prefetched operand back into load -> s_waitcnt vmcnt(0) -> use; a relaxed atomic load at wavefront scope is
+// the same global_load instruction (no cache-bypass bits) but is neither folded nor reordered.
+__device__ __forceinline__ double ldg_pin(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+template <bool PIN>
+__device__ __forceinline__ double ldg(const double* p) {
+  return PIN ? ldg_pin(p) : *p;
+}
+
 // inclusive scan inside segments of consecutive lanes; pos = position of the lane in its segment.  Only additions of
 // the segment's own terms (a scan over the whole wavefront and a difference would cancel: |d|^2 = 0 must stay 0)
 __device__ __forceinline__ double seg_incl_scan(double v, int pos) {
@@ -86,10 +100,16 @@ template <int W, int NA, bool IMG, bool GJS, bool JX, bool BIG>
 __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int T = 64 * W;
-#ifndef PERM_VU
-#define PERM_VU 3
-#endif
-  constexpr int VU = PERM_VU;  // iterations of the V-phase contractions whose loads are in flight together
+#ifndef PERM_ABL
+#define PERM_ABL 0  // timing-only ablation of the V phase (tools/asm_perm_vabl.sh): 1 no V3 tasks, 2 no V12 tasks, 4 V12 without
+#endif              // global loads, 8 V12 without LDS reads, 16 V12 without epilogue, 32 V3 without global loads, 64 V3 without LDS reads
+  // iterations per stage of the V-phase contractions (three stages of operands are in flight): fewer when more of the
+  // operands come from global memory and have to wait in registers
+  constexpr int VU3 = (IMG && !GJS) ? 2 : 3;
+  // Row-point image in LDS: the few global operands left (x_j, G_j) run through the three-buffer pipeline below.  Without
+  // it (large molecules) every operand is global and the pipeline loses (three 8-byte pinned loads per G vector instead of
+  // 16 + 8, twice the registers: N = 100 6.35 vs 5.34 ms): one stage at a time, all its loads up front.
+  constexpr bool PIPE = IMG;
   const int N = A.N, N3 = 3 * N, NN = N * N, P = A.P, NQ = A.NQ, PG = A.PG, npass = A.npass;
   const int SEG = BIG ? (N + 63) >> 6 : 1;  // 64-atom segments of a point (V12 passes of large molecules)
   const int ppp = BIG ? 1 : 64 / N;          // whole column points per V12 pass (N <= 64)
@@ -168,22 +188,15 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
   }
   int cur = 0;
 
-  // output columns of the lane (general store path) and of the transposed rows (fast path)
-  int outcol[3];
-#pragma unroll
-  for (int be = 0; be < 3; ++be) {
-    int oc = -1;
-    if (cvalid) oc = A.colmap ? A.colmap[(int64_t)jv * N3 + 3 * b + be] : (int)A.col0 + jv * N3 + 3 * b + be;
-    outcol[be] = oc;
+  // V12 passes this strip needs: dense strips touch 2 .. NQ column points (a strip of 64 atoms starts anywhere in a point)
+  int npass_e = npass;
+  if (!A.calist) {
+    int64_t last = (64 * s + 63) / N;
+    if (last > A.n_j - 1) last = A.n_j - 1;
+    int nq_used = (int)(last - jv0) + 1;
+    if (nq_used > NQ) nq_used = NQ;
+    npass_e = BIG ? nq_used * SEG : (nq_used + ppp - 1) / ppp;
   }
-  int tcol[3], tpt[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int64_t c = 192 * s + 64 * t + lane;  // relative to col0
-    tcol[t] = (c < n_ca * 3) ? (int)(A.col0 + c) : -1;
-    tpt[t] = (int)(c / N3);
-  }
-
   constexpr bool PF_REG = IMG && NA == 3;  // next image through registers underneath the first V phase (when they are there)
   constexpr int NPF = PF_REG ? (4 * (W * NA) * (W * NA) + T - 1) / T : 1;
   const int n_rounds = (N + W * NA - 1) / (W * NA);
@@ -191,15 +204,6 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
 
   for (int64_t i = i_lo; i < i_hi; ++i) {
     const int64_t row0 = i * N3;  // first row of the point in the full matrix
-    // transposed-row stores: which of the lane's three columns are written for this row point, and where the matrix
-    // diagonal crosses them (lower form: + lam)
-    bool tok[3];
-    int dcol[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      tok[t] = tcol[t] >= 0 && (!lower || tpt[t] <= i);
-      dcol[t] = lower ? (int)((int64_t)tcol[t] - row0) : -1;
-    }
     const double lamv = lower ? A.lam : 0.0;
     const int64_t lrow0 = row0 - A.i_beg * N3;  // ... in the stored matrix (plain layout)
     int coff0 = 0;
@@ -261,84 +265,137 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
               for (int e = tid; e < 4 * NN; e += T) IMn[e] = (e < 3 * NN) ? gi[e] : xi[e - 3 * NN];
             }
           }
-          const int ntask = (A.dbg & 2) ? 0 : npg * (npass + 1);
-          for (int t = w; t < ntask; t += W) {
-            const int pl = t / (npass + 1), kind = t - pl * (npass + 1);
-            const int p = g0 + pl;
-            if (kind < npass) {
-              // ---- V12: lane = (column point qq, row atom a); whole points per pass (N <= 64) or 64-atom segments
-              int qq, a, seg = 0;
-              if (!BIG) {
-                const int ql = lane / N;
-                qq = kind * ppp + ql;
-                a = lane - ql * N;
-                if (ql >= ppp) qq = NQ;  // idle lanes
-              } else {
-                qq = kind / SEG;
-                seg = kind - qq * SEG;
-                a = 64 * seg + lane;
-              }
-              const int jvq = jv0 + qq;
-              const bool ok = qq < NQ && a < N && jvq < A.n_j;
-              const int pr0 = (lane < N) ? permS[p * N + lane] : 0;
-              const int pr1 = (BIG && lane + 64 < N) ? permS[p * N + 64 + lane] : 0;
-              const int ac = ok ? a : 0, qc = ok ? qq : 0;
-              const int pa = permS[p * N + ac];
-              const int jvc = (jvq < A.n_j) ? jvq : (int)A.n_j - 1;
-              const int64_t jq = A.jlist ? (int64_t)A.jlist[jvc] : A.j0 + jvc;
-              const double* xjg = A.XF + jq * NN + pa;  // x_j[pair(pi a, .)] (global; JX: the LDS copy)
-              const double* xjl = Xq + qc * NN + pa;
-              double v0 = 0.0, v1 = 0.0, v2 = 0.0, nn = 0.0;
-              // VU iterations at a time: all their operand loads are issued before the first multiply-add.  (The compiler
-              // refuses to unroll a loop with a run-time trip count around v_readlane -- a convergent operation rules out
-              // the remainder loop -- and then waits for every global x_j load before it issues the next one: 900 cycles
-              // per iteration, 80 % of the kernel at N = 42, P = 27: profiles/r04_assemble_perm_ablation.txt.)  The tail
-              // re-reads entry N - 1 and contributes zero.
-              // x_j is the one operand that may come from global memory (levels below 3): it runs two chunks ahead
-              double xa[VU], xb[VU], xc[VU];
-              auto ld_xj = [&](int m0, double (&dst)[VU]) {
+          // ---- V12 for a batch of PB permutations of the group (pl0 ...): lane = (column point qq, row atom a), whole
+          // points per pass (N <= 64) or 64-atom segments.  x_i and G_i(a, m) do not depend on the permutation: they
+          // are read once per m for the whole batch (the V phase is bound by LDS throughput, not by arithmetic:
+          // profiles/r04_assemble_perm_ablation.txt); per permutation only x_j[pair(pi a, pi m)] differs.
+          auto v12_batch = [&](auto PBc, int kind, int pl0) {
+            constexpr int PB = decltype(PBc)::value;
+            constexpr int VU12 = (PB >= 4) ? 2 : 3;  // iterations per stage
+            int qq, a, seg = 0;
+            if (!BIG) {
+              const int ql = lane / N;
+              qq = kind * ppp + ql;
+              a = lane - ql * N;
+              if (ql >= ppp) qq = NQ;  // idle lanes
+            } else {
+              qq = kind / SEG;
+              seg = kind - qq * SEG;
+              a = 64 * seg + lane;
+            }
+            const int jvq = jv0 + qq;
+            const bool ok = qq < NQ && a < N && jvq < A.n_j;
+            const int ac = ok ? a : 0, qc = ok ? qq : 0;
+            const int jvc = (jvq < A.n_j) ? jvq : (int)A.n_j - 1;
+            const int64_t jq = A.jlist ? (int64_t)A.jlist[jvc] : A.j0 + jvc;
+            const double* const xjg = A.XF + jq * NN;  // x_j (global; JX: the LDS copy)
+            const double* const xjl = Xq + qc * NN;
+            int pr0[PB], pr1[PB], pa[PB];
 #pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                  const int m = (m0 + u < N) ? m0 + u : N - 1;
-                  const int pm = perm_at<BIG>(pr0, pr1, m);
-                  dst[u] = JX ? xjl[pm * N] : xjg[pm * N];
+            for (int bb = 0; bb < PB; ++bb) {
+              const int plb = (pl0 + bb < npg) ? pl0 + bb : npg - 1;  // short last batch: repeats its last permutation
+              const int p = g0 + plb;
+              pr0[bb] = (lane < N) ? permS[p * N + lane] : 0;
+              pr1[bb] = (BIG && lane + 64 < N) ? permS[p * N + 64 + lane] : 0;
+              pa[bb] = permS[p * N + ac];
+            }
+            double v[PB][3], nn[PB];
+#pragma unroll
+            for (int bb = 0; bb < PB; ++bb) v[bb][0] = v[bb][1] = v[bb][2] = nn[bb] = 0.0;
+            // The contraction over m runs in stages of VU12 iterations through three operand buffers: the GLOBAL operands
+            // of stage s + 2 are requested (ldg_pin) before the multiply-adds of stage s, so a global round trip is
+            // covered by two stages of work; LDS operands are read inside the stage.  (History: the compiler refuses to
+            // unroll a loop with a run-time trip count around v_readlane, and it moves plain prefetch loads back to
+            // their use.)  Past-the-end iterations re-read entry N - 1 and are multiplied by zero.
+            struct V12Buf {
+              double xj[JX ? 1 : PB][JX ? 1 : VU12];
+              double xi[IMG ? 1 : VU12];
+              double g[IMG ? 1 : VU12][3];
+            };
+            auto ld12 = [&](int m0, V12Buf& B) {
+              if ((JX && IMG) || (PERM_ABL & 4)) return;
+#pragma unroll
+              for (int u = 0; u < VU12; ++u) {
+                const int m = (m0 + u < N) ? m0 + u : N - 1;
+                if (!JX) {
+#pragma unroll
+                  for (int bb = 0; bb < PB; ++bb) B.xj[bb][u] = ldg<PIPE>(xjg + pa[bb] + perm_at<BIG>(pr0[bb], pr1[bb], m) * N);
                 }
-              };
-              ld_xj(0, xa);
-              ld_xj(VU, xb);
-              for (int m0 = 0; m0 < N; m0 += VU) {
-                double xi_[VU], g_[VU][3];
-                ld_xj(m0 + 2 * VU, xc);
-#pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                  const int m = (m0 + u < N) ? m0 + u : N - 1;
-                  xi_[u] = IMG ? SX[m * N + ac] : XFi[m * N + ac];
-                  const double* g = IMG ? SG + (m * N + ac) * 3 : GDi + (m * N + ac) * 3;
-                  g_[u][0] = g[0];
-                  g_[u][1] = g[1];
-                  g_[u][2] = g[2];
-                }
-#pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                  const double d = (m0 + u < N) ? xi_[u] - xa[u] : 0.0;
-                  nn += d * d;
-                  v0 += d * g_[u][0];
-                  v1 += d * g_[u][1];
-                  v2 += d * g_[u][2];
-                  xa[u] = xb[u];
-                  xb[u] = xc[u];
+                if (!IMG) {
+                  B.xi[u] = XFi[m * N + ac];
+                  const double* g = GDi + (m * N + ac) * 3;
+                  B.g[u][0] = g[0];
+                  B.g[u][1] = g[1];
+                  B.g[u][2] = g[2];
                 }
               }
-              if (!ok) nn = 0.0;
+            };
+            auto comp12 = [&](int m0, const V12Buf& B) {
+              double xi_[VU12], g_[VU12][3], xj_[PB][VU12];
+#pragma unroll
+              for (int u = 0; u < VU12; ++u) {
+                const int m = (m0 + u < N) ? m0 + u : N - 1;
+                xi_[u] = (PERM_ABL & 8) ? 1.0 + m : (IMG ? SX[m * N + ac] : B.xi[u]);
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) g_[u][c3] = (PERM_ABL & 8) ? 0.5 * m : (IMG ? SG[(m * N + ac) * 3 + c3] : B.g[u][c3]);
+#pragma unroll
+                for (int bb = 0; bb < PB; ++bb)
+                  xj_[bb][u] = (PERM_ABL & 4) ? 0.25 * perm_at<BIG>(pr0[bb], pr1[bb], m)
+                                              : (JX ? xjl[pa[bb] + perm_at<BIG>(pr0[bb], pr1[bb], m) * N] : B.xj[bb][u]);
+              }
+#pragma unroll
+              for (int u = 0; u < VU12; ++u) {
+                // past-the-end iterations: multiplied by zero, not selected -- a select on the wave-uniform condition
+                // becomes a branch around the operand loads, and with branches in the body LLVM sinks every stage's
+                // multiply-adds below the last stage's loads
+                const double lv = (m0 + u < N) ? 1.0 : 0.0;
+#pragma unroll
+                for (int bb = 0; bb < PB; ++bb) {
+                  const double d = (xi_[u] - xj_[bb][u]) * lv;
+                  nn[bb] += d * d;
+                  v[bb][0] += d * g_[u][0];
+                  v[bb][1] += d * g_[u][1];
+                  v[bb][2] += d * g_[u][2];
+                }
+              }
+            };
+            if (!PIPE) {
+              V12Buf B0;
+              for (int m0 = 0; m0 < N; m0 += VU12) {
+                ld12(m0, B0);
+                comp12(m0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            } else {
+              V12Buf B0, B1, B2;
+              ld12(0, B0);
+              ld12(VU12, B1);
+              for (int m0 = 0; m0 < N; m0 += 3 * VU12) {
+                ld12(m0 + 2 * VU12, B2);
+                comp12(m0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                ld12(m0 + 3 * VU12, B0);
+                comp12(m0 + VU12, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                ld12(m0 + 4 * VU12, B1);
+                comp12(m0 + 2 * VU12, B2);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#pragma unroll
+            for (int bb = 0; bb < PB; ++bb) {
+              const int pl = pl0 + bb;
+              if (pl >= npg) break;  // wave-uniform
+              if ((PERM_ABL & 16) && v[bb][0] + nn[bb] != 1.2345e-300) break;
               if (ok) {
                 double* dst = vs + ((pl * NQ + qq) * N + a) * 3;
-                dst[0] = v0;
-                dst[1] = v1;
-                dst[2] = v2;
+                dst[0] = v[bb][0];
+                dst[1] = v[bb][1];
+                dst[2] = v[bb][2];
               }
               // |d_p|^2 of every point of the pass (segmented sum over its N lanes), then the Matern scalars
               if (!BIG) {
-                const double nrm2 = seg_incl_scan(nn, a);  // complete in the lane of the point's last atom
+                const double nrm2 = seg_incl_scan(ok ? nn[bb] : 0.0, a);  // complete in the lane of the point's last atom
                 if (ok && a == N - 1) {
                   const double nrm = sqrt5 * sqrt(0.5 * nrm2);
                   const double ex = exp(-nrm * inv_sig);
@@ -349,10 +406,29 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
                   sc[2] = -e_fact * (nrm + sig) * ex;
                 }
               } else {
-                const double tot = wave_sum(nn);
+                const double tot = wave_sum(ok ? nn[bb] : 0.0);
                 if (lane == 0 && qq < NQ) part[(pl * NQ + qq) * SEG + seg] = tot;
               }
+            }
+          };
+          // Tasks of the group, longest first: npass_e x nbatch batched V12 tasks, then one V3 task per permutation
+          // (batches of 2 / 4 permutations per task measured: N = 42, P = 27 32.7 / 38.5 ms against 31.4 with one -- fewer,
+          // longer tasks leave wavefronts idle and put four norm epilogues in a row on the critical path)
+          const int PBG = 1;
+          const int nbatch = (npg + PBG - 1) / PBG;
+          const int nv12 = npass_e * nbatch;
+          const int ntask = (A.dbg & 2) ? 0 : nv12 + npg;
+          for (int t = w; t < ntask; t += W) {
+            if ((PERM_ABL & 1) && t >= nv12) continue;
+            if ((PERM_ABL & 2) && t < nv12) continue;
+            if (t < nv12) {
+              const int kind = t / nbatch, pl0 = (t - kind * nbatch) * PBG;
+              if (PBG == 4) v12_batch(std::integral_constant<int, 4>{}, kind, pl0);
+              else if (PBG == 2) v12_batch(std::integral_constant<int, 2>{}, kind, pl0);
+              else v12_batch(std::integral_constant<int, 1>{}, kind, pl0);
             } else {
+              const int pl = t - nv12;
+              const int p = g0 + pl;
               // ---- V3: lane = column atom (j, b)
               const int pi0 = (lane < N) ? pinvS[p * N + lane] : 0;
               const int pi1 = (BIG && lane + 64 < N) ? pinvS[p * N + 64 + lane] : 0;
@@ -361,44 +437,80 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
               const double* gdj = A.GD + ((int64_t)jpt * NN + b) * 3;
               double u0 = 0.0, u1 = 0.0, u2 = 0.0;
               double d00 = 0.0, d01 = 0.0, d02 = 0.0, d10 = 0.0, d11 = 0.0, d12 = 0.0, d20 = 0.0, d21 = 0.0, d22 = 0.0;
-              double xa[VU], xb[VU], xc[VU];
-              auto ld_xj = [&](int m0, double (&dst)[VU]) {
+              struct V3Buf {
+                double xj[JX ? 1 : VU3];
+                double r[GJS ? 1 : VU3][3];
+                double xi[IMG ? 1 : VU3];
+                double gi[IMG ? 1 : VU3][3];
+              };
+              auto ld3 = [&](int m0, V3Buf& B) {
+                if ((JX && GJS && IMG) || (PERM_ABL & 32)) return;
 #pragma unroll
-                for (int u = 0; u < VU; ++u) {
+                for (int u = 0; u < VU3; ++u) {
                   const int mp = (m0 + u < N) ? m0 + u : N - 1;
-                  dst[u] = JX ? XjS[mp * 64 + lane] : xfj[mp * N];
+                  if (!JX) B.xj[u] = ldg<PIPE>(xfj + mp * N);
+                  if (!GJS) {
+                    B.r[u][0] = ldg<PIPE>(gdj + mp * N3);
+                    B.r[u][1] = ldg<PIPE>(gdj + mp * N3 + 1);
+                    B.r[u][2] = ldg<PIPE>(gdj + mp * N3 + 2);
+                  }
+                  if (!IMG) {
+                    const int mi = perm_at<BIG>(pi0, pi1, mp);
+                    B.xi[u] = XFi[mi * N + ap];
+                    const double* gi = GDi + (mi * N + ap) * 3;
+                    B.gi[u][0] = gi[0];
+                    B.gi[u][1] = gi[1];
+                    B.gi[u][2] = gi[2];
+                  }
                 }
               };
-              ld_xj(0, xa);
-              ld_xj(VU, xb);
-              for (int m0 = 0; m0 < N; m0 += VU) {
-                double xi_[VU], r_[VU][3], gi_[VU][3];
-                ld_xj(m0 + 2 * VU, xc);
+              auto comp3 = [&](int m0, const V3Buf& B) {
+                double xj_[VU3], xi_[VU3], r_[VU3][3], gi_[VU3][3];
 #pragma unroll
-                for (int u = 0; u < VU; ++u) {
+                for (int u = 0; u < VU3; ++u) {
                   const int mp = (m0 + u < N) ? m0 + u : N - 1;
                   const int mi = perm_at<BIG>(pi0, pi1, mp);
-                  xi_[u] = IMG ? SX[mi * N + ap] : XFi[mi * N + ap];
-                  const double* rj = GJS ? GjS + (mp * 64 + lane) * 3 : gdj + mp * N3;
-                  const double* gi = IMG ? SG + (mi * N + ap) * 3 : GDi + (mi * N + ap) * 3;
+                  xj_[u] = (PERM_ABL & 32) ? 0.25 * mi : (JX ? XjS[mp * 64 + lane] : B.xj[u]);
+                  xi_[u] = (PERM_ABL & 64) ? 1.0 + mi : (IMG ? SX[mi * N + ap] : B.xi[u]);
 #pragma unroll
                   for (int c3 = 0; c3 < 3; ++c3) {
-                    r_[u][c3] = rj[c3];
-                    gi_[u][c3] = gi[c3];
+                    r_[u][c3] = (PERM_ABL & 32) ? 0.125 * mi : (GJS ? GjS[(mp * 64 + lane) * 3 + c3] : B.r[u][c3]);
+                    gi_[u][c3] = (PERM_ABL & 64) ? 0.5 * mi : (IMG ? SG[(mi * N + ap) * 3 + c3] : B.gi[u][c3]);
                   }
                 }
 #pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                  const bool live = m0 + u < N;
-                  const double d = live ? xi_[u] - xa[u] : 0.0;
-                  const double r0 = r_[u][0], r1 = r_[u][1], r2 = r_[u][2];
-                  const double g0v = live ? gi_[u][0] : 0.0, g1v = live ? gi_[u][1] : 0.0, g2v = live ? gi_[u][2] : 0.0;
+                for (int u = 0; u < VU3; ++u) {
+                  const double lv = (m0 + u < N) ? 1.0 : 0.0;  // every product below has a factor r
+                  const double d = xi_[u] - xj_[u];
+                  const double r0 = r_[u][0] * lv, r1 = r_[u][1] * lv, r2 = r_[u][2] * lv;
+                  const double g0v = gi_[u][0], g1v = gi_[u][1], g2v = gi_[u][2];
                   u0 += d * r0; u1 += d * r1; u2 += d * r2;
                   d00 += g0v * r0; d01 += g0v * r1; d02 += g0v * r2;
                   d10 += g1v * r0; d11 += g1v * r1; d12 += g1v * r2;
                   d20 += g2v * r0; d21 += g2v * r1; d22 += g2v * r2;
-                  xa[u] = xb[u];
-                  xb[u] = xc[u];
+                }
+              };
+              if (!PIPE) {
+                V3Buf B0;
+                for (int m0 = 0; m0 < N; m0 += VU3) {
+                  ld3(m0, B0);
+                  comp3(m0, B0);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              } else {
+                V3Buf B0, B1, B2;
+                ld3(0, B0);
+                ld3(VU3, B1);
+                for (int m0 = 0; m0 < N; m0 += 3 * VU3) {
+                  ld3(m0 + 2 * VU3, B2);
+                  comp3(m0, B0);
+                  __builtin_amdgcn_sched_barrier(0);
+                  ld3(m0 + 3 * VU3, B0);
+                  comp3(m0 + VU3, B1);
+                  __builtin_amdgcn_sched_barrier(0);
+                  ld3(m0 + 4 * VU3, B1);
+                  comp3(m0 + 2 * VU3, B2);
+                  __builtin_amdgcn_sched_barrier(0);
                 }
               }
               double* dst = ud + pl * 12 * 64 + lane;
@@ -506,8 +618,34 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
         __syncthreads();  // V-phase results of this group are free
       }
 
-      // ---- write the rows of this round: three rows (one row atom) per LDS round trip
+      // ---- write the rows of this round: three rows (one row atom) per LDS round trip.
+      // The per-lane constants of the stores (columns, diagonal crossing, LDS addresses) are recomputed here from an
+      // opaque copy of the lane index: kept live across the V and O phases they end up in scratch, and a scratch reload
+      // between two global stores has to wait (vmcnt counts both) for the stores before it -- the store stream ran
+      // one store at a time.
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
       double* const trw = tr + w * 3 * 192;
+      int outcol[3] = {-1, -1, -1};  // output columns of the lane (general store path)
+      int tcol[3] = {-1, -1, -1};    // ... of the transposed rows (fast path), relative to column 0
+      bool tok[3] = {false, false, false};
+      int dcol[3] = {-1, -1, -1};    // where the matrix diagonal crosses them (lower form: + lam)
+      if (A.fast_store) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int64_t c = 192 * s + 64 * t + lane_s;  // relative to col0
+          tcol[t] = (c < n_ca * 3) ? (int)(A.col0 + c) : -1;
+          const int tpt = (int)((unsigned)c / (unsigned)N3);
+          tok[t] = tcol[t] >= 0 && (!lower || tpt <= i);
+          dcol[t] = lower ? (int)((int64_t)tcol[t] - row0) : -1;
+        }
+      }
+      if (!A.fast_store || A.use_E) {
+        const int bs = (lane_s == lane) ? b : 0;  // (always b: ties the loads below to this point of the program)
+#pragma unroll
+        for (int be = 0; be < 3; ++be)
+          if (cvalid) outcol[be] = A.colmap ? A.colmap[(int64_t)jv * N3 + 3 * bs + be] : (int)A.col0 + jv * N3 + 3 * bs + be;
+      }
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
         const int a = (r * NA + k) * W + w;
@@ -516,7 +654,7 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
 #pragma unroll
             for (int al = 0; al < 3; ++al) {
 #pragma unroll
-              for (int be = 0; be < 3; ++be) trw[al * 192 + 3 * lane + be] = lower ? -acc[k][al][be] : acc[k][al][be];
+              for (int be = 0; be < 3; ++be) trw[al * 192 + 3 * lane_s + be] = lower ? -acc[k][al][be] : acc[k][al][be];
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
@@ -524,7 +662,7 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
 #pragma unroll
             for (int al = 0; al < 3; ++al)
 #pragma unroll
-              for (int t = 0; t < 3; ++t) val[al][t] = trw[al * 192 + 64 * t + lane];
+              for (int t = 0; t < 3; ++t) val[al][t] = trw[al * 192 + 64 * t + lane_s];
 #pragma unroll
             for (int al = 0; al < 3; ++al) {
               const int rr = 3 * a + al;
