@@ -109,6 +109,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   asm.perm_i_chunk (16) its shape: image buffers, permutations per group, row atoms per wavefront, transposed
  *                         full-line stores, row points per workgroup
  *   asm.perm_compact (1)  index-list columns: strips of the REQUESTED column atoms instead of all atoms of every point touched
+ *   asm.perm_lds_rows (1) permutation entries from the LDS copy for 64 < N <= 128 (always beyond 128 atoms); 0 = two lane-held rows (A/B)
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
  *   gemm.nt_c (0)         non-temporal loads / stores of the C tile (after rocBLAS's Tensile kernel for this shape:
  *                         profiles/r03_vendor_kernels.txt; no gain measured)

@@ -17,7 +17,7 @@
 //
 // The kernels live in their own files: assemble_strip.hip (P = 1, 11 <= N <= 21, all columns: the benchmark path),
 // assemble_wave.hip (P = 1, N <= 21: column subsets, row-cyclic shares), assemble_pts.hip (8 <= N <= 24 with a permutation
-// group, dense columns), assemble_perm.hip (everything else: any group, N <= GDML_MAX_ATOMS).  This file resolves the
+// group, dense columns), assemble_perm.hip (everything else: any group, any N).  This file resolves the
 // column selection (train.py:1335-1407), owns the matrix buffer, dispatches, and carries the energy-constraint columns.
 #include "common.h"
 
@@ -105,6 +105,61 @@ __global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
   }
   if (tid < N3) A.K[(i * N3 + tid) * A.ld + col] = out0;
   if (tid + T < N3) A.K[(i * N3 + tid + T) * A.ld + col] = out1;
+  if (tid == 0) A.K[(A.M * N3 + i) * A.ld + col] = ee;
+}
+
+// The same columns for molecules beyond the kernel above (3N > 512, or descriptors that do not fit its LDS tables): nothing
+// staged but the P weights; every output element is summed by one thread, outermost loop over the outputs.
+__global__ void __launch_bounds__(256) ecol_big_kernel(EColArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int N = A.N, D = A.D, N3 = 3 * N;
+  double* wS = smem;       // P
+  double* red = wS + A.P;  // 32
+  const int tid = threadIdx.x, T = blockDim.x, nwaves = T >> 6;
+  const int64_t jj = A.jj_list[blockIdx.x];
+  const int64_t col = A.out_cols[blockIdx.x];
+  const int64_t i = (int64_t)blockIdx.y + A.i0;
+  const double* xq = A.x + jj * D;
+  const double* xi = A.x + i * D;
+  const double* gi = A.g + i * 3 * (int64_t)D;
+  const double sig = A.sig, inv_sig = 1.0 / sig;
+  const double sqrt5 = 2.23606797749978969641;
+  const double e_fact = 5.0 / (3.0 * sig * sig * sig);
+  double ee = 0.0;
+  for (int p = 0; p < A.P; ++p) {
+    const int32_t* tp = A.tp + (size_t)p * D;
+    double part = 0.0;
+    for (int k = tid; k < D; k += T) {
+      const double dk = xq[k] - xi[tp[k]];
+      part += dk * dk;
+    }
+    const double nrm2 = block_sum(part, red, tid, nwaves);
+    const double nrm = sqrt5 * sqrt(nrm2);
+    const double ex = exp(-nrm * inv_sig);
+    if (tid == 0) wS[p] = e_fact * (nrm + sig) * ex;
+    ee -= (1.0 + (nrm * inv_sig) * (1.0 + nrm / (3.0 * sig))) * ex;
+  }
+  __syncthreads();
+  for (int t = tid; t < N3; t += T) {
+    const int bb = t / 3, be = t - 3 * bb;
+    double out = 0.0;
+    for (int p = 0; p < A.P; ++p) {
+      const int32_t* tp = A.tp + (size_t)p * D;
+      const int32_t* perm = A.perm + (size_t)p * N;
+      const int ap = A.pinv[(size_t)p * N + bb];
+      double s = 0.0;
+      for (int m = 0; m < N; ++m) {
+        if (m == ap) continue;
+        const int q = perm[m];
+        const double gv = gi[pair_idx(bb, q) * 3 + be];
+        const int kk = pair_idx(ap, m);
+        const double dk = xq[kk] - xi[tp[kk]];
+        s += dk * (bb < q ? gv : -gv);
+      }
+      out -= wS[p] * s;
+    }
+    A.K[(i * N3 + t) * A.ld + col] = out;
+  }
   if (tid == 0) A.K[(A.M * N3 + i) * A.ld + col] = ee;
 }
 
@@ -274,24 +329,25 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
                                 dense ? nullptr : colmap.data());
   }
   if (rc == GDML_OK && !e_pts.empty()) {
-    if (N3 > 512) rc = gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "E-constraint columns need 3N <= 512");
-    else {
-      EColArgs E;
-      E.x = ts.x; E.g = ts.g; E.tp = ts.tp; E.perm = ts.perm; E.pinv = ts.pinv;
-      E.M = M; E.N = N; E.D = ts.D; E.P = ts.P; E.sig = sig;
-      E.jj_list = d_ep; E.out_cols = d_ec; E.K = ctx->K; E.ld = ld;
-      size_t lds = (size_t)(2 * ts.D + 32) * 8;
-      hipFuncSetAttribute((const void*)ecol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds);
-      for (int64_t i0 = 0; i0 < M; i0 += 65535) {  // grid.y limit
-        E.i0 = i0;
-        const int64_t ny = (M - i0 < 65535) ? M - i0 : 65535;
-        hipLaunchKernelGGL(ecol_kernel, dim3((unsigned)e_pts.size(), (unsigned)ny), dim3(256), lds, ctx->stream, E);
-        ctx->launch_counter++;
-      }
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "ecol launch: %s", hipGetErrorString(e));
+    EColArgs E;
+    E.x = ts.x; E.g = ts.g; E.tp = ts.tp; E.perm = ts.perm; E.pinv = ts.pinv;
+    E.M = M; E.N = N; E.D = ts.D; E.P = ts.P; E.sig = sig;
+    E.jj_list = d_ep; E.out_cols = d_ec; E.K = ctx->K; E.ld = ld;
+    // two outputs per thread and the descriptor tables in LDS, or (large molecules) the table-free kernel
+    const bool small = N3 <= 512 && (size_t)(2 * ts.D + 32) * 8 <= (size_t)160 * 1024;
+    const size_t lds = small ? (size_t)(2 * ts.D + 32) * 8 : (size_t)(ts.P + 32) * 8;
+    if (small) hipFuncSetAttribute((const void*)ecol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else hipFuncSetAttribute((const void*)ecol_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int64_t i0 = 0; i0 < M; i0 += 65535) {  // grid.y limit
+      E.i0 = i0;
+      const int64_t ny = (M - i0 < 65535) ? M - i0 : 65535;
+      const dim3 grid((unsigned)e_pts.size(), (unsigned)ny);
+      if (small) hipLaunchKernelGGL(ecol_kernel, grid, dim3(256), lds, ctx->stream, E);
+      else hipLaunchKernelGGL(ecol_big_kernel, grid, dim3(256), lds, ctx->stream, E);
+      ctx->launch_counter++;
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "ecol launch: %s", hipGetErrorString(e));
   }
   if (rc == GDML_OK) rc = phase_end(ctx, "assemble");
   if (d_jlist) ctx_free(ctx, d_jlist);

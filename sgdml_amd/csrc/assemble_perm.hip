@@ -60,11 +60,14 @@ struct PermArgs {
 };
 
 
-// entry m of a permutation row held one entry per lane (row0: 0..63, row1: 64..127, only for BIG molecules); m is
-// wave-uniform.  Branch-free: a branch here keeps the compiler from unrolling / pipelining the loops around it.
-template <bool BIG>
-__device__ __forceinline__ int perm_at(int row0, int row1, int m) {
-  if (!BIG) return __builtin_amdgcn_readlane(row0, m);
+// entry m of a permutation row; m is wave-uniform.  BIG = 0 (N <= 64) / 1 (N <= 128): the row is held one entry per lane
+// (row0: 0..63, row1: 64..127) and read with v_readlane -- no index load in the dependency chain of an inner loop.  Branch-free:
+// a branch here keeps the compiler from unrolling / pipelining the loops around it.  BIG = 2 (any N): a broadcast read of the
+// row's LDS copy (molecules beyond 128 atoms; the reference has no size limit, train.py:97-302).
+template <int BIG>
+__device__ __forceinline__ int perm_at(int row0, int row1, const int* rowS, int m) {
+  if (BIG == 2) return rowS[m];
+  if (BIG == 0) return __builtin_amdgcn_readlane(row0, m);
   const int lo = __builtin_amdgcn_readlane(row0, m & 63), hi = __builtin_amdgcn_readlane(row1, m & 63);
   return (m < 64) ? lo : hi;
 }
@@ -93,10 +96,11 @@ __device__ __forceinline__ double seg_incl_scan(double v, int pos) {
   return v;
 }
 
-// W: wavefronts per workgroup; NA: row atoms per wavefront and round (W NA >= N: one round); BIG: N > 64.
+// W: wavefronts per workgroup; NA: row atoms per wavefront and round (W NA >= N: one round); BIG: 0 N <= 64, 1 N <= 128,
+// 2 any N (permutation entries from LDS instead of lane-held rows).
 // Shapes built: (W, NA) = (4, 6): N <= 24, two independent workgroups per CU when the LDS allows; (8, 3): N <= 24, one
 // workgroup; (8, 6): N <= 48 in one round, larger molecules in several.
-template <int W, int NA, bool IMG, bool GJS, bool JX, bool BIG>
+template <int W, int NA, bool IMG, bool GJS, bool JX, int BIG>
 __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int T = 64 * W;
@@ -291,12 +295,14 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
             const double* const xjg = A.XF + jq * NN;  // x_j (global; JX: the LDS copy)
             const double* const xjl = Xq + qc * NN;
             int pr0[PB], pr1[PB], pa[PB];
+            const int* prS[PB];
 #pragma unroll
             for (int bb = 0; bb < PB; ++bb) {
               const int plb = (pl0 + bb < npg) ? pl0 + bb : npg - 1;  // short last batch: repeats its last permutation
               const int p = g0 + plb;
               pr0[bb] = (lane < N) ? permS[p * N + lane] : 0;
               pr1[bb] = (BIG && lane + 64 < N) ? permS[p * N + 64 + lane] : 0;
+              prS[bb] = permS + p * N;
               pa[bb] = permS[p * N + ac];
             }
             double v[PB][3], nn[PB];
@@ -319,7 +325,7 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
                 const int m = (m0 + u < N) ? m0 + u : N - 1;
                 if (!JX) {
 #pragma unroll
-                  for (int bb = 0; bb < PB; ++bb) B.xj[bb][u] = ldg<PIPE>(xjg + pa[bb] + perm_at<BIG>(pr0[bb], pr1[bb], m) * N);
+                  for (int bb = 0; bb < PB; ++bb) B.xj[bb][u] = ldg<PIPE>(xjg + pa[bb] + perm_at<BIG>(pr0[bb], pr1[bb], prS[bb], m) * N);
                 }
                 if (!IMG) {
                   B.xi[u] = XFi[m * N + ac];
@@ -340,8 +346,8 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
                 for (int c3 = 0; c3 < 3; ++c3) g_[u][c3] = (PERM_ABL & 8) ? 0.5 * m : (IMG ? SG[(m * N + ac) * 3 + c3] : B.g[u][c3]);
 #pragma unroll
                 for (int bb = 0; bb < PB; ++bb)
-                  xj_[bb][u] = (PERM_ABL & 4) ? 0.25 * perm_at<BIG>(pr0[bb], pr1[bb], m)
-                                              : (JX ? xjl[pa[bb] + perm_at<BIG>(pr0[bb], pr1[bb], m) * N] : B.xj[bb][u]);
+                  xj_[bb][u] = (PERM_ABL & 4) ? 0.25 * perm_at<BIG>(pr0[bb], pr1[bb], prS[bb], m)
+                                              : (JX ? xjl[pa[bb] + perm_at<BIG>(pr0[bb], pr1[bb], prS[bb], m) * N] : B.xj[bb][u]);
               }
 #pragma unroll
               for (int u = 0; u < VU12; ++u) {
@@ -432,6 +438,7 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
               // ---- V3: lane = column atom (j, b)
               const int pi0 = (lane < N) ? pinvS[p * N + lane] : 0;
               const int pi1 = (BIG && lane + 64 < N) ? pinvS[p * N + 64 + lane] : 0;
+              const int* const piS = pinvS + p * N;
               const int ap = pinvS[p * N + b];
               const double* xfj = A.XF + (int64_t)jpt * NN + b;
               const double* gdj = A.GD + ((int64_t)jpt * NN + b) * 3;
@@ -455,7 +462,7 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
                     B.r[u][2] = ldg<PIPE>(gdj + mp * N3 + 2);
                   }
                   if (!IMG) {
-                    const int mi = perm_at<BIG>(pi0, pi1, mp);
+                    const int mi = perm_at<BIG>(pi0, pi1, piS, mp);
                     B.xi[u] = XFi[mi * N + ap];
                     const double* gi = GDi + (mi * N + ap) * 3;
                     B.gi[u][0] = gi[0];
@@ -469,7 +476,7 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
 #pragma unroll
                 for (int u = 0; u < VU3; ++u) {
                   const int mp = (m0 + u < N) ? m0 + u : N - 1;
-                  const int mi = perm_at<BIG>(pi0, pi1, mp);
+                  const int mi = perm_at<BIG>(pi0, pi1, piS, mp);
                   xj_[u] = (PERM_ABL & 32) ? 0.25 * mi : (JX ? XjS[mp * 64 + lane] : B.xj[u]);
                   xi_[u] = (PERM_ABL & 64) ? 1.0 + mi : (IMG ? SX[mi * N + ap] : B.xi[u]);
 #pragma unroll
@@ -552,6 +559,7 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
           const int p = g0 + pl;
           const int pr0 = (lane < N) ? permS[p * N + lane] : 0;
           const int pr1 = (BIG && lane + 64 < N) ? permS[p * N + 64 + lane] : 0;
+          const int* const prS = permS + p * N;
           const int ap = pinvS[p * N + b];
           const double* sc = sc_base + (pl * NQ + q) * 3;
           const double beta = sc[0], cn = sc[1];
@@ -589,7 +597,7 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
             for (int kk = 0; kk < 3; ++kk) {
               const int a0 = (r * NA + 3 * h + kk) * W + w;
               const int a = (a0 < N) ? a0 : N - 1;
-              const int pa = perm_at<BIG>(pr0, pr1, a);
+              const int pa = perm_at<BIG>(pr0, pr1, prS, a);
               const double* gjp = GJS ? GjS + (pa * 64 + lane) * 3 : gjg + pa * N3;
 #pragma unroll
               for (int c3 = 0; c3 < 3; ++c3) {
@@ -750,7 +758,7 @@ static size_t perm_layout(int N, int P, int W, int NA, int n_img, bool gjs, bool
   return (size_t)o * 8;
 }
 
-template <int W, int NA, bool IMG, bool GJS, bool JX, bool BIG>
+template <int W, int NA, bool IMG, bool GJS, bool JX, int BIG>
 static void perm_launch_t(gdml_ctx* ctx, const PermArgs& A, dim3 grid, size_t lds) {
   (void)hipFuncSetAttribute((const void*)assemble_perm_kernel<W, NA, IMG, GJS, JX, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
@@ -902,12 +910,16 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   const int slot = ktime_begin(ctx);
 #define PERM_GO(w, na)                                                                       \
   do {                                                                                       \
-    if (level == 3) perm_launch_t<w, na, true, true, true, false>(ctx, A, grid, lds);        \
-    else if (level == 2) perm_launch_t<w, na, true, true, false, false>(ctx, A, grid, lds);  \
-    else if (level == 1) perm_launch_t<w, na, true, false, false, false>(ctx, A, grid, lds); \
-    else perm_launch_t<w, na, false, false, false, false>(ctx, A, grid, lds);                \
+    if (level == 3) perm_launch_t<w, na, true, true, true, 0>(ctx, A, grid, lds);        \
+    else if (level == 2) perm_launch_t<w, na, true, true, false, 0>(ctx, A, grid, lds);  \
+    else if (level == 1) perm_launch_t<w, na, true, false, false, 0>(ctx, A, grid, lds); \
+    else perm_launch_t<w, na, false, false, false, 0>(ctx, A, grid, lds);                \
   } while (0)
-  if (N > 64) perm_launch_t<8, 6, false, false, false, true>(ctx, A, grid, lds);
+  // beyond 64 atoms the LDS-row variant (measured faster than two lane-held rows + select: N = 100 5.20 -> 4.63 ms, N = 128
+  // 4.31 -> 3.88, N = 70 P = 4 10.59 -> 10.16: profiles/r04_large_molecules.txt); asm.perm_lds_rows = 0 keeps the lane-held
+  // rows for 64 < N <= 128 as the A/B
+  if (N > 128 || (N > 64 && ctx_opt_i(ctx, "asm.perm_lds_rows", 1))) perm_launch_t<8, 6, false, false, false, 2>(ctx, A, grid, lds);
+  else if (N > 64) perm_launch_t<8, 6, false, false, false, 1>(ctx, A, grid, lds);
   else if (W == 4) PERM_GO(4, 6);
   else if (NA == 3) PERM_GO(8, 3);
   else PERM_GO(8, 6);

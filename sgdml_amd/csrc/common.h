@@ -12,7 +12,9 @@
 
 #include "../../include/gdml_hip.h"
 
-#define GDML_MAX_ATOMS 128
+// Sanity bound on the molecule size, not a kernel limit: 32-bit index arithmetic over the N x N x 3 dense tables and the
+// D = N (N - 1) / 2 descriptor rows holds far beyond it; memory (M N^2 32 bytes of dense tables) ends earlier.
+#define GDML_MAX_ATOMS 4096
 
 struct PhaseStat {
   double ms = 0.0;

@@ -714,19 +714,24 @@ __global__ void __launch_bounds__(256, 1) predict_mfma_kernel(PredArgs A, const 
 }
 
 // One workgroup per query: sum the split partials in order, then F = J_x^T F_x.
+// LDSFX = false (D beyond the LDS row, JS = 1): F_x is read where the GEMM pipeline left it.
+template <bool LDSFX>
 __global__ void __launch_bounds__(256) predict_epilogue_kernel(const double* __restrict__ part_F,
                                                                const double* __restrict__ part_E,
                                                                const double* __restrict__ gq,
                                                                int64_t B, int N, int D, int JS,
                                                                double* __restrict__ E_out,
                                                                double* __restrict__ F_out) {
-  extern __shared__ __attribute__((aligned(16))) double fx[];
+  extern __shared__ __attribute__((aligned(16))) double fxs[];
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, T = blockDim.x;
-  for (int k = tid; k < D; k += T) {
-    double s = 0.0;
-    for (int sp = 0; sp < JS; ++sp) s += part_F[((int64_t)sp * B + q) * D + k];
-    fx[k] = s;
+  const double* fx = LDSFX ? fxs : part_F + q * D;
+  if (LDSFX) {
+    for (int k = tid; k < D; k += T) {
+      double s = 0.0;
+      for (int sp = 0; sp < JS; ++sp) s += part_F[((int64_t)sp * B + q) * D + k];
+      fxs[k] = s;
+    }
   }
   if (tid == 0 && E_out) {
     double s = 0.0;
@@ -777,21 +782,27 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   const int64_t MP = md.M * md.P;
   int KPL = 1;
   while (KPL * 64 < D) KPL <<= 1;
-  if (D > 8192) return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "predict kernels support D <= 8192 (N <= 128)");
   const bool big = D > 1024;  // beyond the register-resident wave kernel
   // below ~1e9 (row, query, descriptor) triples the seven launches of the pipeline cost more than the wave kernel
   // (tools/predict_wide_probe.py); option predict.mfma_wide = 2 forces it (tests)
   const int wide_opt = ctx_opt_i(ctx, "predict.mfma_wide", 1);
-  const bool wide = (B >= 256) && (D > 256) && !ctx_opt_i(ctx, "predict.wave_only", 0) &&
-                    (wide_opt == 2 || (wide_opt == 1 && (double)MP * (double)B * (double)D >= 1.0e9));
+  // D > 8192 (N > 128): beyond the register rows of predict_big_kernel<16> -- the GEMM pipeline has no size limit and
+  // takes every batch there (a single query too: correct, if not what the pipeline is tuned for)
+  const bool beyond = D > 8192;
+  const bool wide = beyond || ((B >= 256) && (D > 256) && !ctx_opt_i(ctx, "predict.wave_only", 0) &&
+                               (wide_opt == 2 || (wide_opt == 1 && (double)MP * (double)B * (double)D >= 1.0e9)));
   if (wide) {  // large molecules: the contractions as tiled fp64-MFMA GEMMs (predict_wide.hip)
     double* part;
     GDML_TRY(ctx_slot(ctx, 0, (B * (int64_t)D + B) * 8, &part));
     const int slot = ktime_begin(ctx);
     GDML_TRY(predict_wide_device(ctx, d_xq, B, part, part + B * (int64_t)D));
     ktime_end(ctx, slot, "predict", 10.0 * (double)D * (double)B * (double)MP);
-    hipLaunchKernelGGL(predict_epilogue_kernel, dim3((unsigned)B), dim3(256), (size_t)D * 8, ctx->stream, part,
-                       part + B * (int64_t)D, d_gq, B, N, D, 1, d_E, d_F);
+    if (beyond)  // F_x row longer than the LDS row of the epilogue: read in place (JS = 1)
+      hipLaunchKernelGGL(predict_epilogue_kernel<false>, dim3((unsigned)B), dim3(256), 0, ctx->stream, part,
+                         part + B * (int64_t)D, d_gq, B, N, D, 1, d_E, d_F);
+    else
+      hipLaunchKernelGGL(predict_epilogue_kernel<true>, dim3((unsigned)B), dim3(256), (size_t)D * 8, ctx->stream, part,
+                         part + B * (int64_t)D, d_gq, B, N, D, 1, d_E, d_F);
     ctx->launch_counter++;
     HIP_CHECK(ctx, hipGetLastError());
     return GDML_OK;
@@ -894,7 +905,7 @@ int predict_device(gdml_ctx* ctx, const double* d_xq, const double* d_gq, int64_
   ctx->launch_counter++;
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(predict_epilogue_kernel, dim3((unsigned)B), dim3(256), (size_t)D * 8,
+    hipLaunchKernelGGL(predict_epilogue_kernel<true>, dim3((unsigned)B), dim3(256), (size_t)D * 8,
                        ctx->stream, A.part_F, A.part_E, d_gq, B, N, D, (int)JS, d_E, d_F);
     ctx->launch_counter++;
     e = hipGetLastError();

@@ -12,6 +12,8 @@ Cases (files next to this script):
                    residual after every iteration, coefficients, predictions.
   cols_n24_p6      _assemble_kernel_mat with an index list (incl. partial blocks) and with a point slice on N = 24,
                    P = 6, M = 12 (n = 864): sampled rows of both results -- column modes above the 9-atom fixtures.
+  n150_p2_m3       a 150-atom molecule (D = 11 175) with a two-element group, M = 3 (n = 1350): sampled K entries, analytic
+                   train, predictions -- beyond the 128 atoms the kernels were limited to before round 4.
 """
 import os
 import sys
@@ -114,7 +116,16 @@ def case_cols_n24_p6():
             K_absmax=np.float64(np.abs(K_pts).max()))
 
 
-CASES = ['pcg_n12_p6_m200', 'cols_n24_p6']
+def case_n150_p2_m3():
+    N = 150
+    swp = list(range(N))
+    swp[70], swp[71] = 71, 70
+    perms = g2.group_closure([tuple(swp)], N)
+    assert perms.shape[0] == 2
+    g2._train_and_sample('n150_p2_m3', N, 3, perms, 80, 4, seed=65, jitter=0.3, n_rows=160, n_cols=400)
+
+
+CASES = ['pcg_n12_p6_m200', 'cols_n24_p6', 'n150_p2_m3']
 
 if __name__ == '__main__':
     for c in sys.argv[1:] or CASES:

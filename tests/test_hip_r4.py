@@ -82,9 +82,20 @@ OPTION_SETS = [{}, {'asm.perm_level': 0}, {'asm.perm_level': 1}, {'asm.perm_leve
 @pytest.mark.parametrize('kind', ['id', 'c3xc2', 'c3^3'])
 @pytest.mark.parametrize('N', [24, 42, 65, 100])
 def test_assemble_perm_mode_matrix(N, kind):
+    _check_assembly_modes(N, M_OF_N[N], kind, OPTION_SETS)
+
+
+@pytest.mark.parametrize('N,kind', [(130, 'c3xc2'), (150, 'id'), (172, 'id'), (172, 'c3xc2')])
+def test_assembly_beyond_128_atoms(N, kind):
+    """Molecules larger than the 128 atoms rounds 1-3 stopped at (the reference has no size limit, train.py:97-302):
+    permutation entries from the LDS copy instead of lane-held rows (assemble_perm_kernel<..., 2>), energy-constraint
+    columns with 3N > 512 through ecol_big_kernel (N = 172: 3N = 516).  Same mode matrix, 1e-12 of max|K| vs the oracle."""
+    _check_assembly_modes(N, 2, kind, [{}, {'asm.perm_fast_store': 0}, {'asm.perm_i_chunk': 2}, {'asm.perm_pg': 1}])
+
+
+def _check_assembly_modes(N, M, kind, option_sets):
     from sgdml_amd import _lib
 
-    M = M_OF_N[N]
     xo, go, tp, sig, Ko, KoE = _oracle_case(N, M, kind)
     N3, n = 3 * N, M * 3 * N
     scale = np.abs(Ko).max()
@@ -96,7 +107,7 @@ def test_assemble_perm_mode_matrix(N, kind):
     idx = np.sort(rng.choice(n, size=min(n, 2 * N3 + 7), replace=False))
     idxE = np.sort(np.concatenate([rng.choice(n, size=N3 + 5, replace=False), n + np.arange(M)[::2]]))
     p0, p1 = M // 3, M // 3 + max(1, M // 2)
-    for opts in OPTION_SETS:
+    for opts in option_sets:
         c = _lib.Context()
         try:
             c.set_option('asm.wave', 0)
@@ -224,10 +235,11 @@ def test_iterative_solver_with_permutation_group_vs_reference():
 
 
 @pytest.mark.parametrize('n_atoms,n_train,n_query,n_perms', [(80, 5, 9, 1), (66, 4, 70, 6), (91, 3, 5, 1), (92, 3, 6, 1),
-                                                             (128, 2, 4, 1)])
+                                                             (128, 2, 4, 1), (129, 3, 1, 1), (140, 2, 5, 6), (200, 2, 3, 1)])
 def test_predict_big_kernels_vs_oracle(n_atoms, n_train, n_query, n_perms):
     """predict_big_kernel<8> (1024 < D <= 4096: N = 46 ... 91) and <16> (D <= 8192: N = 92 ... 128) for batches below the
-    GEMM pipeline: forces 1e-10 of the largest force, energies 1e-10 max(1, |E|) against the oracle (predict.py:84-245)."""
+    GEMM pipeline: forces 1e-10 of the largest force, energies 1e-10 max(1, |E|) against the oracle (predict.py:84-245).
+    Beyond 128 atoms (D > 8192) every batch -- a single query too -- takes the GEMM pipeline, whatever the option says."""
     from sgdml_amd import _lib
 
     N, M, B = n_atoms, n_train, n_query

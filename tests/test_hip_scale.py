@@ -42,7 +42,7 @@ def make_task(g, **extra):
     return task
 
 
-@pytest.mark.parametrize('name', ['cfg0_n9_p6', 'cfg3_n42_p27', 'cfg4_n60_p1', 'cfg1_n21_m100', 'cfg3_n42_p27_m60', 'n100_m3'])
+@pytest.mark.parametrize('name', ['cfg0_n9_p6', 'cfg3_n42_p27', 'cfg4_n60_p1', 'cfg1_n21_m100', 'cfg3_n42_p27_m60', 'n100_m3', 'n150_p2_m3'])
 def test_K_samples_at_config_shapes(ctx, name):
     """Device-assembled K (full, un-negated, host copy) vs the reference's sampled rows/columns, norm and max."""
     g = load(name)
@@ -65,7 +65,7 @@ def test_K_samples_at_config_shapes(ctx, name):
     assert np.abs(Kv - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize('name', ['cfg0_n9_p6', 'cfg3_n42_p27', 'cfg4_n60_p1', 'cfg1_n21_m100', 'cfg3_n42_p27_m60', 'n100_m3'])
+@pytest.mark.parametrize('name', ['cfg0_n9_p6', 'cfg3_n42_p27', 'cfg4_n60_p1', 'cfg1_n21_m100', 'cfg3_n42_p27_m60', 'n100_m3', 'n150_p2_m3'])
 def test_dropin_train_predict_at_config_shapes(name):
     """GDMLTrain.train (analytic) + GDMLPredict on the fixture's task: residual of the solve with the
     reference's K-free check, model constants and predictions vs the reference's model (alphas themselves are

@@ -23,7 +23,7 @@ def setup_case(g):
     return M, N, xd, gd, tp, orc.tril_perms_lin_from_tril_perms(tp)
 
 
-@pytest.mark.parametrize('name', ['cfg0_n9_p6', 'cfg3_n42_p27', 'cfg4_n60_p1', 'cfg1_n21_m100', 'cfg3_n42_p27_m60', 'n100_m3'])
+@pytest.mark.parametrize('name', ['cfg0_n9_p6', 'cfg3_n42_p27', 'cfg4_n60_p1', 'cfg1_n21_m100', 'cfg3_n42_p27_m60', 'n100_m3', 'n150_p2_m3'])
 def test_K_samples_and_solve_at_config_shapes(name):
     g = load(name)
     M, N, xd, gd, tp, lin = setup_case(g)
