@@ -113,10 +113,10 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
  *   gemm.nt_c (0)         non-temporal loads / stores of the C tile (after rocBLAS's Tensile kernel for this shape:
  *                         profiles/r03_vendor_kernels.txt; no gain measured)
- *   gemm.cacc (1)         fused GEMM launches: interior tiles accumulate into C loaded up front (0: load-subtract-store epilogue)
- *   gemm.lds16 (2)        fused GEMM launches: 16-byte LDS layout (k pairs, XOR-swizzled rows): ds_write_b128 / ds_read_b128;
- *                         2 = with the operand pairs of the next half k-tile requested 16 MFMAs ahead, 0 = the 8-byte layout
- *   gemm.commit_ks (12)   fused GEMM launches: 4 = A/B reference with the early LDS commit of the prefetched tile
+ *   gemm.lds16 (3)        fused GEMM launches: 3 = the production loop (16-byte LDS layout, operand pairs of the next half k-tile
+ *                         requested 16 MFMAs ahead, last k-tile peeled); 2 = the same with the last k-tile inside the loop (A/B).
+ *                         The 8-byte layout, the late-commit and the load-subtract-store variants of rounds 2-3 are gone from
+ *                         the fused kernel (their A/Bs: profiles/r03_gemm_*.txt)
  *   chol.nb (512: a multiple of 64 up to 512, anything else falls back to 512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),
  *   chol.lookahead (1)    factorisation schedule (fused_diag = 0: the round-1 second-stream look-ahead schedule)
  *   chol.outer (1024)     panel pairs: K = 2 nb trailing update in two launches (= chol.nb: single panels only)

@@ -21,6 +21,7 @@
 // chol.fused_diag = 0; profiles/r02_panel_fusion_ab.txt has the comparison.  The CU-masked / split-stream / chunked
 // variants measured in rounds 1-2 (profiles/r01_chol_timeline_split.txt, r02_sched_probe.txt) are gone.
 #include "common.h"
+#include <type_traits>
 #include <utility>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -228,7 +229,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
         gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(kt_), g.K, tid, rb_);
       }
     };
-    if constexpr (CKS == 4) {
+    if constexpr (CKS == 4 || CKS == 5) {
       // read-ahead form (gemm.lds16 = 2): the operand pairs of the NEXT half are requested while 16 MFMAs of the current
       // one are still to issue, across the tile boundary (the barrier sits before the tile's last 16 MFMAs)
       auto read_half = [&](d2 (&a_)[4], d2 (&b_)[4], int buf, int h) {
@@ -251,20 +252,53 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
       d2 a0[4], b0[4], a1[4], b1[4];
       read_half(a0, b0, 0, 0);
       const int nk32 = (int)nk;
-      for (int kt = 0; kt < nk32; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk32) load_ab(kt + 1, ra, rb);
-        mfma16(a0, b0, 0);
-        read_half(a1, b1, cur, 1);
-        mfma16(a0, b0, 1);
-        mfma16(a1, b1, 0);
-        if (kt + 1 < nk32) {
-          gemm_store_tile16(lds[cur ^ 1][0], tid, ra);
-          gemm_store_tile16(lds[cur ^ 1][1], tid, rb);
+      if constexpr (CKS == 4) {
+        for (int kt = 0; kt < nk32; ++kt) {
+          const int cur = kt & 1;
+          if (kt + 1 < nk32) load_ab(kt + 1, ra, rb);
+          mfma16(a0, b0, 0);
+          read_half(a1, b1, cur, 1);
+          mfma16(a0, b0, 1);
+          mfma16(a1, b1, 0);
+          if (kt + 1 < nk32) {
+            gemm_store_tile16(lds[cur ^ 1][0], tid, ra);
+            gemm_store_tile16(lds[cur ^ 1][1], tid, rb);
+          }
+          __syncthreads();
+          if (kt + 1 < nk32) read_half(a0, b0, cur ^ 1, 0);
+          mfma16(a1, b1, 1);
         }
-        __syncthreads();
-        if (kt + 1 < nk32) read_half(a0, b0, cur ^ 1, 0);
-        mfma16(a1, b1, 1);
+      } else {
+        // CKS = 5 (production): the same schedule with the last k-tile peeled -- no conditionals inside the loop, -0.3 % of the
+        // factorisation (1322 -> 1318 ms on one box, profiles/r04_gemm_peel_stagger_ab.txt).  Committing the prefetched tile to
+        // LDS 16 MFMAs earlier (so that its ds_writes have drained at the barrier) was measured with it: +0.3 %, not kept.
+        auto step = [&](int kt, auto has_next_t) {
+          constexpr bool HN = decltype(has_next_t)::value;
+          const int cur = kt & 1;
+          // (sched_barrier: without the loop's conditionals the machine scheduler hoists the commit and the barrier to the
+          //  20th MFMA and sinks the read-ahead behind the last one)
+          if constexpr (HN) load_ab(kt + 1, ra, rb);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma16(a0, b0, 0);
+          read_half(a1, b1, cur, 1);
+          mfma16(a0, b0, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma16(a1, b1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (HN) {
+            gemm_store_tile16(lds[cur ^ 1][0], tid, ra);
+            gemm_store_tile16(lds[cur ^ 1][1], tid, rb);
+          }
+          if constexpr (HN) {
+            __syncthreads();
+            read_half(a0, b0, cur ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          mfma16(a1, b1, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int kt = 0; kt + 1 < nk32; ++kt) step(kt, std::true_type{});
+        step(nk32 - 1, std::false_type{});
       }
     } else
     for (int64_t kt = 0; kt < nk; ++kt) {
@@ -484,9 +518,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
 template <bool ABL>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
-  // production instantiation: the 16-byte LDS layout with read-ahead of the fused kernel (gemm.lds16 = 2); the ablation
+  // production instantiation: the 16-byte LDS layout with read-ahead of the fused kernel (gemm.lds16 = 3); the ablation
   // instantiation keeps the 8-byte layout its masks were written for
-  gemm_block<ABL, !ABL, true, ABL ? GEMM_COMMIT_KS : 4>(g, lds, blockIdx.x);
+  gemm_block<ABL, !ABL, true, ABL ? GEMM_COMMIT_KS : 5>(g, lds, blockIdx.x);
 }
 
 
@@ -548,14 +582,9 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
       g.tiles2 = (int)(ceil_div(g.M2, GT) * ceil_div(g.N2, GT));
     }
     const dim3 grid((unsigned)(blocks + 1 + g.tiles2));
-    const int pipe = ctx_opt_i(ctx, "gemm.lds16", 2), cacc = ctx_opt_i(ctx, "gemm.cacc", 1);  // pipe = the 16-byte LDS layout
-    const int cks = ctx_opt_i(ctx, "gemm.commit_ks", GEMM_COMMIT_KS);
-    if (!pipe && cacc && cks == 4) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, true, 4>), grid, dim3(256), 0, st, g);
-    else if (pipe == 2 && cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 4>), grid, dim3(256), 0, st, g);
-    else if (pipe && cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true>), grid, dim3(256), 0, st, g);
-    else if (pipe) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, false>), grid, dim3(256), 0, st, g);
-    else if (cacc) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<false, false>), grid, dim3(256), 0, st, g);
+    // gemm.lds16 = 2: the loop with its last k-tile inside (A/B reference of the peeled production loop)
+    if (ctx_opt_i(ctx, "gemm.lds16", 3) == 2) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 4>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 5>), grid, dim3(256), 0, st, g);
   } else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   else
