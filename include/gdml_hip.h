@@ -118,6 +118,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *                         The 8-byte layout, the late-commit and the load-subtract-store variants of rounds 2-3 are gone from
  *                         the fused kernel (their A/Bs: profiles/r03_gemm_*.txt)
  *   chol.nb (512: a multiple of 64 up to 512, anything else falls back to 512), chol.fused_diag (1), chol.fused_min_rows (12288), chol.panel_kernel (1), chol.panel_fused (1),
+ *   chol.small_update (1) rank-64 updates inside the panel chain through rank64_update_kernel (0: the GEMM tile kernel; A/B)
  *   chol.lookahead (1)    factorisation schedule (fused_diag = 0: the round-1 second-stream look-ahead schedule)
  *   chol.outer (1024)     panel pairs: K = 2 nb trailing update in two launches (= chol.nb: single panels only)
  *   chol.outer_min_rows (16384)  trailing rows below which new panels are single again

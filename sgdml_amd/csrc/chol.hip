@@ -616,47 +616,68 @@ int launch_gemm_nt_sub_cyclic(gdml_ctx* ctx, hipStream_t st, const double* A, in
 // scaled column is exchanged through a 64-entry LDS vector (broadcast reads).  Entries above the
 // diagonal are scratch.  info (device int): first failing pivot, global 1-based (LAPACK dpotrf).
 // ------------------------------------------------------------------------------------------
-// One wavefront factors the 64 x 64 tile in T (pitch 65, identity padding outside w x w) in registers:
-// lane = row.  Returns 0 or the 1-based index of the first non-positive pivot.
-__device__ __forceinline__ int potrf64_wave(double* T, double* col, int lane) {
+// One wavefront factors the 64 x 64 tile in T (pitch 65, identity padding outside w x w) in registers: lane = row.
+// Returns 0 or the 1-based index of the first non-positive pivot.  Right-looking elimination blocked by 8 columns (round 4;
+// bit-identical to the rounds 1-3 form, which sent every scaled column through LDS and waited for the round trip before any
+// entry of the next column -- the next pivot included -- could be updated): the columns of the current 8-block are
+// updated from lane broadcasts (v_readlane of the scaled column: no memory on the pivot chain), and the columns right of
+// the block get the block's 8 rank-1 updates at once from an LDS copy of the 8 finished columns (cb: 64 rows x 8,
+// broadcast 16-byte reads).  1/sqrt(d): hardware estimate + two Newton steps (full double precision), then one multiply
+// per lane instead of a correctly rounded sqrt and a division on the 64-step critical path.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int potrf64_wave(double* T, double* cb /* 64 x 8 */, int lane) {
   double row[64];
 #pragma unroll
   for (int c = 0; c < 64; ++c) row[c] = T[lane * 65 + c];
   int fail = 0;
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    const double d = __shfl(row[j], j, 64);
-    if (!(d > 0.0) && fail == 0) fail = j + 1;
-    // 1/sqrt(d): hardware estimate + two Newton steps (full double precision), then one multiply per lane
-    // instead of a correctly rounded sqrt and a division on the 64-step critical path
-    double ri = __builtin_amdgcn_rsq(d);
-    ri = ri * (1.5 - 0.5 * d * ri * ri);
-    ri = ri * (1.5 - 0.5 * d * ri * ri);
-    const double dj = d * ri;
-    const double lr = row[j] * ri;
-    row[j] = (lane == j) ? dj : lr;
-    col[lane] = lr;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    {
-      const d2* col2 = reinterpret_cast<const d2*>(col);
-      const int c0 = (j + 1) | 1;  // first odd column >= j + 1 ... pairs (c0 + 1, c0 + 2) are 16-byte aligned
-      if (((j + 1) & 1) == 0 && j + 1 < 64) {  // j + 1 even: pair (j + 1, j + 2) is aligned already
+  for (int jb = 0; jb < 8; ++jb) {
 #pragma unroll
-        for (int c = j + 1; c < 64; c += 2) {
-          const d2 cc = col2[c >> 1];
-          row[c] -= lr * cc.x;
-          row[c + 1] -= lr * cc.y;
-        }
-      } else if (j + 1 < 64) {  // j + 1 odd: one single column, then aligned pairs
-        row[c0] -= lr * col[c0];
+    for (int jj = 0; jj < 8; ++jj) {
+      const int j = 8 * jb + jj;
+      const double d = readlane_f64(row[j], j);
+      if (!(d > 0.0) && fail == 0) fail = j + 1;
+      double ri = __builtin_amdgcn_rsq(d);
+      ri = ri * (1.5 - 0.5 * d * ri * ri);
+      ri = ri * (1.5 - 0.5 * d * ri * ri);
+      const double lr = row[j] * ri;  // lane r: L[r][j] (lane j: d * ri = the pivot's square root; lanes r < j: scratch)
+      row[j] = lr;
 #pragma unroll
-        for (int c = c0 + 1; c < 64; c += 2) {
-          const d2 cc = col2[c >> 1];
-          row[c] -= lr * cc.x;
-          row[c + 1] -= lr * cc.y;
-        }
-      }
+      for (int c = j + 1; c < 8 * jb + 8; ++c) row[c] -= lr * readlane_f64(lr, c);
     }
+    if (jb < 7) {
+      d2* wr = reinterpret_cast<d2*>(cb + lane * 8);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wr[k] = (d2){row[8 * jb + 2 * k], row[8 * jb + 2 * k + 1]};
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      // 4 columns at a time, the 8 rank-1 updates applied across them (k outer): four independent multiply-add chains
+      // (column by column the compiler emits 8 dependent multiply-adds behind each batch of reads and a lone wavefront
+      // pays the full instruction latency 1792 times; 8 columns at a time need > 256 registers: copies through AGPRs)
+#pragma unroll
+      for (int c0 = 8 * jb + 8; c0 < 64; c0 += 4) {
+        d2 l[4][4];
+        double v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const d2* rd = reinterpret_cast<const d2*>(cb + (c0 + g) * 8);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) l[g][q] = rd[q];
+          v[g] = row[c0 + g];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) v[g] -= row[8 * jb + k] * ((k & 1) ? l[g][k >> 1].y : l[g][k >> 1].x);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) row[c0 + g] = v[g];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // the reads of this block are done before the next block overwrites cb
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from hoisting later blocks' work (and its registers) up here
   }
 #pragma unroll
   for (int c = 0; c < 64; ++c) T[lane * 65 + c] = row[c];
@@ -739,7 +760,6 @@ __device__ __forceinline__ void subst64_row8(double (&t)[8], const double* __res
 // CU's vector L1).
 //   D: top-left of the block (row-major, ld), nbw = nb / 64.  lds: >= 67 KB (aliased onto the GEMM tile buffers).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int potrf64_wave(double* T, double* col, int lane);
 
 // 64 x 64 Cholesky (lower, in place in the LDS tile T, pitch 65) by a whole workgroup of 256 threads with 16
 // doubles of state per thread (the one-wavefront version keeps a row of 64 per lane, too many registers next to
@@ -898,13 +918,17 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
 __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
                                                      int64_t global_off, int* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) double T[64 * 65];
-  __shared__ __attribute__((aligned(16))) double col[64];
+  __shared__ __attribute__((aligned(16))) double col[64 * 8];
   const int lane = threadIdx.x;
-  // coalesced load into LDS, identity padding outside the w x w block
-  for (int r = 0; r < 64; ++r) {
-    double v = (r == lane) ? 1.0 : 0.0;
-    if (r < w && lane < w) v = A[(int64_t)r * ld + lane];
-    T[r * 65 + lane] = v;
+  // coalesced load into LDS, identity padding outside the w x w block; all 64 row loads in flight at once (clamped
+  // addresses + selects: as a loop around a conditional load each row waited for its own round trip, ~50 of ~80 us)
+  {
+    double tv[64];
+    const int lc = lane < w ? lane : w - 1;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) tv[r] = A[(int64_t)(r < w ? r : w - 1) * ld + lc];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) T[r * 65 + lane] = (r < w && lane < w) ? tv[r] : ((r == lane) ? 1.0 : 0.0);
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
   const int fail = potrf64_wave(T, col, lane);
@@ -925,39 +949,45 @@ __global__ void __launch_bounds__(256) potrf_trsm64_kernel(double* __restrict__ 
                                                            const double* __restrict__ Lprev,
                                                            double* __restrict__ Aprev, int wprev) {
   __shared__ __attribute__((aligned(16))) double T[64 * 65];
-  __shared__ __attribute__((aligned(16))) double Ls[64 * 64];
-  __shared__ __attribute__((aligned(16))) double col[64];
+  __shared__ __attribute__((aligned(16))) double Ls[64 * 64];  // L^T (row c = column c of L)
+  __shared__ __attribute__((aligned(16))) double col[64 * 8];
   __shared__ double rinv[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x == 0 && Lprev != nullptr) {  // deferred write-back of the previous diagonal block
-    for (int e = tid; e < 64 * 64; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      if (r < wprev && c <= r) Aprev[(int64_t)r * ld + c] = Lprev[e];
+  // Every global load of this prologue is issued before the first one is used (clamped addresses + selects, no branches
+  // around loads): as loops with a conditional load inside, the 16 rows of the block per wavefront and the 16 entries per
+  // thread of the deferred write-back each waited for their own round trip -- ~30 of the kernel's ~50 us at the head of
+  // every 64-column step of the panel chain (profiles/r04_step_chain.txt).
+  double pv[16];
+  const bool wb = blockIdx.x == 0 && Lprev != nullptr;  // deferred write-back of the previous diagonal block
+  if (wb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pv[i] = Lprev[tid + 256 * i];
+  }
+  {
+    double tv[16];
+    const int lc = lane < w ? lane : w - 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = wave + 4 * i;
+      tv[i] = A[(int64_t)(r < w ? r : w - 1) * ld + lc];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {  // identity padding outside the w x w block
+      const int r = wave + 4 * i;
+      T[r * 65 + lane] = (r < w && lane < w) ? tv[i] : ((r == lane) ? 1.0 : 0.0);
     }
   }
-  for (int r = wave; r < 64; r += 4) {  // coalesced load, identity padding outside the w x w block
-    double v = (r == lane) ? 1.0 : 0.0;
-    if (r < w && lane < w) v = A[(int64_t)r * ld + lane];
-    T[r * 65 + lane] = v;
+  if (wb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+      if (r < wprev && c <= r) Aprev[(int64_t)r * ld + c] = pv[i];
+    }
   }
-  __syncthreads();
-  if (wave == 0) {
-    const int fail = potrf64_wave(T, col, lane);
-    if (blockIdx.x == 0 && fail != 0 && fail <= w && lane == 0) atomicCAS(info, 0, (int)(global_off + fail));
-  }
-  __syncthreads();
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    const double v = (c <= r) ? T[r * 65 + c] : 0.0;  // lower triangle incl. diagonal; identity padding kept
-    Ls[e] = v;
-    if (blockIdx.x == 0) Lsave[e] = v;
-  }
-  __syncthreads();
-  if (tid < 64) rinv[tid] = 1.0 / Ls[tid * 64 + tid];
-  __syncthreads();
+  // this thread's row of the strip: requested here, needed after the factorisation (row-per-thread accesses are 64
+  // separate 16-byte segments per instruction; measured neutral at n = 6300, -1 ms at n = 63 000)
   const int64_t r = (int64_t)blockIdx.x * 256 + tid;
-  if (r >= m) return;
-  double* xr = X + r * ld;
+  double* xr = X + (r < m ? r : m - 1) * ld;
   double x[64];
   const bool al16 = ((reinterpret_cast<uintptr_t>(xr) & 15) == 0) && (w == 64);
   if (al16) {
@@ -971,12 +1001,47 @@ __global__ void __launch_bounds__(256) potrf_trsm64_kernel(double* __restrict__ 
 #pragma unroll
     for (int c = 0; c < 64; ++c) x[c] = (c < w) ? xr[c] : 0.0;
   }
+  __syncthreads();
+  if (wave == 0) {
+    const int fail = potrf64_wave(T, col, lane);
+    if (blockIdx.x == 0 && fail != 0 && fail <= w && lane == 0) atomicCAS(info, 0, (int)(global_off + fail));
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const double v = (c <= r) ? T[r * 65 + c] : 0.0;  // lower triangle incl. diagonal; identity padding kept
+    if (blockIdx.x == 0) Lsave[e] = v;
+    if (r == c) rinv[r] = 1.0 / v;
+  }
+  for (int e = tid; e < 64 * 64; e += 256) {  // L^T: consecutive threads read a column of T (pitch 65), write a row of Ls
+    const int c = e >> 6, r = e & 63;
+    Ls[e] = (c <= r) ? T[r * 65 + c] : 0.0;
+  }
+  __syncthreads();
+  if (r >= m) return;
+  // right-looking substitution: the same multiply-adds in the same order for every entry as a left-looking row loop, but the
+  // dependent chain is one multiply-add + one multiply per column instead of the whole dot product (c terms)
 #pragma unroll
   for (int c = 0; c < 64; ++c) {
-    double sacc = x[c];
+    const double xc = x[c] * rinv[c];
+    x[c] = xc;
+    const double* Lc = Ls + c * 64;  // L[c'][c], c' = 0..63
+    if ((c + 1) & 1) {  // c + 1 odd: one single entry, then aligned pairs
+      if (c + 1 < 64) x[c + 1] -= xc * Lc[c + 1];
 #pragma unroll
-    for (int k = 0; k < c; ++k) sacc -= x[k] * Ls[c * 64 + k];
-    x[c] = sacc * rinv[c];
+      for (int k = c + 2; k < 64; k += 2) {
+        const d2 l = *reinterpret_cast<const d2*>(Lc + k);
+        x[k] -= xc * l.x;
+        x[k + 1] -= xc * l.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = c + 1; k < 64; k += 2) {
+        const d2 l = *reinterpret_cast<const d2*>(Lc + k);
+        x[k] -= xc * l.x;
+        x[k + 1] -= xc * l.y;
+      }
+    }
   }
   if (al16) {
 #pragma unroll
@@ -993,9 +1058,13 @@ __global__ void __launch_bounds__(256) potrf_trsm64_kernel(double* __restrict__ 
 
 __global__ void __launch_bounds__(256) writeback_block_kernel(const double* __restrict__ Lprev,
                                                               double* __restrict__ Aprev, int64_t ld, int wprev) {
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    if (r < wprev && c <= r) Aprev[(int64_t)r * ld + c] = Lprev[e];
+  double pv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pv[i] = Lprev[threadIdx.x + 256 * i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = threadIdx.x + 256 * i, r = e >> 6, c = e & 63;
+    if (r < wprev && c <= r) Aprev[(int64_t)r * ld + c] = pv[i];
   }
 }
 
@@ -1088,9 +1157,16 @@ __global__ void __launch_bounds__(256) panel_trsm_prep_kernel(const double* __re
                                                               double* __restrict__ Tb) {
   const int jj = blockIdx.x, tid = threadIdx.x;
   double* T = Tb + (int64_t)jj * PT_TB;
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;  // L_jj[r][c], c <= r
-    const double v = (c <= r) ? L[(int64_t)(jj * 64 + r) * ldl + jj * 64 + c] : 0.0;
+  double lv[16];  // all 16 loads of a thread in flight at once (a conditional load in the loop waits for each round trip)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + 256 * i;
+    lv[i] = L[(int64_t)(jj * 64 + (e >> 6)) * ldl + jj * 64 + (e & 63)];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + 256 * i, r = e >> 6, c = e & 63;  // L_jj[r][c], c <= r
+    const double v = (c <= r) ? lv[i] : 0.0;
     T[c * PT_LP + r] = v;
     if (r == c) T[64 * PT_LP + r] = 1.0 / v;
   }
@@ -1110,26 +1186,36 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
   // blocks (an array indexed by the owner test would be demoted to scratch memory)
   d4 accA[2][4], accB[2][4];
   const int blkA = wave, blkB = 7 - wave;
+  // every load of the strip is issued before the first use: clamped addresses + selects, no branch around a load (with the
+  // `blk < nbw` test inside the tile loop the compiler emitted 16 branches, each 4 loads + s_waitcnt vmcnt(0): 16 memory
+  // round trips per workgroup before the first step)
   auto load_block = [&](d4 (&acc)[2][4], int blk) {
+    const bool have = blk < nbw && !(ABL && (dbg & 8));
+    const double* pb = X + (have ? blk : 0) * 64 + li;
+    double w[2][4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      const int64_t gr = row0 + 16 * i + lk;
+      // rows past m read row m-1 (clamped index + select instead of predicated loads)
+      const int64_t r0 = gr < m ? gr : m - 1, r1 = gr + 4 < m ? gr + 4 : m - 1;
+      const int64_t r2 = gr + 8 < m ? gr + 8 : m - 1, r3 = gr + 12 < m ? gr + 12 : m - 1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        if (blk < nbw && !(ABL && (dbg & 8))) {
-          // clamped row index + select instead of predicated loads (no divergent branches; rows past m read row m-1)
-          const int64_t gr = row0 + 16 * i + lk;
-          const double* pc = X + blk * 64 + 16 * j + li;
-          const int64_t r0 = gr < m ? gr : m - 1, r1 = gr + 4 < m ? gr + 4 : m - 1;
-          const int64_t r2 = gr + 8 < m ? gr + 8 : m - 1, r3 = gr + 12 < m ? gr + 12 : m - 1;
-          const double w0 = pc[r0 * ld], w1 = pc[r1 * ld], w2 = pc[r2 * ld], w3 = pc[r3 * ld];
-          v0 = gr < m ? w0 : 0.0;
-          v1 = gr + 4 < m ? w1 : 0.0;
-          v2 = gr + 8 < m ? w2 : 0.0;
-          v3 = gr + 12 < m ? w3 : 0.0;
-        }
-        acc[i][j] = (d4){v0, v1, v2, v3};
+        const double* pc = pb + 16 * j;
+        w[i][j][0] = pc[r0 * ld];
+        w[i][j][1] = pc[r1 * ld];
+        w[i][j][2] = pc[r2 * ld];
+        w[i][j][3] = pc[r3 * ld];
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t gr = row0 + 16 * i + lk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = (d4){(have && gr < m) ? w[i][j][0] : 0.0, (have && gr + 4 < m) ? w[i][j][1] : 0.0,
+                         (have && gr + 8 < m) ? w[i][j][2] : 0.0, (have && gr + 12 < m) ? w[i][j][3] : 0.0};
+    }
   };
   load_block(accA, blkA);
   load_block(accB, blkB);
@@ -1246,6 +1332,71 @@ int launch_trsm64(gdml_ctx* ctx, hipStream_t st, const double* Ld, double* X, in
   return GDML_OK;
 }
 
+// Rank-64 update inside the panel chain:  C[m x ncols] -= A[m x 64] B[ncols x 64]^T with a handful of tiles (the rest of an
+// nb x nb diagonal block after one 64-column step: m, ncols <= 448).  The 128 x 128 GEMM tile kernel is the wrong tool
+// there: most tiles are ragged (its guarded path loads element-wise and runs a load-subtract-store epilogue in four
+// serialised batches) and a launch took 20-60 us for < 30 MFLOP, on the dependent chain of every panel.  Here one wavefront
+// owns a 32 x 32 tile (2 x 2 MFMA tiles), both operands come straight from global memory (L2) in MFMA layout as 32-byte
+// runs and ALL loads of the tile -- C included -- are issued before the first use: one memory round trip + 64 MFMAs.
+// Ragged edges: clamped row indices on the loads, guarded stores.  skip_upper: tiles strictly above the diagonal are not
+// computed (C's origin lies on the matrix diagonal; the strict upper triangle is scratch).
+__global__ void __launch_bounds__(256) rank64_update_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                            double* __restrict__ C, int64_t ld, int m, int ncols,
+                                                            int skip_upper) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int tn = (ncols + 31) >> 5;
+  const int t = blockIdx.x * 4 + wave;
+  const int ti = t / tn, tj = t - ti * tn;
+  if (32 * ti >= m) return;
+  if (skip_upper && tj > ti) return;
+  const int r0 = 32 * ti, q0 = 32 * tj;
+  d4 acc[2][2], a[2][4], bb[2][4];
+  int crow[2][4], ccol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) ccol[j] = q0 + 16 * j + li;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) crow[i][r] = r0 + 16 * i + lk + 4 * r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = r0 + 16 * i + li, rb = q0 + 16 * i + li;
+    const double* Ap = A + (int64_t)(ra < m ? ra : m - 1) * ld + 4 * lk;
+    const double* Bp = B + (int64_t)(rb < ncols ? rb : ncols - 1) * ld + 4 * lk;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      a[i][ch] = *reinterpret_cast<const d4*>(Ap + 16 * ch);
+      bb[i][ch] = *reinterpret_cast<const d4*>(Bp + 16 * ch);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = crow[i][r] < m ? crow[i][r] : m - 1, cc = ccol[j] < ncols ? ccol[j] : ncols - 1;
+        acc[i][j][r] = C[(int64_t)rr * ld + cc];
+      }
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[i][ch][sidx], bb[j][ch][sidx], acc[i][j], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (crow[i][r] < m && ccol[j] < ncols) C[(int64_t)crow[i][r] * ld + ccol[j]] = acc[i][j][r];
+}
+
 // Factor one panel: columns [k0, k0+nb), rows [k0, n), 64-wide sub-steps (potrf64 / trsm64 / K=64 gemm).
 int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0, int64_t nb);
 
@@ -1265,6 +1416,7 @@ static int panel_factor(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int
 int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int64_t ld, int64_t k0,
                        int64_t nb) {
   const int fused = ctx_opt_i(ctx, "chol.panel_fused", 1);  // 0: separate potrf64 / trsm64 launches
+  const int small_upd = ctx_opt_i(ctx, "chol.small_update", 1);  // 0: the rank-64 updates of the chain through the GEMM tile kernel (A/B)
   double* save = nullptr;  // two 64 x 64 slots for the deferred write-back of the diagonal blocks
   if (fused) GDML_TRY(ctx_slot(ctx, 5, 2 * 4096 * 8, &save));
   const double* Lprev = nullptr;
@@ -1305,8 +1457,15 @@ int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int6
       const int64_t ncols = k0 + nb - (c0 + w);
       if (ncols > 0) {
         // rest of the panel:  C[c0+w:n, c0+w:k0+nb] -= X[c0+w:n, :] X[c0+w:k0+nb, :]^T
-        GDML_TRY(launch_gemm_nt_sub(ctx, st, X, ld, X, ld, A + (c0 + w) * ld + (c0 + w), ld, m, ncols,
-                                    w, 0));
+        const bool al32 = (reinterpret_cast<uintptr_t>(X) & 31) == 0 && (ld % 4 == 0);
+        if (w == 64 && m <= 2048 && al32 && small_upd) {  // a handful of tiles: one wavefront per 32 x 32 tile
+          const int tiles = (int)(ceil_div(m, 32) * ceil_div(ncols, 32));
+          hipLaunchKernelGGL(rank64_update_kernel, dim3((unsigned)ceil_div(tiles, 4)), dim3(256), 0, st, X, X,
+                             A + (c0 + w) * ld + (c0 + w), ld, (int)m, (int)ncols, 1);
+          ctx->launch_counter++;
+        } else {
+          GDML_TRY(launch_gemm_nt_sub(ctx, st, X, ld, X, ld, A + (c0 + w) * ld + (c0 + w), ld, m, ncols, w, 0));
+        }
       }
     }
   }

@@ -246,6 +246,7 @@ def test_cholesky_multi_panel(ctx, n):
     {'chol.outer': 1024, 'chol.outer_min_rows': 512, 'chol.fused_min_rows': 256},   # panel pairs (K = 1024 bulk in two halves)
     {'chol.outer': 512, 'chol.fused_min_rows': 256},                                # one-level fused schedule
     {'chol.fused_diag': 0},                                                         # look-ahead schedule on two streams
+    {'chol.small_update': 0},                                                       # rank-64 chain updates through the GEMM tile kernel
 ])
 def test_cholesky_schedules_small(ctx_factory, opts):
     """The schedules that only engage on large matrices by default (panel pairs with a K = 1024 trailing update split in two halves, each hiding one
