@@ -18,9 +18,10 @@ for spec in (sys.argv[1:] or ['-']):
         for kv in spec.split(','):
             k, v = kv.split('=')
             ctx.set_option(k, float(v))
-    ts = []
+    ts, ta = [], []
     for rep in range(3):
         ctx.assemble_K(20.0, False, alloc_extra_rows=1, for_cholesky=1e-10)
+        ta.append(ctx.phase_ms('assemble')[0])
         ctx.chol_set_rhs(y)
         info = ctx.chol_factor(1e-10)
         ts.append(ctx.phase_ms('factor')[0])
@@ -28,5 +29,6 @@ for spec in (sys.argv[1:] or ['-']):
     ctx.predict_upload_model(xd, np.zeros_like(xd), tp, 20.0, None)
     Kv = ctx.kernel_matvec(1e-10, False, -a)
     res = np.linalg.norm(-Kv - y) / np.linalg.norm(y)
-    print('%-40s factor %s ms  info %d  resid %.2e' % (spec, ' '.join('%.1f' % t for t in ts), info, res), flush=True)
+    print('%-40s factor %s ms  info %d  resid %.2e  assemble %s ms' % (spec, ' '.join('%.1f' % t for t in ts), info, res,
+                                                                            ' '.join('%.2f' % t for t in ta)), flush=True)
     ctx.close()
