@@ -108,16 +108,24 @@ __global__ void __launch_bounds__(256) predict_kernel(PredArgs A) {
   const int64_t r1 = (r0 + A.rows_per_split < A.MP) ? r0 + A.rows_per_split : A.MP;
   const bool has_aE = A.aE != nullptr;
 
-  for (int64_t r = r0; r < r1; ++r) {
-    double X[KPL], JA[KPL];
+  // Table rows two at a time with the next row requested before the current one is used: as a plain row loop the loads
+  // of row r + 1 were issued after the reductions of row r -- one memory round trip per row and wavefront (16 rows =
+  // ~12 of the kernel's 15.7 us for a single query against 1000 training points).  The loads are relaxed wavefront-scope
+  // atomic loads (plain global_load_dwordx2): LLVM otherwise folds the loop-carried values back into a load at the
+  // head of the loop body (foldPHIArgLoadIntoPHI), right in front of their use.
+  auto load_row = [&](int64_t r, double (&X)[KPL], double (&JA)[KPL], double& ae) {
 #pragma unroll
     for (int t = 0; t < KPL; ++t) {
       const int k = lane + 64 * t;
-      // padding lanes: X = x would need per-query values; use d = 0 via flag below
-      X[t] = (k < D) ? A.xp[r * D + k] : 0.0;
-      JA[t] = (k < D) ? A.jap[r * D + k] : 0.0;
+      const int kc = k < D ? k : D - 1;  // padding lanes read a valid entry and drop it (d = 0 - 0 below)
+      const double xv = __hip_atomic_load(A.xp + r * D + kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const double jv = __hip_atomic_load(A.jap + r * D + kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      X[t] = (k < D) ? xv : 0.0;
+      JA[t] = (k < D) ? jv : 0.0;
     }
-    const double ae = has_aE ? A.aE[r] : 0.0;
+    ae = has_aE ? __hip_atomic_load(A.aE + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0.0;
+  };
+  auto row = [&](const double (&X)[KPL], const double (&JA)[KPL], double ae) {
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       double d[KPL];
@@ -143,6 +151,18 @@ __global__ void __launch_bounds__(256) predict_kernel(PredArgs A) {
 #pragma unroll
       for (int t = 0; t < KPL; ++t) Fx[q][t] += w1 * d[t] - b2 * JA[t];
     }
+  };
+  if (r0 < r1) {
+    double X0[KPL], JA0[KPL], X1[KPL], JA1[KPL], ae0, ae1;
+    int64_t r = r0;
+    load_row(r, X0, JA0, ae0);
+    for (; r + 1 < r1; r += 2) {
+      load_row(r + 1, X1, JA1, ae1);
+      row(X0, JA0, ae0);
+      load_row(r + 2 < r1 ? r + 2 : r1 - 1, X0, JA0, ae0);
+      row(X1, JA1, ae1);
+    }
+    if (r < r1) row(X0, JA0, ae0);  // odd count: X0 holds row r1 - 1
   }
 #pragma unroll
   for (int q = 0; q < QB; ++q) {
@@ -726,28 +746,61 @@ __global__ void __launch_bounds__(256) predict_epilogue_kernel(const double* __r
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, T = blockDim.x;
   const double* fx = LDSFX ? fxs : part_F + q * D;
+  // Loads in batches of 8 with clamped indices, sums in the original order: as plain loops every partial (JS of them: 62 for
+  // a single query against 1000 training points) and every G entry of the back-projection (N - 1 per output) was one load
+  // + s_waitcnt vmcnt(0) -- ~100 dependent memory round trips in the single-geometry latency path.
   if (LDSFX) {
     for (int k = tid; k < D; k += T) {
       double s = 0.0;
-      for (int sp = 0; sp < JS; ++sp) s += part_F[((int64_t)sp * B + q) * D + k];
+      for (int sp0 = 0; sp0 < JS; sp0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int sp = sp0 + u < JS ? sp0 + u : JS - 1;
+          v[u] = part_F[((int64_t)sp * B + q) * D + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (sp0 + u < JS) s += v[u];
+      }
       fxs[k] = s;
     }
   }
   if (tid == 0 && E_out) {
     double s = 0.0;
-    for (int sp = 0; sp < JS; ++sp) s += part_E[(int64_t)sp * B + q];
+    for (int sp0 = 0; sp0 < JS; sp0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part_E[(int64_t)(sp0 + u < JS ? sp0 + u : JS - 1) * B + q];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (sp0 + u < JS) s += v[u];
+    }
     E_out[q] = s;
   }
   __syncthreads();
   const double* g = gq + q * 3 * D;
   for (int t = tid; t < 3 * N; t += T) {
-    int a = t / 3, al = t - 3 * a;
+    const int a = t / 3, al = t - 3 * a;
+    const int other = a == 0 ? 1 : 0;  // any partner != a (N >= 2), for the clamped slots
     double s = 0.0;
-    for (int m = 0; m < N; ++m) {
-      if (m == a) continue;
-      int k = pair_idx(a, m);
-      double gv = g[k * 3 + al] * fx[k];
-      s += (a < m) ? gv : -gv;
+    for (int m0 = 0; m0 < N; m0 += 8) {
+      double gv[8], fv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int mc = m0 + u < N ? m0 + u : N - 1;
+        const int k = pair_idx(a, mc == a ? other : mc);
+        gv[u] = g[k * 3 + al];
+        fv[u] = fx[k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = m0 + u;
+        if (m < N && m != a) {
+          const double v = gv[u] * fv[u];
+          s += (a < m) ? v : -v;
+        }
+      }
     }
     F_out[q * 3 * N + t] = s;
   }

@@ -6,15 +6,15 @@ from bench import synth_geometries
 from sgdml_amd import _lib
 
 def run(N, M, P=1):
-    R, E, F = synth_geometries(N, M + 8, seed=0)
-    Rf = R.reshape(M + 8, -1)
+    R, E, F = synth_geometries(N, M + 1000, seed=0)
+    Rf = R.reshape(M + 1000, -1)
     ctx = _lib.Context(0)
     D = N * (N - 1) // 2
     tp = np.arange(D, dtype=np.int64)[None]
     xd, gd = ctx.desc_from_R(Rf[:M], N)
     rs = np.random.RandomState(0)
     ctx.predict_upload_model(xd, rs.normal(size=xd.shape), tp, 20.0, None)
-    for B in (1, 8, 64, 200):
+    for B in (1, 8, 64, 1000):
         q = np.ascontiguousarray(Rf[M:M + B])
         for _ in range(50):
             ctx.predict(q)
