@@ -197,6 +197,12 @@ __global__ void __launch_bounds__(256) row_sqnorm_kernel(const double* __restric
 // t_part[rc][c] = sum_{r in chunk rc} X[r][c] v[r].  HBM bound (X is read once per call): a thread owns two adjacent
 // columns (16-byte loads; rows are padded to a multiple of 16 doubles, so the pair of an odd last column stays inside the
 // row) and keeps eight rows in flight.
+// the factor is streamed (25 GB per pass against 256 MB of Infinity Cache): NT = non-temporal loads
+template <bool NT>
+__device__ __forceinline__ d2 ld_stream(const d2* p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
 __global__ void __launch_bounds__(256) gemv_t_part_kernel(const double* __restrict__ X, int64_t ld,
                                                           int64_t n, int64_t m,
                                                           const double* __restrict__ v, int rows_per,
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(256) gemv_t_part_kernel(const double* __restri
   for (; r + 8 <= r1; r += 8) {
     d2 x[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const d2*>(col + (r + u) * ld);
+    for (int u = 0; u < 8; ++u) x[u] = ld_stream<NT>(reinterpret_cast<const d2*>(col + (r + u) * ld));
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const double vr = v[r + u];
@@ -237,6 +243,7 @@ __global__ void __launch_bounds__(256) reduce_parts_kernel(const double* __restr
   out[c] = s;
 }
 // out[r] = (sum_c X[r][c] t[c] - v[r]) * inv_lam.  One wavefront per row, 16-byte loads, four of them in flight per lane.
+template <bool NT>
 __global__ void __launch_bounds__(256) gemv_n_precon_kernel(const double* __restrict__ X, int64_t ld,
                                                             int64_t n, int64_t m,
                                                             const double* __restrict__ t,
@@ -253,7 +260,7 @@ __global__ void __launch_bounds__(256) gemv_n_precon_kernel(const double* __rest
     d2 x[4], tt[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      x[u] = *reinterpret_cast<const d2*>(row + c + 128 * u);
+      x[u] = ld_stream<NT>(reinterpret_cast<const d2*>(row + c + 128 * u));
       tt[u] = *reinterpret_cast<const d2*>(t + c + 128 * u);
     }
 #pragma unroll
@@ -608,6 +615,9 @@ static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, dou
   if (!ctx->precon) return gdml_fail(ctx, GDML_ERR_STATE, "no preconditioner resident");
   const ShardGeo sg = shard_geo(ctx);
   const int64_t n_loc = sg.n_loc, m = ctx->precon_m, ld = ctx->K_ld;
+  // non-temporal loads of the factor (it is streamed: 25 GB per pass at configs[2]): PCG iteration 9.66 -> 9.01 ms
+  // (profiles/r04_gemv_nt_ab.txt); cg.gemv_plain = 1: plain loads (A/B)
+  const bool nt = ctx_opt_i(ctx, "cg.gemv_plain", 0) == 0;
   int rows_per = 2048;
   int nparts = (int)((n_loc + rows_per - 1) / rows_per);
   if (nparts < 1) nparts = 1;
@@ -616,17 +626,26 @@ static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, dou
   double* part = buf;
   double* t = buf + (((int64_t)nparts * m + 1) & ~(int64_t)1);  // 16-byte aligned: read in pairs
   if (n_loc > 0) {
-    hipLaunchKernelGGL(gemv_t_part_kernel, dim3(ceil_div(m, 512), nparts), dim3(256), 0, ctx->stream,
-                       ctx->precon, ld, n_loc, m, d_v + sg.row0, rows_per, part);
+    if (nt)
+      hipLaunchKernelGGL(gemv_t_part_kernel<true>, dim3(ceil_div(m, 512), nparts), dim3(256), 0, ctx->stream,
+                         ctx->precon, ld, n_loc, m, d_v + sg.row0, rows_per, part);
+    else
+      hipLaunchKernelGGL(gemv_t_part_kernel<false>, dim3(ceil_div(m, 512), nparts), dim3(256), 0, ctx->stream,
+                         ctx->precon, ld, n_loc, m, d_v + sg.row0, rows_per, part);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m,
                        nparts, t);
   } else {
     HIP_CHECK(ctx, hipMemsetAsync(t, 0, m * 8, ctx->stream));
   }
   GDML_TRY(comm_allreduce_sum(ctx, t, m));
-  if (n_loc > 0)
-    hipLaunchKernelGGL(gemv_n_precon_kernel, dim3(ceil_div(n_loc, 4)), dim3(256), 0, ctx->stream,
-                       ctx->precon, ld, n_loc, m, t, d_v + sg.row0, 1.0 / lam, d_out + sg.row0);
+  if (n_loc > 0) {
+    if (nt)
+      hipLaunchKernelGGL(gemv_n_precon_kernel<true>, dim3(ceil_div(n_loc, 4)), dim3(256), 0, ctx->stream, ctx->precon, ld,
+                         n_loc, m, t, d_v + sg.row0, 1.0 / lam, d_out + sg.row0);
+    else
+      hipLaunchKernelGGL(gemv_n_precon_kernel<false>, dim3(ceil_div(n_loc, 4)), dim3(256), 0, ctx->stream, ctx->precon, ld,
+                         n_loc, m, t, d_v + sg.row0, 1.0 / lam, d_out + sg.row0);
+  }
   ctx->launch_counter += 3;
   HIP_CHECK(ctx, hipGetLastError());
   return comm_allgather_inplace(ctx, d_out, sg.chunk);
