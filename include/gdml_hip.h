@@ -136,6 +136,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   nys.force_qr (0)      take the alternative (QR-equivalent) branch of the second Nystroem factorisation (tests)
  *   nys.force_fail (0)    treat the first k attempts of the jitter-stabilised Cholesky of K_mm as failed (tests)
  *   pcg.depth (2)         PCG iterations queued ahead of the host's convergence test / callback (0 = synchronous)
+ *   pcg.gemv_plain (0)    preconditioner GEMVs with plain instead of non-temporal loads of the streamed factor (A/B)
  * Unknown keys return GDML_ERR_INVALID. */
 int gdml_set_option(gdml_ctx* ctx, const char* key, double value);
 int gdml_get_option(gdml_ctx* ctx, const char* key, double* value_out, int* is_set_out);

@@ -616,8 +616,8 @@ static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, dou
   const ShardGeo sg = shard_geo(ctx);
   const int64_t n_loc = sg.n_loc, m = ctx->precon_m, ld = ctx->K_ld;
   // non-temporal loads of the factor (it is streamed: 25 GB per pass at configs[2]): PCG iteration 9.66 -> 9.01 ms
-  // (profiles/r04_gemv_nt_ab.txt); cg.gemv_plain = 1: plain loads (A/B)
-  const bool nt = ctx_opt_i(ctx, "cg.gemv_plain", 0) == 0;
+  // (profiles/r04_gemv_nt_ab.txt); pcg.gemv_plain = 1: plain loads (A/B)
+  const bool nt = ctx_opt_i(ctx, "pcg.gemv_plain", 0) == 0;
   int rows_per = 2048;
   int nparts = (int)((n_loc + rows_per - 1) / rows_per);
   if (nparts < 1) nparts = 1;
