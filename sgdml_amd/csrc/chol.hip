@@ -270,7 +270,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
         }
       } else {
         // CKS = 5 (production): the same schedule with the last k-tile peeled -- no conditionals inside the loop, -0.3 % of the
-        // factorisation (1322 -> 1318 ms on one box, profiles/r04_gemm_peel_stagger_ab.txt).  Committing the prefetched tile to
+        // factorisation (1322 -> 1318 and 1289 -> 1286 ms on two boxes, profiles/r04_gemm_peel_stagger_ab.txt).  The schedule
+        // is pinned by a sched_barrier at EVERY phase boundary: with one missing (between the first MFMA group and the
+        // read-ahead) a later, unrelated edit of this file made the scheduler sink the reads behind two groups and the kernel
+        // lost 3 % (1322 vs 1282 ms on one box) without any change to this loop's source.  Committing the prefetched tile to
         // LDS 16 MFMAs earlier (so that its ds_writes have drained at the barrier) was measured with it: +0.3 %, not kept.
         auto step = [&](int kt, auto has_next_t) {
           constexpr bool HN = decltype(has_next_t)::value;
@@ -280,7 +283,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
           if constexpr (HN) load_ab(kt + 1, ra, rb);
           __builtin_amdgcn_sched_barrier(0);
           mfma16(a0, b0, 0);
-          read_half(a1, b1, cur, 1);
+          __builtin_amdgcn_sched_barrier(0);  // (between the groups too: in one region the reads were sunk behind BOTH groups and
+          read_half(a1, b1, cur, 1);          //  the third group waited for them -- +3 % factorisation time on a fast box)
+          __builtin_amdgcn_sched_barrier(0);
           mfma16(a0, b0, 1);
           __builtin_amdgcn_sched_barrier(0);
           mfma16(a1, b1, 0);
@@ -1175,7 +1180,7 @@ __global__ void __launch_bounds__(256) panel_trsm_prep_kernel(const double* __re
 
 template <bool ABL>
 __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __restrict__ Tb, const double* __restrict__ L, int64_t ldl,
-                                                            double* __restrict__ X, int64_t ld, int nbw, int64_t m, int dbg) {
+                                                            double* __restrict__ X, int64_t ld, int nbw, int64_t m, int dbg, int nt) {
   __shared__ __attribute__((aligned(16))) double S[PT_ROWS * PT_SP];
   __shared__ __attribute__((aligned(16))) double Lt[PT_TB];
   double* const rinv = Lt + 64 * PT_LP;
@@ -1202,10 +1207,17 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const double* pc = pb + 16 * j;
-        w[i][j][0] = pc[r0 * ld];
-        w[i][j][1] = pc[r1 * ld];
-        w[i][j][2] = pc[r2 * ld];
-        w[i][j][3] = pc[r3 * ld];
+        if (nt) {  // experiment (option trsm.nt): the strip is read once -- keep L and the panels in the caches
+          w[i][j][0] = __builtin_nontemporal_load(pc + r0 * ld);
+          w[i][j][1] = __builtin_nontemporal_load(pc + r1 * ld);
+          w[i][j][2] = __builtin_nontemporal_load(pc + r2 * ld);
+          w[i][j][3] = __builtin_nontemporal_load(pc + r3 * ld);
+        } else {
+          w[i][j][0] = pc[r0 * ld];
+          w[i][j][1] = pc[r1 * ld];
+          w[i][j][2] = pc[r2 * ld];
+          w[i][j][3] = pc[r3 * ld];
+        }
       }
     }
 #pragma unroll
@@ -1300,10 +1312,10 @@ int launch_panel_trsm(gdml_ctx* ctx, hipStream_t st, const double* L, double* X,
   hipLaunchKernelGGL(panel_trsm_prep_kernel, dim3((unsigned)(nb / 64)), dim3(256), 0, st, L, ldl > 0 ? ldl : ld, Tb);
   if (dbg)
     hipLaunchKernelGGL(panel_trsm_kernel<true>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, Tb, L, ldl > 0 ? ldl : ld,
-                       X, ld, nb / 64, m, dbg);
+                       X, ld, nb / 64, m, dbg, 0);
   else
     hipLaunchKernelGGL(panel_trsm_kernel<false>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, Tb, L, ldl > 0 ? ldl : ld,
-                       X, ld, nb / 64, m, 0);
+                       X, ld, nb / 64, m, 0, ctx_opt_i(ctx, "trsm.nt", 0));
   ctx->launch_counter++;
   ktime_end(ctx, slot, "panel_trsm", (double)m * (double)nb * (double)nb);
   ctx->launch_counter++;
