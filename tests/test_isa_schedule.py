@@ -40,16 +40,69 @@ def _phases(body):
     return [tuple(p) for p in out]
 
 
+_ASM = {}
+
+
+def _assembly(name):
+    """gfx950 assembly of sgdml_amd/csrc/<name>.hip (compiled once per test session)."""
+    if name not in _ASM:
+        tmp = tempfile.mkdtemp()
+        try:
+            asm = os.path.join(tmp, name + '.s')
+            subprocess.check_call([HIPCC, '-O3', '-std=c++17', '--offload-arch=gfx950', '-S', '--cuda-device-only', '-o', asm,
+                                   os.path.join(ROOT, 'sgdml_amd', 'csrc', name + '.hip')], stderr=subprocess.DEVNULL)
+            _ASM[name] = open(asm).read()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return _ASM[name]
+
+
+def _kernel(text, sym):
+    start = text.index('\n' + sym + ':')
+    return [l.strip() for l in text[start:text.index('s_endpgm', start)].split('\n') if l.strip() and not l.strip().startswith(';')]
+
+
+def _loads_before_first_full_wait(ins):
+    """Global loads issued before the first `s_waitcnt vmcnt(...)` of a kernel."""
+    n = 0
+    for l in ins:
+        if l.startswith('global_load'):
+            n += 1
+        elif l.startswith('s_waitcnt') and 'vmcnt' in l:
+            break
+    return n
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_step_chain_prologues_keep_their_loads_in_flight():
+    """The 64-column step kernels of the panel chain and the prediction epilogue are latency bound: their global loads must
+    be issued in batches, not one per loop iteration with a wait behind each (a loop around a conditional load compiles to
+    that; profiles/r04_step_chain.txt, r04_latency_path.txt: 30 % of the small-n factorisation, 18-26 % of the small-batch
+    prediction latency)."""
+    chol = _assembly('chol')
+    # potrf_trsm64_kernel: 16 rows of the diagonal block per wavefront (+ this thread's strip row: 32 16-byte loads)
+    assert _loads_before_first_full_wait(_kernel(chol, '_Z19potrf_trsm64_kernelPdS_lillPiS_PKdS_i')) >= 16
+    # stand-alone potrf64_kernel: all 64 rows of the block
+    assert _loads_before_first_full_wait(_kernel(chol, '_Z14potrf64_kernelPdlilPi')) >= 64
+    # panel_trsm_prep_kernel: 16 entries per thread
+    assert _loads_before_first_full_wait(_kernel(chol, '_Z22panel_trsm_prep_kernelPKdlPd')) >= 16
+    # prediction epilogue: the row-split partials in batches of 8
+    pred = _assembly('predict')
+    ins = _kernel(pred, '_Z23predict_epilogue_kernelILb1EEvPKdS1_S1_liiiPdS2_')
+    runs, cur = [], 0
+    for l in ins:
+        if l.startswith('global_load'):
+            cur += 1
+        elif l.startswith('s_waitcnt') and 'vmcnt' in l:
+            if cur:
+                runs.append(cur)
+            cur = 0
+    assert runs and max(runs) >= 8 and sum(1 for r in runs if r == 1) <= 2, runs
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
 def test_trailing_update_loop_keeps_its_schedule():
-    tmp = tempfile.mkdtemp()
-    try:
-        asm = os.path.join(tmp, 'chol.s')
-        subprocess.check_call([HIPCC, '-O3', '-std=c++17', '--offload-arch=gfx950', '-S', '--cuda-device-only', '-o', asm,
-                               os.path.join(ROOT, 'sgdml_amd', 'csrc', 'chol.hip')], stderr=subprocess.DEVNULL)
-        text = open(asm).read()
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+    text = _assembly('chol')
     sym = '_Z23gemm_nt_sub_diag_kernelILb1ELb1ELi5EEv8GemmArgs'
     start = text.index('\n' + sym + ':')
     kern = text[start:text.index('s_endpgm', start)]
