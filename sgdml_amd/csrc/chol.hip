@@ -1180,7 +1180,7 @@ __global__ void __launch_bounds__(256) panel_trsm_prep_kernel(const double* __re
 
 template <bool ABL>
 __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __restrict__ Tb, const double* __restrict__ L, int64_t ldl,
-                                                            double* __restrict__ X, int64_t ld, int nbw, int64_t m, int dbg, int nt) {
+                                                            double* __restrict__ X, int64_t ld, int nbw, int64_t m, int dbg) {
   __shared__ __attribute__((aligned(16))) double S[PT_ROWS * PT_SP];
   __shared__ __attribute__((aligned(16))) double Lt[PT_TB];
   double* const rinv = Lt + 64 * PT_LP;
@@ -1207,17 +1207,10 @@ __global__ void __launch_bounds__(256, 2) panel_trsm_kernel(const double* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const double* pc = pb + 16 * j;
-        if (nt) {  // experiment (option trsm.nt): the strip is read once -- keep L and the panels in the caches
-          w[i][j][0] = __builtin_nontemporal_load(pc + r0 * ld);
-          w[i][j][1] = __builtin_nontemporal_load(pc + r1 * ld);
-          w[i][j][2] = __builtin_nontemporal_load(pc + r2 * ld);
-          w[i][j][3] = __builtin_nontemporal_load(pc + r3 * ld);
-        } else {
-          w[i][j][0] = pc[r0 * ld];
-          w[i][j][1] = pc[r1 * ld];
-          w[i][j][2] = pc[r2 * ld];
-          w[i][j][3] = pc[r3 * ld];
-        }
+        w[i][j][0] = pc[r0 * ld];  // (non-temporal loads of the strip: measured neutral, profiles/r04_gemm_peel_stagger_ab.txt)
+        w[i][j][1] = pc[r1 * ld];
+        w[i][j][2] = pc[r2 * ld];
+        w[i][j][3] = pc[r3 * ld];
       }
     }
 #pragma unroll
@@ -1312,10 +1305,10 @@ int launch_panel_trsm(gdml_ctx* ctx, hipStream_t st, const double* L, double* X,
   hipLaunchKernelGGL(panel_trsm_prep_kernel, dim3((unsigned)(nb / 64)), dim3(256), 0, st, L, ldl > 0 ? ldl : ld, Tb);
   if (dbg)
     hipLaunchKernelGGL(panel_trsm_kernel<true>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, Tb, L, ldl > 0 ? ldl : ld,
-                       X, ld, nb / 64, m, dbg, 0);
+                       X, ld, nb / 64, m, dbg);
   else
     hipLaunchKernelGGL(panel_trsm_kernel<false>, dim3((unsigned)ceil_div(m, PT_ROWS)), dim3(256), 0, st, Tb, L, ldl > 0 ? ldl : ld,
-                       X, ld, nb / 64, m, 0, ctx_opt_i(ctx, "trsm.nt", 0));
+                       X, ld, nb / 64, m, 0);
   ctx->launch_counter++;
   ktime_end(ctx, slot, "panel_trsm", (double)m * (double)nb * (double)nb);
   ctx->launch_counter++;
