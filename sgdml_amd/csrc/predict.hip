@@ -782,9 +782,9 @@ __global__ void __launch_bounds__(256) predict_epilogue_kernel(const double* __r
   const double* g = gq + q * 3 * D;
   for (int t = tid; t < 3 * N; t += T) {
     const int a = t / 3, al = t - 3 * a;
-    const int other = a == 0 ? 1 : 0;  // any partner != a (N >= 2), for the clamped slots
+    const int other = a == 0 ? 1 : 0;  // any partner != a, for the clamped slots
     double s = 0.0;
-    for (int m0 = 0; m0 < N; m0 += 8) {
+    for (int m0 = 0; m0 < N && N >= 2; m0 += 8) {  // (a single atom has no descriptor entries: nothing to read)
       double gv[8], fv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
