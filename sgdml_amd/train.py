@@ -3,6 +3,7 @@
 (task/model dictionaries, label normalisation, integration constant) is host glue; the numerics
 (descriptors, kernel matrix, Cholesky / PCG, predictions) run in the HIP library.
 """
+import hashlib
 import logging
 import timeit
 from functools import partial
@@ -252,7 +253,7 @@ class GDMLTrain(object):
             'n_test': 0,
             'md5_test': None,
             'f_err': {'mae': np.nan, 'rmse': np.nan},
-            'R_desc': R_desc.T,
+            'R_desc': R_desc.T if R_desc.flags.writeable else R_desc.T.copy(),  # (cached descriptors are read-only)
             'R_d_desc_alpha': R_d_desc_alpha,
             'c': 0.0,
             'std': std,
@@ -275,6 +276,33 @@ class GDMLTrain(object):
         return model
 
     # ------------------------------------------------------------------ training
+
+    def _train_descriptors(self, desc, R, lat_and_inv, callback):
+        """Descriptors and Jacobians of the training geometries, reused across train() calls on the same geometries.
+
+        sigma-grid reuse (the reference's `sgdml all` rebuilds them for every sigma, cli.py:993-1098): they do
+        not depend on sigma, lam or the labels, so a hyper-parameter sweep computes them once.  Keyed by the CONTENT of the
+        geometries (+ lattice): the same array modified in place is a different key.  One entry; the cached arrays are
+        read-only because models keep views of them (`R_desc.T`).  What a sweep shares beyond this -- device-side tables,
+        validation set, matrix buffer -- is content-hashed inside the library; the pairwise norms themselves are NOT cached:
+        measured at < 3 % of a sweep (profiles/r03_sweep_kernel_stats.txt)."""
+        key = None
+        if R.nbytes <= (16 << 20):
+            h = hashlib.blake2b(np.ascontiguousarray(R).tobytes(), digest_size=16)
+            if lat_and_inv is not None:
+                h.update(np.ascontiguousarray(lat_and_inv[0], dtype=np.float64).tobytes())
+            key = (desc.n_atoms, R.shape, h.digest())
+            hit = getattr(self, '_desc_cache', None)
+            if hit is not None and hit[0] == key:
+                if callback is not None:
+                    callback(R.shape[0], R.shape[0], sec_disp_str='reused')
+                return hit[1], hit[2]
+        R_desc, R_d_desc = desc.from_R(R, lat_and_inv=lat_and_inv, callback=callback)
+        if key is not None and R_d_desc.nbytes <= (1 << 30):
+            R_desc.setflags(write=False)
+            R_d_desc.setflags(write=False)
+            self._desc_cache = (key, R_desc, R_d_desc)
+        return R_desc, R_d_desc
 
     def train(self, task, save_progr_callback=None, callback=None):
         """Train a model from a task (train.py:836-1088)."""
@@ -305,12 +333,11 @@ class GDMLTrain(object):
                 )
 
         R = task['R_train'].reshape(n_train, -1)
-        R_desc, R_d_desc = desc.from_R(
+        R_desc, R_d_desc = self._train_descriptors(
+            desc,
             R,
-            lat_and_inv=lat_and_inv,
-            callback=partial(callback, disp_str='Generating descriptors and their Jacobians')
-            if callback is not None
-            else None,
+            lat_and_inv,
+            partial(callback, disp_str='Generating descriptors and their Jacobians') if callback is not None else None,
         )
 
         # label vector (train.py:937-947)

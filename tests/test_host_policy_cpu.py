@@ -260,3 +260,39 @@ def test_distributed_cadence_broadcasts_only_when_a_checkpoint_can_be_written(tr
     assert clock0 == 0  # no writer: no per-iteration broadcast at all
     assert clock1 == (iters1 + 9) // 10  # a writer: the clock of iterations 0, 10, 20, ...
     assert total1 - clock1 == total0  # everything else (draws, solver choice, k, writer flag) is the same
+
+
+def test_descriptors_are_reused_across_a_sigma_sweep(trainer):
+    """sigma-grid reuse: GDMLTrain computes descriptors / Jacobians of a set of training geometries once --
+    a second train() on the same geometries (another sigma, other labels) gets the same arrays back, read-only; geometries
+    changed IN PLACE, a lattice, or another molecule size are different keys; models get writable copies."""
+    from sgdml_amd.utils.desc import Desc
+
+    tr, ctx = trainer
+    n_calls = []
+    real = ctx.desc_from_R
+    ctx.desc_from_R = lambda R, n, lat=None: (n_calls.append(1), real(R, n, lat))[1]
+    ds = orc.synth_dataset(5, 12, seed=3, jitter=0.2)
+    R = ds['R'].reshape(12, -1).copy()
+    desc = Desc(5)
+    desc._ctx = ctx
+    seen = []
+    a = tr._train_descriptors(desc, R, None, lambda *args, **kw: seen.append(kw.get('sec_disp_str')))
+    b = tr._train_descriptors(desc, R.copy(), None, lambda *args, **kw: seen.append(kw.get('sec_disp_str')))
+    assert len(n_calls) == 1 and a[0] is b[0] and a[1] is b[1] and seen[-1] == 'reused'
+    assert not a[0].flags.writeable and not a[1].flags.writeable
+    xo, go = orc.desc_from_R(R)
+    assert np.array_equal(a[0], xo) and np.array_equal(a[1], go)
+    R[0, 0] += 0.25  # same buffer, new content
+    c = tr._train_descriptors(desc, R, None, None)
+    assert len(n_calls) == 2 and c[0] is not a[0] and not np.array_equal(c[0], a[0])
+    lat = 20.0 * np.eye(3)
+    d = tr._train_descriptors(desc, R, (lat, np.linalg.inv(lat)), None)
+    assert len(n_calls) == 3 and d[0] is not c[0]
+    # the model dictionary keeps a writable array (the reference's is writable: a view of a local)
+    model = tr.create_model({'z': np.arange(5), 'R_train': R.reshape(12, 5, 3), 'F_train': np.zeros((12, 5, 3)), 'sig': 10,
+                             'lam': 1e-10, 'use_E': False, 'use_E_cstr': False, 'use_sym': False, 'perms': np.arange(5)[None],
+                             'dataset_name': np.array('x'), 'dataset_theory': np.array('y'), 'idxs_train': np.arange(12),
+                             'md5_train': 'm', 'idxs_valid': np.arange(0), 'md5_valid': 'm', 'type': 't', 'code_version': '1.0.3'},
+                            'analytic', d[0], d[1], np.arange(10), 1.0, np.zeros(12 * 15))
+    assert model['R_desc'].flags.writeable and np.array_equal(model['R_desc'], d[0].T)
