@@ -183,3 +183,18 @@ def test_pcg_with_permutation_group_matches_reference():
     ours, ref = np.array(r_hist[1:] + [resid]), g['resid_hist']
     np.testing.assert_allclose(ours[:8], ref[:8], rtol=1e-6)
     assert_same_convergence(ours, ref, np.linalg.norm(y))
+
+
+def test_fixed_entry_split_of_the_perm_summed_block_matches_the_oracle():
+    """Groundwork for the permutation-group assembly redesign: descriptor entries fixed by every
+    permutation of the group contribute once per (i, j), the others once per permutation -- same K to rounding
+    (tools/perm_split_check.py; train.py:165-232)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from perm_split_check import check
+
+    perms = np.array([[0, 1, 2, 3, 4, 5, 6, 7], [1, 2, 0, 3, 4, 5, 6, 7], [2, 0, 1, 3, 4, 5, 6, 7],
+                      [0, 1, 2, 4, 3, 5, 6, 7], [1, 2, 0, 4, 3, 5, 6, 7], [2, 0, 1, 4, 3, 5, 6, 7]])
+    dev, ratio, n_fixed, D = check(8, 3, perms)
+    assert D == 28 and n_fixed == 3  # the pairs among atoms 5, 6, 7
+    assert dev <= 1e-14 and ratio < 1.0
