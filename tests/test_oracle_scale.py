@@ -196,5 +196,5 @@ def test_fixed_entry_split_of_the_perm_summed_block_matches_the_oracle():
     perms = np.array([[0, 1, 2, 3, 4, 5, 6, 7], [1, 2, 0, 3, 4, 5, 6, 7], [2, 0, 1, 3, 4, 5, 6, 7],
                       [0, 1, 2, 4, 3, 5, 6, 7], [1, 2, 0, 4, 3, 5, 6, 7], [2, 0, 1, 4, 3, 5, 6, 7]])
     dev, ratio, n_fixed, D = check(8, 3, perms)
-    assert D == 28 and n_fixed == 3  # the pairs among atoms 5, 6, 7
+    assert D == 28 and n_fixed == 4  # the pairs among atoms 5, 6, 7 and the swapped pair {3, 4}, which maps to itself
     assert dev <= 1e-14 and ratio < 1.0
