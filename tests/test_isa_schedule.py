@@ -132,3 +132,20 @@ def test_trailing_update_loop_keeps_its_schedule():
         # the commit of the prefetched tile sits between the 48th MFMA and the barrier
         kinds = [k for k, _ in ph]
         assert kinds.index('lds_write') > kinds.index('lds_read') and kinds.index('lds_write') < kinds.index('barrier'), ph
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_predict_kernel_requests_table_rows_ahead():
+    """predict_kernel (batches below the MFMA kernel; the single-geometry latency path): the loads of the next table rows are
+    issued at the head of the row loop, before the reductions / sqrt / exp of the current row -- not one row per memory round
+    trip (profiles/r04_latency_path.txt)."""
+    pred = _assembly('predict')
+    sym = '_Z14predict_kernelILi4ELi1EEv8PredArgs'
+    start = pred.index('\n' + sym + ':')
+    kern = pred[start:pred.index('s_endpgm', start)]
+    m = re.search(r'^(\.LBB\d+_\d+):[^\n]*Inner Loop Header[^\n]*\n', kern, flags=re.M)
+    assert m, 'row loop not found'
+    body = [l.strip() for l in kern[m.end():].split('\n') if l.strip() and not l.strip().startswith(';')]
+    first_math = next(i for i, l in enumerate(body) if l.startswith(('v_rsq_f64', 'v_sqrt_f64', 'v_exp_f32', 'v_ldexp_f64')))
+    loads_ahead = sum(1 for l in body[:first_math] if l.startswith('global_load'))
+    assert loads_ahead >= 16, loads_ahead  # X and J alpha of two rows (KPL = 4: 8 loads per row)
