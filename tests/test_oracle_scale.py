@@ -198,3 +198,16 @@ def test_fixed_entry_split_of_the_perm_summed_block_matches_the_oracle():
     dev, ratio, n_fixed, D = check(8, 3, perms)
     assert D == 28 and n_fixed == 4  # the pairs among atoms 5, 6, 7 and the swapped pair {3, 4}, which maps to itself
     assert dev <= 1e-14 and ratio < 1.0
+
+
+def test_planned_perm_assembly_data_flow_matches_the_oracle():
+    """Groundwork (tools/perm_mfma_emulate.py): the atom-pair forms of u_p, v_p, the diagonal and single terms of J_i^T P J_j, and
+    the outer products accumulated as 16 x 16 x 4 MFMA tiles in C layout (lane / register -> row, column), emulated in NumPy for a
+    6-element group on 8 atoms and a ragged strip of column atoms, against the oracle's K (train.py:165-232)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from perm_mfma_emulate import check
+
+    perms = np.array([[0, 1, 2, 3, 4, 5, 6, 7], [1, 2, 0, 3, 4, 5, 6, 7], [2, 0, 1, 3, 4, 5, 6, 7],
+                      [0, 1, 2, 4, 3, 5, 6, 7], [1, 2, 0, 4, 3, 5, 6, 7], [2, 0, 1, 4, 3, 5, 6, 7]])
+    assert check(8, perms, strip=[7, 0, 3, 4, 1]) <= 1e-14
