@@ -312,7 +312,7 @@ def perm_group(n_atoms, kind):
 
 
 def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', sig=20, lam=1e-10, max_memory=None, seed=3,
-                 traj=None, n_inducing=None, dist_backend=None):
+                 traj=None, n_inducing=None, dist_backend=None, options=None):
     """One BASELINE configuration shape run to a SOLUTION through the drop-in GDMLTrain.train (sgdml/train.py:836-1088):
     analytic = assemble + Cholesky + solves; cg = the reference's iterative policy (leverage-score inducing points,
     Nystroem preconditioner, PCG to solver_tol = 1e-4, restarts) -- wall-clock to the converged model, phases,
@@ -346,6 +346,8 @@ def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', si
         tr._force_solver = solver
         tr._force_n_inducing_pts = n_inducing
         ctx = tr._context()
+        for k_, v_ in (options or {}).items():
+            ctx.set_option(k_, v_)
         if dist_backend is not None:
             tr.init_distributed(backend=dist_backend)
         ctx.profile(True)
@@ -387,6 +389,8 @@ def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', si
             out.update({'time_to_tol_s': wall, 'solver_tol': float(model['solver_tol']), 'solver_iters': int(model['solver_iters']),
                         'converged': bool(model['solver_resid'] <= model['solver_tol'] * model['norm_y_train']),
                         'inducing_pts_per_stage': draws, 'restarts': max(0, len(draws) - 1),
+                        'precon_form': getattr(tr, '_last_precon_form', None),
+                        'f32_gram_min_pivot': ctx.get_option('pcg.f32_last_min_pivot'),
                         'ms_per_pcg_iteration': ph.get('pcg', 0.0) / max(1, int(model['solver_iters']))})
         return out
     finally:
@@ -785,7 +789,8 @@ def run_analytic(args):
             t0 = time.perf_counter()
             got = c0.mem_reserve()
             arena = {'reserved_GB': got / 2**30, 'reserve_s': time.perf_counter() - t0,
-                     'note': 'one hipMalloc per process (gdml_mem_reserve); every kernel matrix below is carved from it'}
+                     'note': 'one hipMalloc per process (gdml_mem_reserve); every large buffer below (kernel matrices, the fp32 '
+                             'copy of the preconditioner factor) is carved from it first-fit'}
             c0.close()
         except Exception as e:
             arena = {'error': repr(e)}

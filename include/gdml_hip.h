@@ -70,10 +70,11 @@ int gdml_sync(gdml_ctx* ctx);
 int gdml_mem_info(gdml_ctx* ctx, int64_t* held, int64_t* free_b, int64_t* total_b);
 
 /* Process-level device arena: reserve ONE block of `bytes` on the context's device and keep it until the process ends
- * (or until gdml_mem_reserve(ctx, 0, ...)).  The large buffers of any context on that device -- the kernel matrix, the
- * Nystroem matrix -- are carved from it instead of hipMalloc / hipFree, which cost seconds per call beyond ~128 GB on this
- * driver; the block survives gdml_ctx_destroy.  One large buffer at a time; a request that does not fit, or arrives while the
- * block is taken, goes to hipMalloc.  gdml_mem_info counts the idle part of the arena as free.  reserved_out: bytes now held.
+ * (or until gdml_mem_reserve(ctx, 0, ...), which fails with GDML_ERR_STATE while any buffer is carved from it).  The large
+ * buffers (>= 1 GiB) of every context on that device -- the kernel matrix, the Nystroem matrix, the fp32 copy of the
+ * preconditioner factor -- are carved from it first-fit instead of hipMalloc / hipFree, which cost seconds per call beyond
+ * ~128 GB on this driver; the block survives gdml_ctx_destroy.  A request that fits no gap goes to hipMalloc.  gdml_mem_info
+ * counts the idle part of the arena as free.  reserved_out: bytes now held.
  * (The reference sizes its work to host RAM, sgdml/train.py:949-964; there is nothing to mirror here.) */
 int gdml_mem_reserve(gdml_ctx* ctx, int64_t bytes, int64_t* reserved_out);
 
@@ -137,6 +138,15 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   nys.force_fail (0)    treat the first k attempts of the jitter-stabilised Cholesky of K_mm as failed (tests)
  *   pcg.depth (2)         PCG iterations queued ahead of the host's convergence test / callback (0 = synchronous)
  *   pcg.gemv_plain (0)    preconditioner GEMVs with plain instead of non-temporal loads of the streamed factor (A/B)
+ *   pcg.precon_form (2)   application of the Nystroem preconditioner: 0 = stored n x m fp64 factor streamed twice per application
+ *                         (the reference's form, iterative.py:120-140); 3 = the factor stored in fp32 plus an m x m Gram
+ *                         correction (half the bytes per application; the exact Woodbury inverse on the rounded factor's column
+ *                         space: csrc/cg.hip); 2 = automatic: 3 once the factor reaches 1 GiB per rank, else 0; 1 = matrix-free
+ *                         (two kernel mat-vecs + an m x m matrix; experimental: does not converge at lam = 1e-10, never automatic)
+ *   pcg.f32_rows_per (1024), pcg.f32_rw (4)  shape of the fp32 form's two GEMVs: rows per partial sum of X32^T v, rows per
+ *                         wavefront of X32 t (A/B)
+ *   pcg.f32_min_pivot (1e-7)  fp32 form: smallest squared Cholesky pivot of the rounded factor's Gram matrix below which the
+ *                         reference's fp64 form is kept (gdml_get_option("pcg.f32_last_min_pivot") reads the last value seen)
  * Unknown keys return GDML_ERR_INVALID. */
 int gdml_set_option(gdml_ctx* ctx, const char* key, double value);
 int gdml_get_option(gdml_ctx* ctx, const char* key, double* value_out, int* is_set_out);
@@ -263,7 +273,13 @@ int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, const double* 
  *   K_mm needed (iterative.py:442-463); bit 0 = the second Cholesky failed and
  *   the alternative branch ran (the reference's QR of [K_nm; sqrt(lam) I], iterative.py:313-324; here a
  *   shifted CholeskyQR3 on fp64 MFMA with the same R^T R up to rounding).
- * gdml_precon_apply: out = (L^T L v - v)/lam  (iterative.py:120-140).
+ *   lev_scores_out may be NULL: the scores are then computed on demand by gdml_nystroem_lev_scores (valid until the next
+ *   assembly overwrites the matrix).  *info bit 1 / bit 2: the preconditioner will be applied matrix-free / from the fp32
+ *   copy of the factor (option pcg.precon_form); the matrix-free form skips the second tall triangular solve of the factor
+ *   until somebody asks for the scores.
+ * gdml_precon_apply: out = (L^T L v - v)/lam  (iterative.py:120-140).  Matrix-free form: with X = L^-1 K_mn = Z^T K_mn,
+ *   Z = L_mm^-T L^-T (m x m), L^T L v = K_nm Z Z^T K_mn v: K_mn v is gdml_kernel_matvec followed by a gather of the m inducing
+ *   entries, K_nm t a scatter followed by the mat-vec; the n x m factor is not read.  fp32 form: (X32 T0 X32^T v - v)/lam.
  * gdml_pcg: preconditioned CG for (-K + lam I) x = y with scipy.sparse.linalg.cg semantics
  *   (iterative.py:740-752: rtol*||y||, atol = 0, x0 optional).  Vectors and CG scalars stay on the device; the host
  *   reads the residual of an iteration only when it queues the iteration `pcg.depth` (default 2) steps later, so the GPU
@@ -277,6 +293,7 @@ int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, const double* 
 typedef int (*gdml_pcg_cb)(int64_t iter, double resid, void* user);
 int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* idx, int64_t m,
                          double* lev_scores_out, double* LinvKmn_host_out, int* info);
+int gdml_nystroem_lev_scores(gdml_ctx* ctx, double* lev_scores_out);
 int gdml_precon_apply(gdml_ctx* ctx, double lam, const double* v, int64_t n, double* out);
 int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const double* x0,
              int64_t n, double rtol, int64_t maxiter, int use_precon, gdml_pcg_cb cb,

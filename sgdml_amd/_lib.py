@@ -48,6 +48,7 @@ SIGNATURES = {
     'gdml_kernel_matvec': (C.c_int, [_vp, C.c_double, C.c_int, _vp, C.c_int64, _vp]),
     'gdml_predict_errors': (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp]),
     'gdml_nystroem_factor': (C.c_int, [_vp, C.c_double, _vp, C.c_int64, _vp, _vp, C.POINTER(C.c_int)]),
+    'gdml_nystroem_lev_scores': (C.c_int, [_vp, _vp]),
     'gdml_precon_apply': (C.c_int, [_vp, C.c_double, _vp, C.c_int64, _vp]),
     'gdml_pcg': (C.c_int, [_vp, C.c_double, C.c_int, _vp, _vp, C.c_int64, C.c_double, C.c_int64, C.c_int,
                            PCG_CB, C.c_int64, _vp, _vp, _ip, _dp, C.POINTER(C.c_int)]),
@@ -512,20 +513,31 @@ class Context(object):
                                                  _ptr(out)))
         return out
 
-    def nystroem_factor(self, lam, idx, want_factor=False):
-        """(leverage scores, factor or None, info).  info is a bit field (gdml_nystroem_factor): bit 0 = the second
-        Cholesky failed and the QR-equivalent branch ran (iterative.py:313-324); info >> 8 = jitter escalations of the
-        first one (iterative.py:442-463)."""
-        idx = i64(idx)
+    def _n_lev(self):
         n_rows, _, _ = self.K_shape()  # rows held by this rank
         n_glob = self.n_train * 3 * self.n_atoms + (0 if n_rows % (3 * self.n_atoms) == 0 else self.n_train)
         _, world = self.comm_info()
-        lev = np.empty(n_glob if world > 1 else n_rows)
+        return n_glob if world > 1 else n_rows
+
+    def nystroem_factor(self, lam, idx, want_factor=False, want_lev=True):
+        """(leverage scores or None, factor or None, info).  info is a bit field (gdml_nystroem_factor): bit 0 = the second
+        Cholesky failed and the QR-equivalent branch ran (iterative.py:313-324); bit 1 = the preconditioner is applied
+        matrix-free (option pcg.precon_form); info >> 8 = jitter escalations of the first Cholesky (iterative.py:442-463).
+        want_lev=False: the scores are computed on demand by nystroem_lev_scores()."""
+        idx = i64(idx)
+        n_rows, _, _ = self.K_shape()
+        lev = np.empty(self._n_lev()) if want_lev else None
         fac = np.empty((idx.size, n_rows)) if want_factor else None
         info = C.c_int(0)
         self._check(self._lib.gdml_nystroem_factor(self._h, float(lam), _ptr(idx), idx.size, _ptr(lev),
                                                    _ptr(fac), C.byref(info)))
         return lev, fac, info.value
+
+    def nystroem_lev_scores(self):
+        """Leverage scores of the resident Nystroem factor (gdml_nystroem_lev_scores): valid until the next assembly."""
+        lev = np.empty(self._n_lev())
+        self._check(self._lib.gdml_nystroem_lev_scores(self._h, _ptr(lev)))
+        return lev
 
     def precon_apply(self, lam, v):
         v = f64(v).ravel()

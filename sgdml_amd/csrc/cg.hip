@@ -85,7 +85,7 @@ __device__ __forceinline__ void tn_store(double* __restrict__ S, int tid, const 
 template <bool FULL>
 __device__ __forceinline__ void syrk_tn_tile(const double* __restrict__ X, int64_t ldx, int64_t n, int64_t m,
                                              double* __restrict__ C, int64_t ldc, int64_t row0, int64_t col0,
-                                             double (*lds)[2][TBK * TT]) {
+                                             double (*lds)[2][TBK * TT], int accumulate) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
@@ -155,14 +155,14 @@ __device__ __forceinline__ void syrk_tn_tile(const double* __restrict__ X, int64
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t gr = row0 + wm * 64 + 32 * (i >> 1) + 2 * (lk + 4 * r) + (i & 1);
-        if (FULL || (gr < m && gc < m)) C[gr * ldc + gc] = acc[i][j][r];
+        if (FULL || (gr < m && gc < m)) C[gr * ldc + gc] = accumulate ? C[gr * ldc + gc] + acc[i][j][r] : acc[i][j][r];
       }
     }
 }
 
 __global__ void __launch_bounds__(256, 2) syrk_tn_kernel(const double* __restrict__ X, int64_t ldx,
                                                          int64_t n, int64_t m, double* __restrict__ C,
-                                                         int64_t ldc, int tiles) {
+                                                         int64_t ldc, int tiles, int accumulate) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][TBK * TT];
   // linear block id -> lower-triangular tile (ti >= tj)
   const int64_t b = blockIdx.x;
@@ -174,9 +174,9 @@ __global__ void __launch_bounds__(256, 2) syrk_tn_kernel(const double* __restric
   const int64_t row0 = ti * TT, col0 = tj * TT;
   const bool aligned = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx % 2 == 0);
   if (aligned && row0 + TT <= m && col0 + TT <= m && 16 * ldx * 8 < ((int64_t)1 << 32))
-    syrk_tn_tile<true>(X, ldx, n, m, C, ldc, row0, col0, lds);
+    syrk_tn_tile<true>(X, ldx, n, m, C, ldc, row0, col0, lds, accumulate);
   else
-    syrk_tn_tile<false>(X, ldx, n, m, C, ldc, row0, col0, lds);
+    syrk_tn_tile<false>(X, ldx, n, m, C, ldc, row0, col0, lds, accumulate);
 }
 
 // out[r] = sum_c X[r][c]^2   (leverage scores, iterative.py:107-109)
@@ -242,8 +242,9 @@ __global__ void __launch_bounds__(256) reduce_parts_kernel(const double* __restr
   for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * m + c];
   out[c] = s;
 }
-// out[r] = (sum_c X[r][c] t[c] - v[r]) * inv_lam.  One wavefront per row, 16-byte loads, four of them in flight per lane.
-template <bool NT>
+// out[r] = (sum_c X[r][c] t[c] - v[r]) * inv_lam  (PRECON; otherwise the plain product sum_c X[r][c] t[c]).  One wavefront
+// per row, 16-byte loads, four of them in flight per lane.
+template <bool NT, bool PRECON = true>
 __global__ void __launch_bounds__(256) gemv_n_precon_kernel(const double* __restrict__ X, int64_t ld,
                                                             int64_t n, int64_t m,
                                                             const double* __restrict__ t,
@@ -277,7 +278,186 @@ __global__ void __launch_bounds__(256) gemv_n_precon_kernel(const double* __rest
   }
   if (lane == 0 && m2 < m) s0 += row[m2] * t[m2];
   const double s = wave_sum(s0 + s1);
-  if (lane == 0) out[r] = (s - v[r]) * inv_lam;
+  if (lane == 0) out[r] = PRECON ? (s - v[r]) * inv_lam : s;
+}
+
+// ---- matrix-free form of the preconditioner (pcg.precon_form): K_mn v is the kernel mat-vec followed by a gather of the
+// inducing entries, K_nm t a scatter of t into an n-vector followed by the mat-vec (K is symmetric)
+__global__ void __launch_bounds__(256) gather_idx_kernel(const double* __restrict__ s, const int64_t* __restrict__ idx,
+                                                         int64_t m, double* __restrict__ t) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < m) t[q] = s[idx[q]];
+}
+__global__ void __launch_bounds__(256) scatter_idx_kernel(const double* __restrict__ t, const int64_t* __restrict__ idx,
+                                                          int64_t m, double* __restrict__ e) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < m) e[idx[q]] = t[q];
+}
+__global__ void __launch_bounds__(256) precon_finish_kernel(const double* __restrict__ w, const double* __restrict__ v,
+                                                            double inv_lam, int64_t n, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (w[i] - v[i]) * inv_lam;
+}
+
+// ---- fp32-stored form of the factor (pcg.precon_form = 3).  The two GEMVs of an application are HBM bound at the rate
+// the memory delivers (16 n m bytes per application); the factor's information content is not: what the preconditioner needs
+// from X is its column SPACE to an angle theta with theta^2 sigma_max << lam (fp32: 6e-8), and the spectrum
+// 1 - lam / (sigma_i + lam) on it -- which no rounded X can carry (1 - 1e-12), and which the stored fp64 factor itself only
+// holds to ~1e-10 (profiles/r05_pcg_bisect.txt).  So X is rounded to fp32 (half the bytes) and the spectrum is put back
+// by an m x m matrix:   P v = (X32 T0 X32^T v - v) / lam,   T0 = L_G^-T G0 L_G^-1,
+// G = X32^T X32 = L_G L_G^T (fp64 Gram of the rounded factor: X32 L_G^-T is orthonormal to rounding), G0 = I - lam L^-1 L^-T
+// = the Gram of the exact factor (L L^T = K_nm^T K_nm + lam I, iterative.py:293-306).  In exact arithmetic and without
+// rounding this IS (X X^T v - v)/lam; with it, it is the exact Woodbury inverse of a Nystroem approximation on range(X32).
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// X32 <- float(X); pad columns [m, ld) of X32 <- 0.  X itself stays as it is (leverage scores, fall-back to the fp64 form)
+__global__ void __launch_bounds__(256) round_f32_kernel(const double* __restrict__ X, int64_t ld, int64_t n, int64_t m,
+                                                        float* __restrict__ X32) {
+  const int64_t r = blockIdx.x;
+  const double* row = X + r * ld;
+  float* row32 = X32 + r * ld;
+  for (int64_t c = threadIdx.x; c < ld; c += 256) row32[c] = c < m ? (float)row[c] : 0.0f;
+}
+// D (rows x ld doubles) <- double(X32 rows): the Gram matrix of the rounded factor is accumulated chunk by chunk
+__global__ void __launch_bounds__(256) widen_f32_kernel(const float* __restrict__ X32, int64_t ld, double* __restrict__ D) {
+  const int64_t r = blockIdx.x;
+  const float* src = X32 + r * ld;
+  double* dst = D + r * ld;
+  for (int64_t c = threadIdx.x; c < ld; c += 256) dst[c] = (double)src[c];
+}
+__global__ void __launch_bounds__(256) cg_scale_kernel(double* __restrict__ A, int64_t count, double f) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) A[i] *= f;
+}
+// A (lower triangle valid) mirrored into the upper triangle; then A <- I - A
+__global__ void __launch_bounds__(256) sym_fill_kernel(double* __restrict__ A, int64_t ld, int64_t m) {
+  const int64_t r = blockIdx.x;
+  for (int64_t c = threadIdx.x; c < r; c += 256) A[c * ld + r] = A[r * ld + c];
+}
+__global__ void __launch_bounds__(256) eye_minus_kernel(double* __restrict__ A, int64_t ld, int64_t m) {
+  const int64_t r = blockIdx.x;
+  for (int64_t c = threadIdx.x; c < m; c += 256) A[r * ld + c] = (c == r ? 1.0 : 0.0) - A[r * ld + c];
+}
+// t_part[rc][c] = sum_{r in chunk rc} X32[r][c] v[r]: a thread owns four adjacent columns (16-byte loads); products and
+// sums in fp64 (the fp32 values are exact doubles).  The sums are COMPENSATED (Kahan): what the operator needs from
+// X32^T v on the dominant subspace is 1 - lam / (sigma + lam) ~ 1 - 1e-12, and a plain chain of rows_per additions loses
+// eps sqrt(rows_per) of that (profiles/r05_f32_diag.txt: 1.4e-2 of the top direction's action against 1.8e-3 for a blocked
+// CPU sum, the difference between a 300-iteration plateau and none); the kernel is HBM bound, the four extra additions
+// per element are free.
+struct KahanSum {
+  double s = 0.0, c = 0.0;
+  __device__ __forceinline__ void add_prod(double x, double v) {
+    const double y = __builtin_fma(x, v, -c);
+    const double t = s + y;
+    c = (t - s) - y;
+    s = t;
+  }
+  __device__ __forceinline__ void add(double x) {
+    const double y = x - c;
+    const double t = s + y;
+    c = (t - s) - y;
+    s = t;
+  }
+};
+template <bool NT>
+__global__ void __launch_bounds__(256) gemv_t_part_f32_kernel(const float* __restrict__ X, int64_t ld, int64_t n, int64_t m,
+                                                              const double* __restrict__ v, int rows_per,
+                                                              double* __restrict__ part) {
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = (r0 + rows_per < n) ? r0 + rows_per : n;
+  if (c >= m) return;
+  const float* col = X + c;
+  KahanSum s0, s1, s2, s3;
+  int64_t r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    f4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const f4* p = reinterpret_cast<const f4*>(col + (r + u) * ld);
+      x[u] = NT ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double vr = v[r + u];
+      s0.add_prod((double)x[u].x, vr);
+      s1.add_prod((double)x[u].y, vr);
+      s2.add_prod((double)x[u].z, vr);
+      s3.add_prod((double)x[u].w, vr);
+    }
+  }
+  for (; r < r1; ++r) {
+    const f4 x = *reinterpret_cast<const f4*>(col + r * ld);
+    const double vr = v[r];
+    s0.add_prod((double)x.x, vr);
+    s1.add_prod((double)x.y, vr);
+    s2.add_prod((double)x.z, vr);
+    s3.add_prod((double)x.w, vr);
+  }
+  double* o = part + (int64_t)blockIdx.y * m + c;
+  o[0] = s0.s;
+  if (c + 1 < m) o[1] = s1.s;
+  if (c + 2 < m) o[2] = s2.s;
+  if (c + 3 < m) o[3] = s3.s;
+}
+__global__ void __launch_bounds__(256) reduce_parts_kahan_kernel(const double* __restrict__ part, int64_t m, int nparts,
+                                                                 double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= m) return;
+  KahanSum s;
+  for (int p = 0; p < nparts; ++p) s.add(part[(int64_t)p * m + c]);
+  out[c] = s.s;
+}
+// out[r] = (sum_c X32[r][c] t[c] - v[r]) * inv_lam.  A wavefront owns RW consecutive rows: a row of X32 is half as long
+// as the fp64 vector t it is multiplied with, so with one row per wavefront the t reads (from L2) would be twice the X32
+// reads (from HBM); t is loaded once per RW rows.  t is padded with zeros up to a multiple of 4, X32's pad columns are zero.
+template <bool NT, int RW>
+__global__ void __launch_bounds__(256) gemv_n_precon_f32_kernel(const float* __restrict__ X, int64_t ld, int64_t n, int64_t m,
+                                                                const double* __restrict__ t, const double* __restrict__ v,
+                                                                double inv_lam, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (r0 >= n) return;
+  const float* row[RW];
+#pragma unroll
+  for (int k = 0; k < RW; ++k) row[k] = X + ((r0 + k < n) ? r0 + k : n - 1) * ld;
+  const int64_t m4 = (m + 3) & ~(int64_t)3;
+  double s[RW];
+#pragma unroll
+  for (int k = 0; k < RW; ++k) s[k] = 0.0;
+  int64_t c = 4 * lane;
+  for (; c + 256 < m4; c += 512) {
+    f4 x[2][RW];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        const f4* p = reinterpret_cast<const f4*>(row[k] + c + 256 * u);
+        x[u][k] = NT ? __builtin_nontemporal_load(p) : *p;
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const d2 ta = *reinterpret_cast<const d2*>(t + c + 256 * u);
+      const d2 tb = *reinterpret_cast<const d2*>(t + c + 256 * u + 2);
+#pragma unroll
+      for (int k = 0; k < RW; ++k)
+        s[k] += ((double)x[u][k].x * ta.x + (double)x[u][k].y * ta.y) + ((double)x[u][k].z * tb.x + (double)x[u][k].w * tb.y);
+    }
+  }
+  for (; c < m4; c += 256) {
+    const d2 ta = *reinterpret_cast<const d2*>(t + c);
+    const d2 tb = *reinterpret_cast<const d2*>(t + c + 2);
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const f4 x = *reinterpret_cast<const f4*>(row[k] + c);
+      s[k] += ((double)x.x * ta.x + (double)x.y * ta.y) + ((double)x.z * tb.x + (double)x.w * tb.y);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    const double sk = wave_sum(s[k]);
+    if (lane == 0 && r0 + k < n) out[r0 + k] = (sk - v[r0 + k]) * inv_lam;
+  }
 }
 
 // ---- vector kernels of the PCG loop.  The CG scalars (rho, p.Ap, ||r||^2) never leave the device: a dot product is
@@ -480,6 +660,149 @@ __global__ void __launch_bounds__(256) gather_neg_rows_sharded_kernel(const doub
   }
 }
 
+// Form of the preconditioner application (option pcg.precon_form):
+//   0  the stored n x m fp64 factor, streamed twice per application -- the reference's operator (iterative.py:120-140)
+//   1  matrix-free (two kernel mat-vecs + the m x m matrix Z).  Experimental: the same operator to ~1e-8 of its norm, which
+//      is NOT enough -- (X X^T - I) v cancels to lam / (sigma + lam) ~ 1e-12 on the dominant subspace, X = K_nm Z is only
+//      orthonormal when formed row by row (cond(K_nm) ~ 1e10: |K_nm| |Z| eps ~ 1e-5), and PCG at lam = 1e-10 does not
+//      converge with it (profiles/r05_pcg_bisect.txt).  Usable for lam >~ 1e-6; never chosen automatically.
+//   3  the factor stored in fp32 + the m x m Gram correction T0 (above): half the bytes per application
+//   2  automatic (default): 3 when the factor is large enough for its streaming to dominate an iteration (>= 1 GiB per
+//      rank) AND the extra build work -- one more Gram pass over the factor, 2 n m^2 flops, and ~8 m^3 for T0 -- is paid back
+//      within ~500 iterations (4 n m bytes saved per pass, two passes: break-even at ~0.027 m (1 + 4 m / n) iterations;
+//      configs[2] 310, configs[4] 210, configs[3] 840: measured 17.9 s stored against 19.4 s there), else 0 -- every
+//      reference-parity fixture of the test suite stays on the reference's form.
+// Every input of the decision is the same on every rank.
+static int choose_precon_form(const gdml_ctx* ctx, const ShardGeo& sg, int64_t m, int64_t ld) {
+  const int opt = ctx_opt_i(ctx, "pcg.precon_form", 2);
+  if (opt == 0 || opt == 1 || opt == 3) return opt;
+  if (8.0 * (double)sg.chunk * (double)m < (double)((int64_t)1 << 30)) return 0;
+  const double break_even = 0.027 * (double)m * (1.0 + 4.0 * (double)m / (double)(sg.chunk > 0 ? sg.chunk : 1));
+  return break_even <= 500.0 ? 3 : 0;
+}
+
+static int ensure_buf(gdml_ctx* ctx, void** p, int64_t* have, int64_t want) {
+  if (*have >= want) return GDML_OK;
+  if (*p) GDML_TRY(ctx_free(ctx, *p));
+  *p = nullptr;
+  *have = 0;
+  GDML_TRY(ctx_alloc(ctx, p, want));
+  *have = want;
+  return GDML_OK;
+}
+
+// fp32 form: X (complete fp64 factor, rows of this rank) and S = L (lower, L L^T = K_nm^T K_nm + lam I) -> X32, T0.
+// X itself is not modified.  *usable = 0 when the Gram matrix of the rounded factor cannot be factored or is too ill
+// conditioned for X32 L_G^-T to be orthonormal to ~1e-9 (squared singular values sigma_i / (sigma_i + lam) of X below the
+// threshold: inducing columns the data does not support, a numerically rank-deficient K_mm).  The caller then keeps the
+// reference's fp64 form.
+static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S, int64_t n_loc, int64_t m, int64_t ld,
+                          int* usable) {
+  *usable = 0;
+  ctx->opts["pcg.f32_last_min_pivot"] = 0.0;
+  hipStream_t st = ctx->stream;
+  GDML_TRY(ensure_buf(ctx, (void**)&ctx->precon_X32, &ctx->precon_X32_bytes, (n_loc > 0 ? n_loc : 1) * ld * 4));
+  GDML_TRY(ensure_buf(ctx, (void**)&ctx->precon_T0, &ctx->precon_T0_bytes, m * ld * 8));
+  void* tmp = nullptr;
+  GDML_TRY(ctx_alloc(ctx, &tmp, 2 * m * ld * 8));
+  double* Rb = (double*)tmp;   // L^-T, later L_G^-T
+  double* G = Rb + m * ld;     // Gram of the rounded factor, then its Cholesky factor
+  double* G0 = ctx->precon_T0; // lives in the T0 buffer until T0 itself is formed
+  double* H = G;               // (G is dead once L_G^-T has been formed from it)
+  const int tiles = (int)((m + TT - 1) / TT);
+  const dim3 tri((unsigned)(tiles * (tiles + 1) / 2));
+  auto identity = [&](double* A) -> int {
+    HIP_CHECK(ctx, hipMemsetAsync(A, 0, m * ld * 8, st));
+    hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, A, ld, m, 1.0);
+    return GDML_OK;
+  };
+  auto body = [&]() -> int {
+    // G0 = I - lam L^-1 L^-T: R = L^-T (the solve applied to the identity), lam R^T R on the MFMA Gram kernel
+    GDML_TRY(identity(Rb));
+    GDML_TRY(tall_trsm(ctx, S, Rb, m, m, ld));
+    hipLaunchKernelGGL(cg_scale_kernel, dim3(ceil_div(m * ld, 256)), dim3(256), 0, st, Rb, m * ld, sqrt(lam));
+    hipLaunchKernelGGL(syrk_tn_kernel, tri, dim3(256), 0, st, Rb, ld, m, m, G0, ld, tiles, 0);
+    hipLaunchKernelGGL(sym_fill_kernel, dim3((unsigned)m), dim3(256), 0, st, G0, ld, m);
+    hipLaunchKernelGGL(eye_minus_kernel, dim3((unsigned)m), dim3(256), 0, st, G0, ld, m);
+    // rounded factor and its Gram (summed over the row shards).  The fp32 values are widened chunk by chunk into a work
+    // buffer and the Gram kernel accumulates over the chunks: X stays untouched, and the accumulation chains stay short
+    if (n_loc > 0)
+      hipLaunchKernelGGL(round_f32_kernel, dim3((unsigned)n_loc), dim3(256), 0, st, X, ld, n_loc, m, ctx->precon_X32);
+    {
+      int64_t chunk = ((int64_t)2 << 30) / (ld * 8);
+      chunk = chunk < 1024 ? 1024 : chunk / 16 * 16;
+      if (chunk > n_loc) chunk = n_loc > 0 ? n_loc : 1;
+      double* D;
+      GDML_TRY(ctx_slot(ctx, 11, chunk * ld * 8, &D));
+      if (n_loc == 0) HIP_CHECK(ctx, hipMemsetAsync(G, 0, m * ld * 8, st));
+      for (int64_t r0 = 0; r0 < n_loc; r0 += chunk) {
+        const int64_t rows = (n_loc - r0 < chunk) ? n_loc - r0 : chunk;
+        hipLaunchKernelGGL(widen_f32_kernel, dim3((unsigned)rows), dim3(256), 0, st, ctx->precon_X32 + r0 * ld, ld, D);
+        hipLaunchKernelGGL(syrk_tn_kernel, tri, dim3(256), 0, st, D, ld, rows, m, G, ld, tiles, r0 > 0 ? 1 : 0);
+      }
+    }
+    GDML_TRY(comm_allreduce_sum(ctx, G, m * ld));
+    int inf = 0;
+    int rcg = chol_factor_device(ctx, G, m, ld, &inf);
+    if (rcg == GDML_ERR_NOT_PD || inf != 0) return GDML_OK;  // *usable stays 0: X is intact, the caller keeps the fp64 form
+    GDML_TRY(rcg);
+    {  // conditioning of the rounded factor's Gram matrix, from its Cholesky pivots: X32 L_G^-T is orthonormal to
+       // eps cond(G); beyond ~1e7 the reference's form is kept (pcg.f32_min_pivot: threshold on the smallest squared pivot)
+      std::vector<double> diag((size_t)m);
+      HIP_CHECK(ctx, hipMemcpy2DAsync(diag.data(), 8, G, (ld + 1) * 8, 8, m, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(ctx, hipStreamSynchronize(st));
+      double dmin = 1e300;
+      for (double d : diag) dmin = d < dmin ? d : dmin;
+      ctx->opts["pcg.f32_last_min_pivot"] = dmin * dmin;  // diagnostic, read back with gdml_get_option
+      if (!(dmin * dmin >= ctx_opt(ctx, "pcg.f32_min_pivot", 1e-7))) return GDML_OK;
+    }
+    // T0 = L_G^-T G0 L_G^-1 = Zt G0 Zt^T, Zt = L_G^-T:   H = -(Zt G0^T),   T0 = 0 - Zt H^T
+    GDML_TRY(identity(Rb));
+    GDML_TRY(tall_trsm(ctx, G, Rb, m, m, ld));
+    HIP_CHECK(ctx, hipMemsetAsync(H, 0, m * ld * 8, st));
+    GDML_TRY(launch_gemm_nt_sub(ctx, st, Rb, ld, G0, ld, H, ld, m, m, m, 0));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->precon_T0, 0, m * ld * 8, st));  // G0 is dead: its buffer becomes T0
+    GDML_TRY(launch_gemm_nt_sub(ctx, st, Rb, ld, H, ld, ctx->precon_T0, ld, m, m, m, 0));
+    HIP_CHECK(ctx, hipGetLastError());
+    *usable = 1;
+    return GDML_OK;
+  };
+  int rc = body();
+  int rc2 = ctx_free(ctx, tmp);
+  return rc != GDML_OK ? rc : rc2;
+}
+
+// leverage scores = squared row norms of the complete factor X (iterative.py:107-109), replicated on every rank
+static int lev_scores_to_host(gdml_ctx* ctx, const ShardGeo& sg, double* lev_scores_out) {
+  const int64_t n_loc = sg.n_loc, m = ctx->precon_m, ld = ctx->K_ld;
+  double* X = ctx->precon;
+  if (ctx->precon_stage < 2) {  // the matrix-free form left X = K_nm L_mm^-T: the second solve (iterative.py:335-345) now
+    GDML_TRY(tall_trsm(ctx, ctx->K + n_loc * ld, X, n_loc, m, ld));
+    ctx->precon_stage = 2;
+  }
+  double* d_lev;
+  GDML_TRY(ctx_slot(ctx, 2, sg.n_pad * 8, &d_lev));
+  if (n_loc > 0)
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(ceil_div(n_loc, 4)), dim3(256), 0, ctx->stream, X, ld, n_loc, m,
+                       d_lev + sg.row0);
+  GDML_TRY(comm_allgather_inplace(ctx, d_lev, sg.chunk));
+  HIP_CHECK(ctx, hipMemcpyAsync(lev_scores_out, d_lev, sg.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return GDML_OK;
+}
+
+extern "C" int gdml_nystroem_lev_scores(gdml_ctx* ctx, double* lev_scores_out) {
+  if (!ctx || !lev_scores_out) return GDML_ERR_INVALID;
+  if (!ctx->precon || !ctx->K)
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_nystroem_lev_scores: no Nystroem factor resident (an assembly since "
+                                          "gdml_nystroem_factor overwrites it)");
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const ShardGeo sg = shard_geo(ctx);
+  int rc = lev_scores_to_host(ctx, sg, lev_scores_out);
+  if (rc == GDML_ERR_HIP) comm_abort(ctx);
+  return rc;
+}
+
 extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* idx, int64_t m,
                                     double* lev_scores_out, double* LinvKmn_host_out, int* info) {
   if (!ctx || !idx || m < 1) return GDML_ERR_INVALID;
@@ -492,14 +815,29 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
   if (info) *info = 0;
   double* X = ctx->K;               // this rank's rows of K_nm
   double* S = ctx->K + n_loc * ld;  // m x m work block (replicated)
+  int form = choose_precon_form(ctx, sg, m, ld);
+  // matrix-free form: Z = L_mm^-T L^-T, built by applying to the m x m identity every triangular solve X receives
+  double* Z = nullptr;
+  if (form == 1) {
+    GDML_TRY(ensure_buf(ctx, (void**)&ctx->precon_Z, &ctx->precon_Z_bytes, m * ld * 8));
+    Z = ctx->precon_Z;
+  }
+  GDML_TRY(ensure_buf(ctx, (void**)&ctx->precon_idx, &ctx->precon_idx_bytes, m * 8));
+  int64_t* d_idx = ctx->precon_idx;
   void* tmp = nullptr;
-  GDML_TRY(ctx_alloc(ctx, &tmp, m * m * 8 + m * 8));
+  GDML_TRY(ctx_alloc(ctx, &tmp, m * m * 8));
   double* backup = (double*)tmp;
-  int64_t* d_idx = (int64_t*)(backup + m * m);
+  // the second solve of X is only needed by the stored form, the leverage scores and the host copy
+  const bool want_X = form != 1 || lev_scores_out || LinvKmn_host_out;
+  int stage = 1;
   int rc = GDML_OK;
   auto body = [&]() -> int {
     HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
     phase_begin(ctx);
+    if (Z) {
+      HIP_CHECK(ctx, hipMemsetAsync(Z, 0, m * ld * 8, ctx->stream));
+      hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, Z, ld, m, 1.0);
+    }
     // K_mm = -K[idx, :]: every rank contributes the rows it owns, the sum replicates the block
     hipLaunchKernelGGL(gather_neg_rows_sharded_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, X, S,
                        ld, d_idx, m, sg.row0, n_loc);
@@ -512,17 +850,28 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
       return gdml_fail(ctx, GDML_ERR_NOT_PD,
                        "Failed to factorize despite strong regularization (max: 10)! You could try a larger sigma.");
     GDML_TRY(tall_trsm(ctx, S, X, n_loc, m, ld));  // K_nm <- K_nm L_mm^-T  (iterative.py:276-286)
+    if (Z) GDML_TRY(tall_trsm(ctx, S, Z, m, m, ld));
     // inner = K_nm^T K_nm + lam I  (iterative.py:293-294): local SYRK, summed over the shards
     const int tiles = (int)((m + TT - 1) / TT);
     hipLaunchKernelGGL(syrk_tn_kernel, dim3((unsigned)(tiles * (tiles + 1) / 2)), dim3(256), 0,
-                       ctx->stream, X, ld, n_loc, m, S, ld, tiles);
+                       ctx->stream, X, ld, n_loc, m, S, ld, tiles, 0);
     GDML_TRY(comm_allreduce_sum(ctx, S, m * ld));
     hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, S, ld, m, lam);
     GDML_TRY(cho_factor_stable_dev(ctx, S, m, ld, backup, false, -14, &ok));  // iterative.py:304-306
     if (ok && ctx_opt_i(ctx, "nys.force_qr", 0)) ok = 0;  // test hook: take the alternative branch
     if (ok) {
-      GDML_TRY(tall_trsm(ctx, S, X, n_loc, m, ld));  // iterative.py:335-345
+      if (want_X) {
+        GDML_TRY(tall_trsm(ctx, S, X, n_loc, m, ld));  // iterative.py:335-345
+        stage = 2;
+      }
+      if (Z) GDML_TRY(tall_trsm(ctx, S, Z, m, m, ld));
+      if (form == 3) {
+        int usable = 0;
+        GDML_TRY(build_f32_form(ctx, lam, X, S, n_loc, m, ld, &usable));
+        if (!usable) form = 0;
+      }
     } else {
+      if (form == 3) form = 0;  // no Cholesky factor of the inner matrix to take the exact Gram from: the reference's form
       // "QR fact. (alt.)" (iterative.py:313-324): R of the stacked matrix [K_nm; sqrt(lam) I], i.e. the Cholesky
       // factor of K_nm^T K_nm + lam I obtained WITHOUT trusting the Gram matrix.  Here: shifted CholeskyQR3 -- three
       // rounds of (Gram on fp64 MFMA, small Cholesky, tall triangular solve); the first Gram is shifted so that
@@ -543,7 +892,7 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
         const int64_t rows = n_loc + ((!ctx->K_sharded || ctx->rank == 0) ? m : 0);
         const int tiles = (int)((m + TT - 1) / TT);
         hipLaunchKernelGGL(syrk_tn_kernel, dim3((unsigned)(tiles * (tiles + 1) / 2)), dim3(256), 0, ctx->stream, X, ld,
-                           rows, m, G, ld, tiles);
+                           rows, m, G, ld, tiles, 0);
         rcq = comm_allreduce_sum(ctx, G, m * ld);
         if (rcq != GDML_OK) break;
         if (pass == 0) {
@@ -566,7 +915,9 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
           rcq = gdml_fail(ctx, GDML_ERR_NOT_PD, "Nystroem factor: K_nm^T K_nm + lam I is singular to working precision "
                                                 "(shifted CholeskyQR pass %d failed at pivot %d)", pass + 1, inf);
         if (rcq == GDML_OK) rcq = tall_trsm(ctx, G, X, n_loc + m, m, ld);  // X and B (every rank its own copy of B)
+        if (rcq == GDML_OK && Z) rcq = tall_trsm(ctx, G, Z, m, m, ld);
       }
+      stage = 2;  // the three factors are gone after this branch: X is always completed here
       int rcf = ctx_free(ctx, gtmp);
       GDML_TRY(rcq);
       GDML_TRY(rcf);
@@ -580,18 +931,15 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
     ctx->precon = X;
     ctx->precon_m = m;
     ctx->precon_n = sg.n;
+    ctx->precon_form = form;
+    ctx->precon_stage = stage;
+    ctx->precon_sig = ctx->K_sig;
+    ctx->precon_use_E = ctx->K_use_E;
+    if (info && form == 1) *info |= 2;
+    if (info && form == 3) *info |= 4;
     if (lev_scores_out) {
-      double* d_lev;
-      rc = ctx_slot(ctx, 2, sg.n_pad * 8, &d_lev);
-      if (rc == GDML_OK && n_loc > 0)
-        hipLaunchKernelGGL(row_sqnorm_kernel, dim3(ceil_div(n_loc, 4)), dim3(256), 0, ctx->stream, X, ld,
-                           n_loc, m, d_lev + sg.row0);
-      if (rc == GDML_OK) rc = comm_allgather_inplace(ctx, d_lev, sg.chunk);
-      if (rc == GDML_OK) {
-        hipError_t e = hipMemcpyAsync(lev_scores_out, d_lev, sg.n * 8, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "lev scores: %s", hipGetErrorString(e));
-      }
+      rc = lev_scores_to_host(ctx, sg, lev_scores_out);
+      if (rc == GDML_ERR_HIP) comm_abort(ctx);
     }
     if (rc == GDML_OK && LinvKmn_host_out) {
       // host gets this rank's columns of L^-1 K_mn as an (m x n_loc) array: transpose of X
@@ -610,11 +958,106 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
   return rc != GDML_OK ? rc : rc2;
 }
 
+// Matrix-free form: d_out = (K_nm Z Z^T K_mn d_v - d_v)/lam.  The n x m factor X = K_nm Z is never read: K_mn v is the
+// kernel mat-vec followed by a gather of the m inducing entries, K_nm t a scatter into an n-vector followed by the
+// mat-vec -- 2 x 10 M^2 P D flops and 16 m^2 bytes per application instead of 16 n m bytes (at configs[2]: 2 x 1.0 ms +
+// 0.3 ms against 7.8 ms).  Sharded: the mat-vecs are query-sharded and all-gather their result; Z is replicated.
+static int precon_apply_mf(gdml_ctx* ctx, double lam, const double* d_v, double* d_out) {
+  const int64_t m = ctx->precon_m, n = ctx->precon_n, ld = ctx->K_ld;
+  if (!ctx->precon_Z || !ctx->precon_idx) return gdml_fail(ctx, GDML_ERR_STATE, "matrix-free preconditioner not resident");
+  Model& md = ctx->model;
+  if (!md.xp || md.M != ctx->ts.M || md.N != ctx->ts.N || md.P != ctx->ts.P || md.sig != ctx->precon_sig)
+    GDML_TRY(operator_model_from_trainset(ctx, ctx->precon_sig));
+  int64_t n_pad = n;
+  if (ctx->world > 1) {
+    int64_t p0, p1, per;
+    shard_points(ctx, ctx->ts.M, &p0, &p1, &per);
+    n_pad = per * 3 * ctx->ts.N * ctx->world;
+    if (n_pad < n) n_pad = n;
+  }
+  n_pad = (n_pad + 31) / 32 * 32;
+  const int64_t m_pad = (m + 31) / 32 * 32;
+  const int rows_per = 512;
+  const int nparts = (int)((m + rows_per - 1) / rows_per);
+  double* buf;
+  GDML_TRY(ctx_slot(ctx, 10, (2 * n_pad + 2 * m_pad + (int64_t)nparts * m_pad) * 8, &buf));
+  double* s = buf;            // K v, later K e
+  double* e = s + n_pad;      // scattered m-vector
+  double* t1 = e + n_pad;
+  double* t2 = t1 + m_pad;
+  double* part = t2 + m_pad;
+  hipStream_t st = ctx->stream;
+  const double* Z = ctx->precon_Z;
+  GDML_TRY(matvec_device(ctx, 0.0, ctx->precon_use_E, d_v, n, s));
+  hipLaunchKernelGGL(gather_idx_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, s, ctx->precon_idx, m, t1);
+  hipLaunchKernelGGL(gemv_t_part_kernel<false>, dim3(ceil_div(m, 512), nparts), dim3(256), 0, st, Z, ld, m, m, t1, rows_per,
+                     part);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, part, m, nparts, t2);
+  hipLaunchKernelGGL((gemv_n_precon_kernel<false, false>), dim3(ceil_div(m, 4)), dim3(256), 0, st, Z, ld, m, m, t2,
+                     (const double*)nullptr, 1.0, t1);
+  HIP_CHECK(ctx, hipMemsetAsync(e, 0, n_pad * 8, st));
+  hipLaunchKernelGGL(scatter_idx_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, t1, ctx->precon_idx, m, e);
+  GDML_TRY(matvec_device(ctx, 0.0, ctx->precon_use_E, e, n, s));
+  hipLaunchKernelGGL(precon_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, s, d_v, 1.0 / lam, n, d_out);
+  ctx->launch_counter += 7;
+  HIP_CHECK(ctx, hipGetLastError());
+  return GDML_OK;
+}
+
 // d_out = (X X^T d_v - d_v)/lam on replicated (padded) device vectors; X row-sharded
 static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, double* d_out) {
   if (!ctx->precon) return gdml_fail(ctx, GDML_ERR_STATE, "no preconditioner resident");
+  if (ctx->precon_form == 1) return precon_apply_mf(ctx, lam, d_v, d_out);
   const ShardGeo sg = shard_geo(ctx);
   const int64_t n_loc = sg.n_loc, m = ctx->precon_m, ld = ctx->K_ld;
+  if (ctx->precon_form == 3) {
+    // (X32 T0 X32^T v - v)/lam: the two passes read n_loc x m x 4 bytes each; T0 (m x m, fp64, replicated) in between
+    if (!ctx->precon_X32 || !ctx->precon_T0) return gdml_fail(ctx, GDML_ERR_STATE, "fp32 preconditioner not resident");
+    const bool nt = ctx_opt_i(ctx, "pcg.gemv_plain", 0) == 0;
+    int rows_per = ctx_opt_i(ctx, "pcg.f32_rows_per", 1024);
+    if (rows_per < 64) rows_per = 64;
+    int rw = ctx_opt_i(ctx, "pcg.f32_rw", 4);
+    int nparts = (int)((n_loc + rows_per - 1) / rows_per);
+    if (nparts < 1) nparts = 1;
+    double* buf;
+    GDML_TRY(ctx_slot(ctx, 3, ((int64_t)nparts * m + 2 * ld + 4) * 8, &buf));
+    double* part = buf;
+    double* t = buf + (((int64_t)nparts * m + 1) & ~(int64_t)1);
+    double* u = t + ld;
+    const int slot = ktime_begin(ctx);
+    if (n_loc > 0) {
+      if (nt)
+        hipLaunchKernelGGL(gemv_t_part_f32_kernel<true>, dim3(ceil_div(m, 1024), nparts), dim3(256), 0, ctx->stream,
+                           ctx->precon_X32, ld, n_loc, m, d_v + sg.row0, rows_per, part);
+      else
+        hipLaunchKernelGGL(gemv_t_part_f32_kernel<false>, dim3(ceil_div(m, 1024), nparts), dim3(256), 0, ctx->stream,
+                           ctx->precon_X32, ld, n_loc, m, d_v + sg.row0, rows_per, part);
+      hipLaunchKernelGGL(reduce_parts_kahan_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m, nparts, t);
+    } else {
+      HIP_CHECK(ctx, hipMemsetAsync(t, 0, m * 8, ctx->stream));
+    }
+    GDML_TRY(comm_allreduce_sum(ctx, t, m));
+    HIP_CHECK(ctx, hipMemsetAsync(u, 0, ld * 8, ctx->stream));  // pad entries [m, m4) stay zero
+    hipLaunchKernelGGL((gemv_n_precon_kernel<false, false>), dim3(ceil_div(m, 4)), dim3(256), 0, ctx->stream, ctx->precon_T0,
+                       ld, m, m, t, (const double*)nullptr, 1.0, u);
+    if (n_loc > 0) {
+      const float* X32 = ctx->precon_X32;
+      const double *vv = d_v + sg.row0;
+      double* oo = d_out + sg.row0;
+      const double il = 1.0 / lam;
+#define GDML_GEMV_N_F32(NT_, RW_)                                                                                          \
+  hipLaunchKernelGGL((gemv_n_precon_f32_kernel<NT_, RW_>), dim3(ceil_div(n_loc, 4 * RW_)), dim3(256), 0, ctx->stream, X32, \
+                     ld, n_loc, m, u, vv, il, oo)
+      if (rw >= 4) { if (nt) GDML_GEMV_N_F32(true, 4); else GDML_GEMV_N_F32(false, 4); }
+      else if (rw >= 2) { if (nt) GDML_GEMV_N_F32(true, 2); else GDML_GEMV_N_F32(false, 2); }
+      else { if (nt) GDML_GEMV_N_F32(true, 1); else GDML_GEMV_N_F32(false, 1); }
+#undef GDML_GEMV_N_F32
+    }
+    ktime_end(ctx, slot, "precon_gemv", 2.0 * 4.0 * (double)n_loc * (double)m + 8.0 * (double)m * (double)m);
+    ctx->launch_counter += 5;
+    HIP_CHECK(ctx, hipGetLastError());
+    return comm_allgather_inplace(ctx, d_out, sg.chunk);
+  }
   // non-temporal loads of the factor (it is streamed: 25 GB per pass at configs[2]): PCG iteration 9.66 -> 9.01 ms
   // (profiles/r04_gemv_nt_ab.txt); pcg.gemv_plain = 1: plain loads (A/B)
   const bool nt = ctx_opt_i(ctx, "pcg.gemv_plain", 0) == 0;
@@ -625,6 +1068,7 @@ static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, dou
   GDML_TRY(ctx_slot(ctx, 3, ((int64_t)nparts * m + m + 2) * 8, &buf));
   double* part = buf;
   double* t = buf + (((int64_t)nparts * m + 1) & ~(int64_t)1);  // 16-byte aligned: read in pairs
+  const int kslot = ktime_begin(ctx);
   if (n_loc > 0) {
     if (nt)
       hipLaunchKernelGGL(gemv_t_part_kernel<true>, dim3(ceil_div(m, 512), nparts), dim3(256), 0, ctx->stream,
@@ -646,6 +1090,7 @@ static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, dou
       hipLaunchKernelGGL(gemv_n_precon_kernel<false>, dim3(ceil_div(n_loc, 4)), dim3(256), 0, ctx->stream, ctx->precon, ld,
                          n_loc, m, t, d_v + sg.row0, 1.0 / lam, d_out + sg.row0);
   }
+  ktime_end(ctx, kslot, "precon_gemv", 2.0 * 8.0 * (double)n_loc * (double)m);
   ctx->launch_counter += 3;
   HIP_CHECK(ctx, hipGetLastError());
   return comm_allgather_inplace(ctx, d_out, sg.chunk);

@@ -102,6 +102,22 @@ struct gdml_ctx {
   // Nystroem preconditioner L^-1 K_mn (m x n)
   double* precon = nullptr;
   int64_t precon_m = 0, precon_n = 0;
+  // form of the resident preconditioner (option pcg.precon_form): 0 = the stored n x m factor X = K_nm Z is streamed twice
+  // per application; 1 = matrix-free, P v = (K_nm Z Z^T K_mn v - v)/lam through two kernel mat-vecs and the m x m matrix
+  // Z = L_mm^-T L^-T (cg.hip).  precon_stage: triangular solves applied to X so far (1: only L_mm^-T -- the matrix-free
+  // form does not need the second one until somebody asks for leverage scores).
+  int precon_form = 0, precon_stage = 2, precon_use_E = 0;
+  double precon_sig = 0;
+  double* precon_Z = nullptr;     // m x K_ld, upper triangular
+  int64_t precon_Z_bytes = 0;
+  int64_t* precon_idx = nullptr;  // device copy of the inducing column indices (m)
+  int64_t precon_idx_bytes = 0;
+  // form 3: the factor rounded to fp32 (n_loc x K_ld floats) + the m x m correction T0 that makes
+  // (X32 T0 X32^T - I)/lam the exact Woodbury inverse on range(X32) (cg.hip)
+  float* precon_X32 = nullptr;
+  int64_t precon_X32_bytes = 0;
+  double* precon_T0 = nullptr;
+  int64_t precon_T0_bytes = 0;
 
   // scratch
   double* scratch = nullptr;

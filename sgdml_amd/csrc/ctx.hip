@@ -1,6 +1,8 @@
 // Context, memory, phase timers, raw buffer helpers.
 #include <stdarg.h>
 
+#include <mutex>
+
 #include "common.h"
 
 static std::string g_create_err;
@@ -18,7 +20,7 @@ int gdml_fail(gdml_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int gdml_abi_version(void) { return 3; }
+extern "C" int gdml_abi_version(void) { return 4; }
 
 // ---- options --------------------------------------------------------------------------------
 // Every tuning / ablation switch of the library is a (key, value) pair of the context, read at the
@@ -31,7 +33,7 @@ static const char* kKnownOptions[] = {
     "gemm.debug", "gemm.nt_c", "gemm.lds16", "chol.nb", "chol.small_update", "pcg.gemv_plain", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
     "chol.fused_min_rows", "chol.outer", "chol.outer_min_rows", "chol.merge_gemm1", "chol.tail_lookahead", "trsm.debug",
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
-    "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb", "dist.lookahead", "pcg.depth"};
+    "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb", "dist.lookahead", "pcg.depth", "pcg.precon_form", "pcg.f32_rows_per", "pcg.f32_rw", "pcg.f32_min_pivot", "pcg.f32_last_min_pivot"};
 
 double ctx_opt(const gdml_ctx* ctx, const char* key, double dflt) {
   auto it = ctx->opts.find(key);
@@ -75,27 +77,64 @@ static void options_from_env(gdml_ctx* ctx) {
 // hipMalloc of the large kernel matrices costs seconds on this driver once a request passes what the runtime has at hand
 // (3.5-6.5 s for 128-200 GB, erratic below: profiles/r03_malloc_probe.txt, r04_malloc_probe.txt -- hipMallocAsync pools and
 // hipMemCreate / hipMemMap pay the same per byte), and hipFree gives it back.  A long-lived process therefore reserves
-// ONE block per device once and keeps it: the context's large buffers (in practice the kernel matrix / the Nystroem
-// matrix) are carved from it, a buffer handed back is not freed, and the block survives contexts.  One tenant at a time:
-// a second large request while the arena is taken falls through to hipMalloc.
+// ONE block per device once and keeps it: the large buffers of every context on the device (the kernel matrix / the
+// Nystroem matrix, the fp32 copy of the preconditioner factor, its m x m companions) are carved from it first-fit, a
+// buffer handed back is not freed, and the block survives contexts.  A request that fits no gap goes to hipMalloc.
+// (Round 4 had one tenant at a time; the idle remainder could not be handed out, which the memory models had to know.)
+struct ArenaBlock {
+  int64_t off, bytes;
+  gdml_ctx* owner;
+};
 struct DeviceArena {
   void* base = nullptr;
   int64_t bytes = 0;
-  gdml_ctx* owner = nullptr;  // context holding the block, or null
-  int64_t used = 0;
+  std::vector<ArenaBlock> blocks;  // sorted by offset
 };
 static DeviceArena g_arena[64];
-static const int64_t kArenaMinRequest = (int64_t)4 << 30;  // the matrices; work buffers (<= ~3 GB by construction) stay with hipMalloc,
-                                                          // so a cached work slot can never sit on the arena when a matrix needs it
+// Contexts of one process live on several threads (a solve in a worker thread, a Python __del__ closing a context from
+// another): every read or write of an arena entry happens under this lock.  It is never held across a kernel launch;
+// hipMalloc / hipFree of the block itself run under it (seconds, once per process).
+static std::mutex g_arena_mu;
+static const int64_t kArenaMinRequest = (int64_t)1 << 30;  // small work buffers stay with hipMalloc
+static const int64_t kArenaAlign = (int64_t)2 << 20;
 
 static DeviceArena* arena_of(const gdml_ctx* ctx) { return (ctx->device >= 0 && ctx->device < 64) ? &g_arena[ctx->device] : nullptr; }
 
-static void arena_release_owner(gdml_ctx* ctx) {
-  DeviceArena* a = arena_of(ctx);
-  if (a && a->owner == ctx) {
-    a->owner = nullptr;
-    a->used = 0;
+// first-fit carve; caller holds g_arena_mu.  Returns nullptr when no gap is large enough.
+static void* arena_carve(DeviceArena* a, gdml_ctx* ctx, int64_t bytes) {
+  const int64_t need = (bytes + kArenaAlign - 1) / kArenaAlign * kArenaAlign;
+  int64_t off = 0;
+  size_t pos = 0;
+  for (; pos <= a->blocks.size(); ++pos) {
+    const int64_t end = pos < a->blocks.size() ? a->blocks[pos].off : a->bytes;
+    if (end - off >= need) break;
+    if (pos < a->blocks.size()) off = a->blocks[pos].off + a->blocks[pos].bytes;
   }
+  if (pos > a->blocks.size()) return nullptr;
+  a->blocks.insert(a->blocks.begin() + (long)pos, ArenaBlock{off, need, ctx});
+  return (char*)a->base + off;
+}
+static bool arena_owns(const DeviceArena* a, const void* p) {
+  return a && a->base && (const char*)p >= (const char*)a->base && (const char*)p < (const char*)a->base + a->bytes;
+}
+static void arena_release(DeviceArena* a, const void* p) {  // caller holds g_arena_mu
+  const int64_t off = (const char*)p - (const char*)a->base;
+  for (size_t i = 0; i < a->blocks.size(); ++i)
+    if (a->blocks[i].off == off) {
+      a->blocks.erase(a->blocks.begin() + (long)i);
+      return;
+    }
+}
+static void arena_release_owner(gdml_ctx* ctx) {  // caller holds g_arena_mu
+  DeviceArena* a = arena_of(ctx);
+  if (!a) return;
+  for (size_t i = a->blocks.size(); i-- > 0;)
+    if (a->blocks[i].owner == ctx) a->blocks.erase(a->blocks.begin() + (long)i);
+}
+static int64_t arena_idle_bytes(const DeviceArena* a) {  // caller holds g_arena_mu
+  int64_t used = 0;
+  for (const ArenaBlock& b : a->blocks) used += b.bytes;
+  return a->bytes - used;
 }
 
 extern "C" int gdml_device_count(int* n_out) {
@@ -170,9 +209,10 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   }
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
     DeviceArena* a = arena_of(ctx);
     for (auto& kv : ctx->allocs)
-      if (!(a && a->base == kv.first && a->owner == ctx)) hipFree(kv.first);
+      if (!arena_owns(a, kv.first)) hipFree(kv.first);
     ctx->allocs.clear();
     arena_release_owner(ctx);  // the block itself stays with the process
   }
@@ -207,11 +247,12 @@ extern "C" int gdml_mem_info(gdml_ctx* ctx, int64_t* held, int64_t* free_b, int6
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   HIP_CHECK(ctx, hipMemGetInfo(&f, &t));
   if (held) *held = ctx->held;
-  // what a large buffer of THIS context could get: driver-free memory plus the part of the process arena nobody uses
-  // (the context's own resident matrix is re-used in place by the next assembly: callers add it themselves)
+  // what a large buffer of this context could get: driver-free memory plus the idle part of the process arena (the
+  // context's own resident matrix is re-used in place by the next assembly: callers add resident_K_bytes themselves)
   {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
     const DeviceArena* a = arena_of(ctx);
-    if (a && a->base && (a->owner == nullptr || a->owner == ctx)) f += (size_t)(a->bytes - a->used);
+    if (a && a->base) f += (size_t)arena_idle_bytes(a);
   }
   if (free_b) *free_b = (int64_t)f;
   if (total_b) *total_b = (int64_t)t;
@@ -223,8 +264,9 @@ extern "C" int gdml_mem_reserve(gdml_ctx* ctx, int64_t bytes, int64_t* reserved_
   DeviceArena* a = arena_of(ctx);
   if (!a) return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_mem_reserve: device index out of range");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lk(g_arena_mu);
   if (bytes != a->bytes || bytes == 0) {
-    if (a->owner) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_mem_reserve: the arena is in use (a context holds its kernel matrix)");
+    if (!a->blocks.empty()) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_mem_reserve: the arena is in use (a context holds a buffer carved from it)");
     if (a->base) {
       HIP_CHECK(ctx, hipFree(a->base));
       a->base = nullptr;
@@ -250,22 +292,29 @@ int ctx_alloc(gdml_ctx* ctx, void** p, int64_t bytes) {
   if (bytes <= 0) bytes = 8;
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   DeviceArena* a = arena_of(ctx);
-  if (a && a->base && !a->owner && bytes >= kArenaMinRequest && bytes <= a->bytes) {
-    a->owner = ctx;
-    a->used = bytes;
-    *p = a->base;
-    ctx->allocs[*p] = bytes;
-    ctx->held += bytes;
-    return GDML_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    if (a && a->base && bytes >= kArenaMinRequest && bytes <= a->bytes) {
+      void* q = arena_carve(a, ctx, bytes);
+      if (q) {
+        *p = q;
+        ctx->allocs[*p] = bytes;
+        ctx->held += bytes;
+        return GDML_OK;
+      }
+    }
   }
   hipError_t e = hipMalloc(p, (size_t)bytes);
-  if (e == hipErrorOutOfMemory && a && a->base && !a->owner) {
+  if (e == hipErrorOutOfMemory && a) {
     // an idle arena must not be the reason a larger request fails: give it back and try once more
-    (void)hipGetLastError();
-    (void)hipFree(a->base);
-    a->base = nullptr;
-    a->bytes = 0;
-    e = hipMalloc(p, (size_t)bytes);
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    if (a->base && a->blocks.empty()) {
+      (void)hipGetLastError();
+      (void)hipFree(a->base);
+      a->base = nullptr;
+      a->bytes = 0;
+      e = hipMalloc(p, (size_t)bytes);
+    }
   }
   if (e != hipSuccess) {
     *p = nullptr;
@@ -285,10 +334,13 @@ int ctx_free(gdml_ctx* ctx, void* p) {
   HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->held -= it->second;
   ctx->allocs.erase(it);
-  DeviceArena* a = arena_of(ctx);
-  if (a && a->base == p && a->owner == ctx) {  // back to the arena, not to the driver
-    arena_release_owner(ctx);
-    return GDML_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    DeviceArena* a = arena_of(ctx);
+    if (arena_owns(a, p)) {  // back to the arena, not to the driver
+      arena_release(a, p);
+      return GDML_OK;
+    }
   }
   HIP_CHECK(ctx, hipFree(p));
   return GDML_OK;

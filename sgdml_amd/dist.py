@@ -118,6 +118,16 @@ def init_comm_from_torch_distributed(ctx, group=None, backend='rccl'):
     else:
         raise ValueError("backend must be 'rccl' or 'host'")
     ctx._bcast = lambda arr, src=0: broadcast_array(arr, src=src, group=group)
+    # the rank as the group knows it: gdml_comm_info answers 0 of 1 while the communicator is parked (gdml_comm_suspend), so
+    # anything that must happen on ONE rank (checkpoint writers) is gated on this, not on comm_info()
+    ctx._dist_rank, ctx._dist_world = rank, world
+
+    def all_min(value):
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return float(t[0])
+
+    ctx._all_min = all_min
     return rank, world
 
 

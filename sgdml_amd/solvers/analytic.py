@@ -48,7 +48,13 @@ class Analytic(object):
                 n = len(y)
                 need = Analytic.est_device_memory(n_train, (1 + int(np.sqrt(8 * dim_d + 1))) // 2, False)
                 _, free_b, _ = ctx.mem_info()
-                if need > free_b + ctx.resident_K_bytes():
+                fits = need <= free_b + ctx.resident_K_bytes()
+                # free HBM differs between ranks: the decision is collective (minimum over the ranks), or one rank re-raises
+                # while the others finish the LU and the next collective hangs
+                all_min = getattr(ctx, '_all_min', None)
+                if all_min is not None:
+                    fits = bool(all_min(1.0 if fits else 0.0))
+                if not fits:
                     raise
                 if self.callback is not None:
                     cb = partial(self.callback, disp_str='Solving linear system (LU factorization)      ')

@@ -57,7 +57,7 @@ class Iterative(object):
 
     def _nystroem_cholesky_factor(
         self, R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr, col_idxs, callback_task_name='',
-        callback=None, want_factor=True,
+        callback=None, want_factor=True, want_lev=True,
     ):
         """L^-1 K_mn (m x n) for the inducing columns col_idxs (iterative.py:208-351).  The factor stays
         resident on the GPU as the preconditioner; the host copy is optional."""
@@ -75,19 +75,31 @@ class Iterative(object):
         ctx.assemble_K(sig, use_E_cstr, idx=col_idxs, alloc_extra_rows=m)
         if callback is not None:
             callback(DONE)
-        lev, fac, _ = ctx.nystroem_factor(lam, col_idxs, want_factor=want_factor)
+        lev, fac, info = ctx.nystroem_factor(lam, col_idxs, want_factor=want_factor, want_lev=want_lev)
         self._last_lev_scores = lev
+        self._last_factor_info = info
         return fac
 
-    def _init_precon_operator(self, task, R_desc, R_d_desc, tril_perms_lin, inducing_pts_idxs, callback=None):
-        """Builds the device-resident preconditioner; returns (apply, lev_scores) (iterative.py:83-142)."""
+    def _init_precon_operator(self, task, R_desc, R_d_desc, tril_perms_lin, inducing_pts_idxs, callback=None,
+                              want_lev=True):
+        """Builds the device-resident preconditioner; returns (apply, lev_scores) (iterative.py:83-142).  The reference
+        gets the leverage scores "basically for free once we got the factor" (:107-109); here they are one more pass over
+        the resident factor, so solve() asks for them only when a restart needs them (want_lev=False: lev_scores is None,
+        self._lev_scores_now() computes them from the resident matrix).  self.precon_form reports how the library will
+        apply the operator (option pcg.precon_form): 'stored' = the reference's fp64 factor, 'fp32' = the factor rounded to
+        fp32 with its m x m Gram correction (large systems), 'matrix-free' (experimental)."""
         lam = task['lam']
         self._nystroem_cholesky_factor(
             R_desc, R_d_desc, tril_perms_lin, task['sig'], lam, use_E_cstr=task['use_E_cstr'],
-            col_idxs=inducing_pts_idxs, callback=callback, want_factor=False,
+            col_idxs=inducing_pts_idxs, callback=callback, want_factor=False, want_lev=want_lev,
         )
         ctx = self._ctx()
+        self.precon_form = {0: 'stored', 2: 'matrix-free', 4: 'fp32'}[self._last_factor_info & 6]
         return (lambda v: ctx.precon_apply(lam, v)), self._last_lev_scores
+
+    def _lev_scores_now(self):
+        """Leverage scores of the resident preconditioner (valid until the next assembly)."""
+        return self._ctx().nystroem_lev_scores()
 
     def _init_kernel_operator(self, task, R_desc, R_d_desc, tril_perms_lin, lam, n, callback=None):
         """Matrix-free K v - lam v on the training set (iterative.py:144-206)."""
@@ -174,7 +186,8 @@ class Iterative(object):
         else:
             lev_scores = self._lev_scores(R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr, n_inducing_pts)
             inducing_pts_idxs = self.inducing_pts_from_lev_scores(lev_scores, n_inducing_pts * dim_i)
-        _, lev_scores = self._init_precon_operator(task, R_desc, R_d_desc, tril_perms_lin, inducing_pts_idxs)
+        _, lev_scores = self._init_precon_operator(task, R_desc, R_d_desc, tril_perms_lin, inducing_pts_idxs,
+                                                   want_lev=False)
         if self.callback is not None:
             dur_s = timeit.default_timer() - start
             self.callback(DONE, sec_disp_str='took {:.1f} s'.format(dur_s) if dur_s >= 0.1 else '')
@@ -247,7 +260,9 @@ class Iterative(object):
                     ctx.set_alphas(alphas_F, alphas_E)
                     E_pred, _ = ctx.predict(None)
                     unconv_model['c'] = np.mean(np.squeeze(task['E_train']) - E_pred * y_std)
-                if save_progr_callback is not None and (not sharded or ctx.comm_info()[0] == 0):  # one writer
+                # one writer: the group's rank 0 (comm_info() reports rank 0 on EVERY rank while the communicator is
+                # parked for a redundant solve, so the gate is the rank recorded by init_distributed)
+                if save_progr_callback is not None and getattr(ctx, '_dist_rank', 0) == 0:
                     save_progr_callback(unconv_model)
 
             state['num_iters'] += 1
@@ -277,8 +292,11 @@ class Iterative(object):
                 alphas = -state['alpha_t']
                 break
             n_inducing_pts = min(int(np.ceil(1.2 * n_inducing_pts)), n_train)
+            if lev_scores is None:  # the scores of the preconditioner that just stagnated (iterative.py:783-789)
+                lev_scores = self._lev_scores_now()
             inducing_pts_idxs = self.inducing_pts_from_lev_scores(lev_scores, n_inducing_pts * dim_i)
-            _, lev_scores = self._init_precon_operator(task, R_desc, R_d_desc, tril_perms_lin, inducing_pts_idxs)
+            _, lev_scores = self._init_precon_operator(task, R_desc, R_d_desc, tril_perms_lin, inducing_pts_idxs,
+                                                       want_lev=False)
             self._init_kernel_operator(task, R_desc, R_d_desc, tril_perms_lin, lam, n)
             if num_restarts <= 2:  # the reference's benchmark cache answers from its third result on (predict.py:815-830)
                 self._spend_reference_benchmark_draw(n_train, dim_i)

@@ -391,6 +391,7 @@ class GDMLTrain(object):
             ) = iterative.solve(task, R_desc, R_d_desc, tril_perms_lin, y, y_std,
                                 save_progr_callback=save_progr_callback)
             solver_keys['norm_y_train'] = np.linalg.norm(y)
+            self._last_precon_form = getattr(iterative, 'precon_form', None)  # 'stored' / 'matrix-free' (diagnostics)
             if not is_conv:
                 self.log.warning('Iterative solver did not converge!')
 

@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 def main():
     out_path, n_atoms, n_train, nb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     backend = sys.argv[5] if len(sys.argv) > 5 else 'host'  # 'rccl': one GPU per rank, collectives inside the library
+    lookahead = int(sys.argv[6]) if len(sys.argv) > 6 else 0  # dist.lookahead: the three-stream schedule + second communicator
     import torch.distributed as dist
 
     dist.init_process_group('gloo')
@@ -26,6 +27,7 @@ def main():
     ctx = _lib.Context(0 if backend == 'host' else int(os.environ.get('LOCAL_RANK', rank)))
     init_comm_from_torch_distributed(ctx, backend=backend)
     ctx.set_option('dist.nb', nb)
+    ctx.set_option('dist.lookahead', lookahead)
     xd, gd = ctx.desc_from_R(ds['R'].reshape(n_train, -1), n_atoms)
     ctx.train_upload(xd, gd, np.arange(n_atoms * (n_atoms - 1) // 2, dtype=np.int64)[None])
     alphas = ctx.dist_chol_solve(20.0, 1e-10, y)

@@ -23,16 +23,49 @@ def main():
     from sgdml_amd.train import GDMLTrain
 
     # solver 'ecstr' / 'lu': what the sharded solvers do not carry, run by every rank redundantly (parked communicator)
-    fixture = {'ecstr': 'n5_p2_ecstr', 'lu': 'lu_branch'}.get(solver, 'pcg_n9_m400')
+    fixture = {'ecstr': 'n5_p2_ecstr', 'ecstr_cg': 'n5_p2_ecstr', 'lu': 'lu_branch'}.get(solver, 'pcg_n9_m400')
     g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', fixture + '.npz')))
     M, N = g['R_train'].shape[:2]
     task = {
         'type': 't', 'code_version': '1.0.3', 'dataset_name': np.array('synth'), 'dataset_theory': np.array('pair'),
         'z': g['z'] if 'z' in g else np.full(N, 6), 'R_train': g['R_train'], 'F_train': g['F_train'], 'E_train': g['E_train'],
         'idxs_train': np.arange(M), 'md5_train': 'x', 'idxs_valid': np.arange(0), 'md5_valid': 'x',
-        'sig': int(g['sig']), 'lam': float(g['lam']), 'use_E': True, 'use_E_cstr': solver == 'ecstr',
+        'sig': int(g['sig']), 'lam': float(g['lam']), 'use_E': True, 'use_E_cstr': solver in ('ecstr', 'ecstr_cg'),
         'use_sym': g['perms'].shape[0] > 1, 'perms': g['perms'],
     }
+    if solver == 'ecstr_cg':
+        # energy constraints through the ITERATIVE solver, redundantly on every rank, with a checkpoint writer: the writer
+        # must be the group's rank 0 only although gdml_comm_info says "rank 0" on every rank while the communicator is parked
+        from sgdml_amd.solvers import iterative as it_mod
+
+        class FakeClock(object):  # 60 s per timer call: a checkpoint is due every tenth iteration (iterative.py:675-680)
+            t = 0.0
+
+            def default_timer(self):
+                self.t += 60.0
+                return self.t
+
+        it_mod.timeit = FakeClock()
+        tr = GDMLTrain()
+        tr._force_solver = 'cg'
+        tr._force_n_inducing_pts = 1
+        tr.init_distributed(backend=backend)
+        np.random.seed(5 + rank)
+
+        def writer(m):
+            with open(out_path + '.ckpt.rank%d' % rank, 'a') as f:
+                f.write('%d\n' % int(m['solver_iters']))
+
+        model = tr.train(task, save_progr_callback=writer)
+        assert tr._context().comm_info() == (rank, world)
+        chk = [None] * world
+        dist.all_gather_object(chk, float(np.abs(model['alphas_F']).sum()))
+        assert len(set(chk)) == 1, chk
+        if rank == 0:
+            np.savez(out_path, iters=model['solver_iters'], alphas=model['alphas_F'])
+        tr.__del__()
+        dist.destroy_process_group()
+        return
     if solver in ('ecstr', 'lu'):
         from sgdml_amd.solvers.analytic import Analytic
         took, orig = [], Analytic.solve

@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
     lib = _lib.load()
     for name in _header_functions():
         assert hasattr(lib, name), name
-    assert lib.gdml_abi_version() == 3
+    assert lib.gdml_abi_version() == 4
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -378,16 +378,20 @@ _P6 = np.array([[0, 1, 2, 3, 4, 5, 6, 7, 8], [1, 2, 0, 3, 4, 5, 6, 7, 8], [2, 0,
                 [0, 1, 2, 4, 3, 5, 6, 7, 8], [1, 2, 0, 4, 3, 5, 6, 7, 8], [2, 0, 1, 4, 3, 5, 6, 7, 8]])
 
 
+@pytest.mark.parametrize('lookahead', [0, 1])
 @pytest.mark.parametrize('N,M,nb,perms', [(21, 30, 128, None), (9, 100, 256, None), (21, 70, 512, None),
                                           (9, 60, 256, _P6), (26, 20, 128, None)])
-def test_distributed_cholesky_single_rank(ctx, N, M, nb, perms):
+def test_distributed_cholesky_single_rank(ctx, N, M, nb, perms, lookahead):
     """gdml_dist_chol_solve with one rank (no communicator): row-cyclic assembly (register-resident kernel for
     P = 1, N <= 21; the LDS kernel's cyclic mode for permutation groups and larger molecules), broadcast-buffer panel
-    solve, cyclic-lower trailing update, blocked backward substitution -- vs the single-GPU factorisation."""
+    solve, cyclic-lower trailing update, blocked backward substitution -- vs the single-GPU factorisation.  Both
+    schedules: dist.lookahead = 0 (every step in order on the compute stream, the default) and 1 (one panel of look-ahead
+    over three streams)."""
     ds = orc.synth_dataset(N, M, seed=9, jitter=0.3)
     y = ds['F'].ravel() / np.std(ds['F'])
     a_ref, Kop = _reference_solve(ctx, ds['R'], y, N, 20.0, 1e-10, perms)
     ctx.set_option('dist.nb', nb)
+    ctx.set_option('dist.lookahead', lookahead)
     a = ctx.dist_chol_solve(20.0, 1e-10, y)
     r = Kop(-a) + y  # y - A x with A x = -(K x - lam x)
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(y)
@@ -398,16 +402,19 @@ def test_distributed_cholesky_single_rank(ctx, N, M, nb, perms):
     assert np.abs(a - a_ref).max() <= 1e-4 * np.abs(a_ref).max()
 
 
+@pytest.mark.parametrize('lookahead', [0, 1])
 @pytest.mark.parametrize('world,N,M,nb', [(2, 21, 30, 128), (3, 21, 45, 128), (2, 9, 120, 512)])
-def test_distributed_cholesky_processes_share_one_gpu(tmp_path, ctx, world, N, M, nb):
+def test_distributed_cholesky_processes_share_one_gpu(tmp_path, ctx, world, N, M, nb, lookahead):
     """The block-row-cyclic Cholesky run by `world` processes (each holds only its row blocks of the matrix;
-    collectives host-staged through gloo): same solution as one GPU, and every rank holds ~1/world of the matrix."""
+    collectives host-staged through gloo): same solution as one GPU, and every rank holds ~1/world of the matrix.
+    lookahead = 1: the opt-in three-stream schedule (comm_ensure_second, block broadcasts on the critical stream, panel
+    gather on the collective stream) under host-staged collectives."""
     out = str(tmp_path / 'dchol.npz')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
-    port = 29600 + (os.getpid() % 300) + 7 * world + M % 7
+    port = 29600 + (os.getpid() % 300) + 7 * world + M % 7 + 31 * lookahead
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(ROOT, 'tests', '_dist_chol_worker.py'), out, str(N), str(M), str(nb)]
+           os.path.join(ROOT, 'tests', '_dist_chol_worker.py'), out, str(N), str(M), str(nb), 'host', str(lookahead)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     r = dict(np.load(out))
@@ -468,6 +475,26 @@ def test_dropin_train_distributed_analytic(tmp_path):
         tr.__del__()
     assert np.abs(r['alphas'] - model['alphas_F']).max() <= 1e-5 * np.abs(model['alphas_F']).max()
     assert abs(float(r['c']) - model['c']) <= 1e-6 * max(1.0, abs(model['c']))
+
+
+def test_redundant_iterative_solve_has_one_checkpoint_writer(tmp_path):
+    """Energy constraints after init_distributed: every rank trains redundantly under a parked communicator, where
+    gdml_comm_info answers rank 0 of 1 on EVERY rank.  The checkpoint writer is gated on the group's rank (round-4 advisor
+    finding): with two processes and a clock that makes every tenth iteration a checkpoint, only rank 0 calls
+    save_progr_callback."""
+    out = str(tmp_path / 'ecstr_cg.npz')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+    port = 29900 + (os.getpid() % 40)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', '_sharded_worker.py'), out, 'host', 'ecstr_cg']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r = dict(np.load(out))
+    assert int(r['iters']) >= 20, int(r['iters'])  # long enough for checkpoints to be due
+    written = [ln for ln in open(out + '.ckpt.rank0').read().split() if ln]
+    assert len(written) >= 1 and all(int(v) % 10 == 1 for v in written), written  # solver_iters = iteration + 1
+    assert not os.path.exists(out + '.ckpt.rank1')
 
 
 @pytest.mark.parametrize('mode', ['ecstr', 'lu'])
