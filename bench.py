@@ -635,6 +635,58 @@ def run_sharded_cg(args, rank, world):
     }
 
 
+def predict_sweep(ctx, lib, Rq_all, N, M, P, n_dev_reps=20):
+    """Prediction throughput of the resident model at B = 1, 64 (host arrays in, host E / F out: what the ASE calculator and a
+    small validation loop pay, latency bound) and B = 1000, 16384 (device-resident queries and results: the contraction itself).
+    Roofline per SURVEY.md 8(d): one query costs ~10 M P D flops and, streamed once, 16 M P D bytes of table; a batch shares
+    the table, so large batches are bound by the fp64 pipes and a single query by HBM (in practice by launch latency)."""
+    D = N * (N - 1) // 2
+    N3 = 3 * N
+    flops_q = 10.0 * M * P * D
+    bytes_t = 16.0 * M * P * D
+    out = []
+    for B in (1, 64):
+        q = np.ascontiguousarray(Rq_all[:B])
+        for _ in range(30):
+            ctx.predict(q)
+        ts = []
+        for _ in range(300):
+            t0 = time.perf_counter()
+            ctx.predict(q)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        out.append({'batch': B, 'path': 'host arrays in / out (gdml_predict' + (', single launch)' if B <= 8 else ')'),
+                    'latency_us': t * 1e6, 'geoms_per_s': B / t, 'forces_per_s': B * N3 / t,
+                    'algorithmic_TFLOPs': flops_q * B / t / 1e12, 'table_GBs': bytes_t / t / 1e9})
+    for B in (1000, 16384):
+        reps = -(-B // Rq_all.shape[0])
+        Rq = np.ascontiguousarray(np.tile(Rq_all, (reps, 1))[:B])
+        dR, dE, dF = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        ctx._check(lib.gdml_dev_alloc(ctx._h, B * N3 * 8, C.byref(dR)))
+        ctx._check(lib.gdml_dev_alloc(ctx._h, B * 8, C.byref(dE)))
+        ctx._check(lib.gdml_dev_alloc(ctx._h, B * N3 * 8, C.byref(dF)))
+        ctx._check(lib.gdml_memcpy_h2d(ctx._h, dR, Rq.ctypes.data_as(C.c_void_p), Rq.nbytes))
+        ms = []
+        for rep in range(n_dev_reps + 3):
+            ctx._check(lib.gdml_predict_dev(ctx._h, dR, B, None, None, dE, dF))
+            if rep >= 3:
+                ms.append(ctx.phase_ms('predict')[0])
+        for p_ in (dR, dE, dF):
+            ctx._check(lib.gdml_dev_free(ctx._h, p_))
+        t = float(np.median(ms)) * 1e-3
+        out.append({'batch': B, 'path': 'device-resident queries and results (gdml_predict_dev: descriptors + contraction + epilogue)',
+                    'ms': t * 1e3, 'geoms_per_s': B / t, 'forces_per_s': B * N3 / t,
+                    'algorithmic_TFLOPs': flops_q * B / t / 1e12, 'table_GBs': bytes_t / t / 1e9})
+    big, one = out[-1], out[0]
+    roof = {'large_batch': {'batch': big['batch'], 'bound': 'fp64 pipes', 'achieved': big['algorithmic_TFLOPs'], 'peak': FP64_MFMA_PEAK_TF,
+                            'unit': 'TFLOP/s', 'frac': big['algorithmic_TFLOPs'] / FP64_MFMA_PEAK_TF,
+                            'algorithmic_flops_per_query': flops_q},
+            'single_query': {'batch': 1, 'bound': 'hbm (streamed tables) -- in practice launch latency', 'achieved': one['table_GBs'],
+                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': one['table_GBs'] / HBM_PEAK_GBS,
+                             'algorithmic_bytes_per_query': bytes_t}}
+    return out, roof
+
+
 def run_analytic(args):
     from sgdml_amd import _lib
 
@@ -773,6 +825,11 @@ def run_analytic(args):
         'roofline': roof,
     }
     out.update(extra)
+    try:  # the metric names "predict forces/sec": the resident model at four batch sizes, with both rooflines
+        ctx.profile(False)
+        out['predict']['by_batch'], out['roofline_predict'] = predict_sweep(ctx, lib, Rq, N, M, 1)
+    except Exception as e:
+        out['predict']['by_batch'] = {'error': repr(e)}
     ctx.close()
     if not args.no_configs:
         cfgs = []

@@ -128,6 +128,11 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   trsm.debug (0)        timing-only ablation mask of the row-local panel solve (results are wrong when set)
  *   trsv.persist (1)      backward substitution as one persistent launch
  *   predict.wave_only (0), predict.mfma (1), predict.mfma_wide (1), predict.fill   prediction kernel choice
+ *   predict.fused (1)     gdml_predict with 1-8 host geometries (D <= 256, at most 384 coordinates): ONE launch -- geometries in through the kernel
+ *                         arguments, descriptors + contraction + last-workgroup reduction + back-projection, E / F out through
+ *                         host-mapped memory (0: descriptor kernel, contraction, epilogue and three copies); predict.fused_rows
+ *                         (16) table rows per wavefront, predict.fused_spin (1) completion by polling the kernel's sequence
+ *                         number instead of synchronising the stream.  This path records no "predict" phase time
  *   lu.nb (64)            panel width of the LU fallback
  *   comm.force_collectives (0)  issue collectives even for world == 1 without a communicator (tests)
  *   dist.nb (512)         row-block size of the distributed Cholesky (multiple of 128)

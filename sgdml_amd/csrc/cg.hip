@@ -701,10 +701,14 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
   *usable = 0;
   ctx->opts["pcg.f32_last_min_pivot"] = 0.0;
   hipStream_t st = ctx->stream;
-  GDML_TRY(ensure_buf(ctx, (void**)&ctx->precon_X32, &ctx->precon_X32_bytes, (n_loc > 0 ? n_loc : 1) * ld * 4));
-  GDML_TRY(ensure_buf(ctx, (void**)&ctx->precon_T0, &ctx->precon_T0_bytes, m * ld * 8));
   void* tmp = nullptr;
-  GDML_TRY(ctx_alloc(ctx, &tmp, 2 * m * ld * 8));
+  {  // no room for the fp32 copy next to the fp64 factor: keep the reference's form (X is untouched at this point)
+    int rc_a = ensure_buf(ctx, (void**)&ctx->precon_X32, &ctx->precon_X32_bytes, (n_loc > 0 ? n_loc : 1) * ld * 4);
+    if (rc_a == GDML_OK) rc_a = ensure_buf(ctx, (void**)&ctx->precon_T0, &ctx->precon_T0_bytes, m * ld * 8);
+    if (rc_a == GDML_OK) rc_a = ctx_alloc(ctx, &tmp, 2 * m * ld * 8);
+    if (rc_a == GDML_ERR_OOM) return GDML_OK;
+    GDML_TRY(rc_a);
+  }
   double* Rb = (double*)tmp;   // L^-T, later L_G^-T
   double* G = Rb + m * ld;     // Gram of the rounded factor, then its Cholesky factor
   double* G0 = ctx->precon_T0; // lives in the T0 buffer until T0 itself is formed

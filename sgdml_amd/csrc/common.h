@@ -16,6 +16,13 @@
 // D = N (N - 1) / 2 descriptor rows holds far beyond it; memory (M N^2 32 bytes of dense tables) ends earlier.
 #define GDML_MAX_ATOMS 4096
 
+// periodic cell handed to the descriptor code by value (desc.hip, the single-launch prediction path of predict.hip)
+struct Lattice {
+  double lat[9];
+  double inv[9];
+  int use;
+};
+
 struct PhaseStat {
   double ms = 0.0;
   int64_t launches = 0;
@@ -79,6 +86,13 @@ struct gdml_ctx {
   int64_t phase_pending_launches = 0;
   double* h_pin = nullptr;           // pinned host staging for small transfers (single-geometry latency path)
   int64_t h_pin_bytes = 0;
+  // single-launch prediction of small host batches (predict_fused_kernel): host-mapped result block the kernel writes
+  // directly ([0] = completion sequence number, [8 ...] = E, F), its device alias, the launch counter of the last-block-done
+  // reduction and the sequence number of the last launch
+  double* h_map = nullptr;
+  double* h_map_dev = nullptr;
+  unsigned* d_fused_counter = nullptr;
+  unsigned long long fused_seq = 0;
   int64_t launch_counter = 0;
   bool profiling = false;
   std::map<std::string, KernelStat> kstats;

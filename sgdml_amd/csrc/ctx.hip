@@ -32,7 +32,7 @@ static const char* kKnownOptions[] = {
     "asm.pts", "asm.pts_nv", "asm.pts_nt", "asm.pts_xcd", "asm.pts_i_chunk", "asm.pts_debug", "asm.perm_debug", "asm.perm_w", "asm.perm_lds_kb", "asm.perm_level", "asm.perm_nimg", "asm.perm_pg", "asm.perm_na", "asm.perm_fast_store", "asm.perm_i_chunk", "asm.perm_compact", "asm.perm_lds_rows",
     "gemm.debug", "gemm.nt_c", "gemm.lds16", "chol.nb", "chol.small_update", "pcg.gemv_plain", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
     "chol.fused_min_rows", "chol.outer", "chol.outer_min_rows", "chol.merge_gemm1", "chol.tail_lookahead", "trsm.debug",
-    "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide",
+    "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide", "predict.fused", "predict.fused_rows", "predict.fused_spin",
     "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb", "dist.lookahead", "pcg.depth", "pcg.precon_form", "pcg.f32_rows_per", "pcg.f32_rw", "pcg.f32_min_pivot", "pcg.f32_last_min_pivot"};
 
 double ctx_opt(const gdml_ctx* ctx, const char* key, double dflt) {
@@ -224,6 +224,7 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
+  if (ctx->h_map) hipHostFree(ctx->h_map);
   if (ctx->h_coll) hipHostFree(ctx->h_coll);
   delete ctx;
   return GDML_OK;

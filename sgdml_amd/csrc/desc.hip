@@ -2,12 +2,6 @@
 // upload (replaces the H2D copies at sgdml/train.py:1447-1448).
 #include "common.h"
 
-struct Lattice {
-  double lat[9];
-  double inv[9];
-  int use;
-};
-
 // One thread per (geometry m, pair k).  Pair order = np.tril_indices(N,-1): k -> (i_k > j_k).
 // x[m,k] = 1/|r_i - r_j| ; g[m,k,:] = (r_i - r_j)/d^3   (desc.py:163, :193-205)
 __global__ void __launch_bounds__(256) desc_kernel(const double* __restrict__ R, int64_t M, int N,

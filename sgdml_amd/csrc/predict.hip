@@ -18,6 +18,8 @@
 // registers) and a contiguous split of the table rows, reduces |d|^2 and a with cross-lane
 // shuffles, and keeps its partial F_x in registers.  Partials of the splits are summed in a fixed
 // order by the epilogue kernel (deterministic), which also applies J_x^T.
+#include <stddef.h>
+
 #include "common.h"
 
 int upload_perms(gdml_ctx* ctx, const int64_t* tril_perms, int P, int N, std::vector<int32_t>& h_tp,
@@ -1063,6 +1065,304 @@ extern "C" int gdml_set_alphas(gdml_ctx* ctx, const double* alphas_F, const doub
   return GDML_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Single launch for small HOST batches (the ASE-calculator / MD step, sgdml/intf/ase_calc.py:93-106): descriptors,
+// contraction and back-projection in one kernel, geometries in through the kernel arguments, E / F out through
+// host-mapped memory, completion signalled by a sequence number the host polls -- no copy command, no second and third
+// launch, no stream synchronisation.  (Three launches + three copies cost 55.7 us host-to-host for ~25 us of kernels:
+// profiles/r04_latency_path.txt.)
+//   grid = (row shares, queries).  Every wavefront: x_q from R (kernel arguments) into registers -> its share of the table
+//     rows (the row loop of predict_kernel) -> F_x, E partials of the workgroup's four wavefronts summed through LDS -> one
+//     partial per workgroup;
+//   the LAST workgroup of a query to finish (ticket): sums that query's partials in a fixed order, computes the Jacobian
+//     entries (r_i - r_j) / d^3 from R again, F = J^T F_x, writes E, F to the mapped block; the last QUERY to finish then
+//     writes the sequence number.
+// B <= 8 queries, D <= 256 (N <= 23), 3 N B <= 384 coordinates (3 KB of kernel arguments: six queries at N = 21).
+// ------------------------------------------------------------------------------------------
+#define FUSED_MAX_COORDS 384
+#define FUSED_MAX_Q 8
+struct FusedArgs {
+  const double* xp;
+  const double* jap;
+  const double* aE;
+  int64_t MP;
+  int D, N, B, want_E;
+  double sig;
+  int rows_per_wave;
+  double* part;                // (B, n_wg, D + 1) workgroup partials: F_x, then E
+  unsigned* counter;           // [q] workgroups of query q that have finished; [FUSED_MAX_Q] queries done
+  double* out;                 // host-mapped: E (B), F (B, 3N)
+  unsigned long long* flag;    // host-mapped
+  unsigned long long seq;
+  Lattice L;
+  double R[FUSED_MAX_COORDS];  // (B, N, 3)
+};
+typedef const __attribute__((address_space(4))) double* kernarg_dp;
+
+// r_i - r_j of query q (minimum image with a lattice: desc.py:44-77), from the kernel-argument copy of R
+__device__ __forceinline__ void fused_pair_diff(kernarg_dp R, const Lattice& L, int N, int q, int i, int j, double (&d)[3]) {
+  const int bi = (q * N + i) * 3, bj = (q * N + j) * 3;
+  double d0 = R[bi] - R[bj], d1 = R[bi + 1] - R[bj + 1], d2 = R[bi + 2] - R[bj + 2];
+  if (L.use) {
+    const double c0 = rint(L.inv[0] * d0 + L.inv[1] * d1 + L.inv[2] * d2);
+    const double c1 = rint(L.inv[3] * d0 + L.inv[4] * d1 + L.inv[5] * d2);
+    const double c2 = rint(L.inv[6] * d0 + L.inv[7] * d1 + L.inv[8] * d2);
+    d0 -= L.lat[0] * c0 + L.lat[1] * c1 + L.lat[2] * c2;
+    d1 -= L.lat[3] * c0 + L.lat[4] * c1 + L.lat[5] * c2;
+    d2 -= L.lat[6] * c0 + L.lat[7] * c1 + L.lat[8] * c2;
+  }
+  d[0] = d0; d[1] = d1; d[2] = d2;
+}
+__device__ __forceinline__ void fused_pair_of(int k, int& i, int& j) {  // k = i (i - 1) / 2 + j, i > j
+  i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);
+  while (i * (i - 1) / 2 > k) --i;
+  while ((i + 1) * i / 2 <= k) ++i;
+  j = k - i * (i - 1) / 2;
+}
+
+template <int KPL>
+__global__ void __launch_bounds__(256) predict_fused_kernel(FusedArgs A) {
+  __shared__ double s_fx[4][KPL * 64];  // per-wavefront F_x; reused by the query's last workgroup: [0] = its summed F_x
+  __shared__ double s_E[4];
+  __shared__ double s_g[KPL * 64 * 3];
+  __shared__ unsigned s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = A.D, N = A.N, B = A.B;
+  const int q = (int)blockIdx.y;  // a workgroup serves ONE query: grid = (row shares, queries)
+  kernarg_dp Rk = (kernarg_dp)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                               offsetof(FusedArgs, R));
+  const double sig = A.sig, inv_sig = 1.0 / sig;
+  const double sqrt5 = 2.23606797749978969641;
+  const double fact = 5.0 / (3.0 * sig * sig * sig);
+  const double dscale = 5.0 / sig;
+  const double inv_3sig = 1.0 / (3.0 * sig);
+
+  // ---- query descriptor (same arithmetic as desc_kernel)
+  double x[KPL], Fx[KPL], E = 0.0;
+#pragma unroll
+  for (int t = 0; t < KPL; ++t) {
+    const int k = lane + 64 * t;
+    double v = 0.0;
+    if (k < D) {
+      int i, j;
+      fused_pair_of(k, i, j);
+      double d[3];
+      fused_pair_diff(Rk, A.L, N, q, i, j, d);
+      v = 1.0 / sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    }
+    x[t] = v;
+    Fx[t] = 0.0;
+  }
+
+  // ---- this wavefront's table rows (the row loop of predict_kernel)
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t r0 = gw * A.rows_per_wave;
+  const int64_t r1 = (r0 + A.rows_per_wave < A.MP) ? r0 + A.rows_per_wave : A.MP;
+  const bool has_aE = A.aE != nullptr;
+  auto load_row = [&](int64_t r, double (&X)[KPL], double (&JA)[KPL], double& ae) {
+#pragma unroll
+    for (int t = 0; t < KPL; ++t) {
+      const int k = lane + 64 * t;
+      const int kc = k < D ? k : D - 1;
+      const double xv = __hip_atomic_load(A.xp + r * D + kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const double jv = __hip_atomic_load(A.jap + r * D + kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      X[t] = (k < D) ? xv : 0.0;
+      JA[t] = (k < D) ? jv : 0.0;
+    }
+    ae = has_aE ? __hip_atomic_load(A.aE + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0.0;
+  };
+  auto row = [&](const double (&X)[KPL], const double (&JA)[KPL], double ae) {
+    double d[KPL];
+    double s2 = 0.0, sa = 0.0;
+#pragma unroll
+    for (int t = 0; t < KPL; ++t) {
+      d[t] = x[t] - X[t];
+      s2 += d[t] * d[t];
+      sa += d[t] * JA[t];
+    }
+    s2 = wave_sum(s2);
+    sa = wave_sum(sa);
+    const double nrm = sqrt5 * sqrt(s2);
+    const double ex = exp(-nrm * inv_sig);
+    const double b = fact * ex;
+    const double b2 = b * (nrm + sig);
+    double w1 = dscale * sa * b;
+    E += sa * b2;
+    if (has_aE) {
+      w1 += ae * b2;
+      E += ae * (1.0 + (nrm * inv_sig) * (1.0 + nrm * inv_3sig)) * ex;
+    }
+#pragma unroll
+    for (int t = 0; t < KPL; ++t) Fx[t] += w1 * d[t] - b2 * JA[t];
+  };
+  if (r0 < r1) {
+    double X0[KPL], JA0[KPL], X1[KPL], JA1[KPL], ae0, ae1;
+    int64_t r = r0;
+    load_row(r, X0, JA0, ae0);
+    for (; r + 1 < r1; r += 2) {
+      load_row(r + 1, X1, JA1, ae1);
+      row(X0, JA0, ae0);
+      load_row(r + 2 < r1 ? r + 2 : r1 - 1, X0, JA0, ae0);
+      row(X1, JA1, ae1);
+    }
+    if (r < r1) row(X0, JA0, ae0);
+  }
+
+  // ---- the workgroup's four wavefronts -> one partial (padding lanes hold zeros)
+#pragma unroll
+  for (int t = 0; t < KPL; ++t) s_fx[wave][lane + 64 * t] = Fx[t];
+  if (lane == 0) s_E[wave] = E;
+  __syncthreads();
+  const int n_wg = (int)gridDim.x;
+  double* my_part = A.part + ((int64_t)q * n_wg + blockIdx.x) * (D + 1);
+  for (int k = tid; k < D; k += 256) my_part[k] = (s_fx[0][k] + s_fx[1][k]) + (s_fx[2][k] + s_fx[3][k]);
+  if (tid == 0) my_part[D] = (s_E[0] + s_E[1]) + (s_E[2] + s_E[3]);
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_ticket = atomicAdd(A.counter + q, 1u);
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;
+
+  // ---- the query's last workgroup: every partial of this query is visible
+  __threadfence();
+  double* fxs = &s_fx[0][0];
+  const double* qpart = A.part + (int64_t)q * n_wg * (D + 1);
+  for (int k = tid; k < D + 1; k += 256) {
+    double s = 0.0;
+    for (int w0 = 0; w0 < n_wg; w0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int w = w0 + u < n_wg ? w0 + u : n_wg - 1;
+        v[u] = __hip_atomic_load(qpart + (int64_t)w * (D + 1) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (w0 + u < n_wg) s += v[u];
+    }
+    if (k < D) fxs[k] = s;
+    else if (A.want_E) A.out[q] = s;
+  }
+  for (int k = tid; k < D; k += 256) {  // Jacobian entries (r_i - r_j) / d^3  (desc.py:193-205)
+    int i, j;
+    fused_pair_of(k, i, j);
+    double d[3];
+    fused_pair_diff(Rk, A.L, N, q, i, j, d);
+    const double dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const double inv3 = 1.0 / (dist * dist * dist);
+    s_g[k * 3 + 0] = d[0] * inv3;
+    s_g[k * 3 + 1] = d[1] * inv3;
+    s_g[k * 3 + 2] = d[2] * inv3;
+  }
+  __syncthreads();
+  for (int t = tid; t < 3 * N; t += 256) {  // F = J_x^T F_x  (desc.py:405-408), same order as predict_epilogue_kernel
+    const int a = t / 3, al = t - 3 * a;
+    double s = 0.0;
+    for (int m = 0; m < N; ++m) {
+      if (m == a) continue;
+      const int k = pair_idx(a, m);
+      const double v = s_g[k * 3 + al] * fxs[k];
+      s += (a < m) ? v : -v;
+    }
+    A.out[B + (int64_t)q * 3 * N + t] = s;
+  }
+  __threadfence_system();  // this query's E, F are in host memory before it is counted as done
+  __syncthreads();
+  if (tid == 0) {
+    A.counter[q] = 0u;
+    const unsigned done = atomicAdd(A.counter + FUSED_MAX_Q, 1u);
+    if (done == (unsigned)B - 1) {  // the last query to finish publishes the sequence number
+      __threadfence_system();
+      A.counter[FUSED_MAX_Q] = 0u;
+      __hip_atomic_store(A.flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// Host side of the single-launch path.  Returns GDML_OK with *done = 0 when the shape is not served.
+static int predict_fused(gdml_ctx* ctx, const double* R, int64_t B, const double* lat, const double* lat_inv, double* E_out,
+                         double* F_out, int* done) {
+  *done = 0;
+  Model& md = ctx->model;
+  const int N = md.N, D = md.D;
+  if (B < 1 || B > FUSED_MAX_Q || D > 256 || D < 1 || B * 3 * N > FUSED_MAX_COORDS || ctx->profiling ||
+      !ctx_opt_i(ctx, "predict.fused", 1))
+    return GDML_OK;
+  if (!ctx->h_map) {
+    if (hipHostMalloc((void**)&ctx->h_map, 8192, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->h_map = nullptr;
+      return GDML_OK;
+    }
+    memset(ctx->h_map, 0, 8192);
+    if (hipHostGetDevicePointer((void**)&ctx->h_map_dev, ctx->h_map, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipHostFree(ctx->h_map);
+      ctx->h_map = nullptr;
+      return GDML_OK;
+    }
+  }
+  if (!ctx->d_fused_counter) {
+    GDML_TRY(ctx_alloc(ctx, (void**)&ctx->d_fused_counter, 64));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->d_fused_counter, 0, 64, ctx->stream));
+  }
+  const int64_t MP = md.M * md.P;
+  int rows = ctx_opt_i(ctx, "predict.fused_rows", 16);
+  if (rows < 2) rows = 2;
+  // at most 4 x 256 wavefronts (a few per CU: the launch is latency bound, not throughput bound)
+  while ((MP + rows - 1) / rows > 1024) rows *= 2;
+  const int64_t n_waves = (MP + rows - 1) / rows;
+  const int n_wg = (int)((n_waves + 3) / 4);
+  double* part;
+  GDML_TRY(ctx_slot(ctx, 0, (int64_t)n_wg * B * (D + 1) * 8, &part));
+  FusedArgs A;
+  A.xp = md.xp; A.jap = md.jap; A.aE = md.has_aE ? md.aE : nullptr;
+  A.MP = MP; A.D = D; A.N = N; A.B = (int)B; A.want_E = E_out != nullptr;
+  A.sig = md.sig; A.rows_per_wave = rows; A.part = part; A.counter = ctx->d_fused_counter;
+  A.out = ctx->h_map_dev + 8;
+  A.flag = (unsigned long long*)ctx->h_map_dev;
+  A.seq = ++ctx->fused_seq;
+  memset(&A.L, 0, sizeof(A.L));
+  if (lat && lat_inv) {
+    memcpy(A.L.lat, lat, sizeof(A.L.lat));
+    memcpy(A.L.inv, lat_inv, sizeof(A.L.inv));
+    A.L.use = 1;
+  }
+  memcpy(A.R, R, (size_t)B * 3 * N * 8);
+  int KPL = 1;
+  while (KPL * 64 < D) KPL <<= 1;
+  const dim3 grid((unsigned)n_wg, (unsigned)B);
+  switch (KPL) {
+    case 1: hipLaunchKernelGGL(predict_fused_kernel<1>, grid, dim3(256), 0, ctx->stream, A); break;
+    case 2: hipLaunchKernelGGL(predict_fused_kernel<2>, grid, dim3(256), 0, ctx->stream, A); break;
+    default: hipLaunchKernelGGL(predict_fused_kernel<4>, grid, dim3(256), 0, ctx->stream, A); break;
+  }
+  ctx->launch_counter++;
+  HIP_CHECK(ctx, hipGetLastError());
+  // completion: the kernel's last store is the sequence number (system scope, after E and F)
+  volatile unsigned long long* flag = (volatile unsigned long long*)ctx->h_map;
+  bool seen = false;
+  if (ctx_opt_i(ctx, "predict.fused_spin", 1)) {
+    for (int64_t spin = 0; spin < ((int64_t)1 << 26); ++spin) {  // bounded: a few hundred ms of polling at most
+      if (*flag == A.seq) {
+        seen = true;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  if (!seen) {
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*flag != A.seq) return gdml_fail(ctx, GDML_ERR_HIP, "single-launch prediction: the kernel finished without publishing");
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const double* h_out = ctx->h_map + 8;
+  if (E_out) memcpy(E_out, h_out, (size_t)B * 8);
+  memcpy(F_out, h_out + B, (size_t)B * 3 * N * 8);
+  *done = 1;
+  return GDML_OK;
+}
+
 static int predict_common(gdml_ctx* ctx, const double* R, bool R_on_device, int64_t B,
                           const double* lat, const double* lat_inv, double* E_out, double* F_out,
                           bool out_on_device) {
@@ -1073,6 +1373,11 @@ static int predict_common(gdml_ctx* ctx, const double* R, bool R_on_device, int6
     return gdml_fail(ctx, GDML_ERR_INVALID, "lattice and inverse must both be given or both NULL");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int N = md.N, D = md.D;
+  if (R != nullptr && !R_on_device && !out_on_device && B >= 1 && B <= FUSED_MAX_Q) {
+    int done = 0;
+    GDML_TRY(predict_fused(ctx, R, B, lat, lat_inv, E_out, F_out, &done));
+    if (done) return GDML_OK;
+  }
   const double *d_xq, *d_gq;
   double* buf = nullptr;
   double *d_E = E_out, *d_F = F_out;

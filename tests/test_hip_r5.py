@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import gdml_oracle as orc  # noqa: E402
 from _pcg_compare import assert_same_convergence  # noqa: E402
+from tests.test_oracle_golden import _lat, _model, cancel_floor  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -223,6 +224,72 @@ def test_precon_form_is_chosen_by_size():
             b = c.precon_apply(1e-10, v)
             c.set_option('pcg.precon_form', 2)
             assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max()
+    finally:
+        c.close()
+
+
+# ------------------------------------------------------------------ single-launch prediction
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 5, 7])
+def test_single_launch_prediction(golden, ctx, B):
+    """Host batches of up to eight geometries take ONE launch (descriptors from the kernel arguments, contraction,
+    last-workgroup reduction and back-projection, E / F through host-mapped memory): equal to the three-kernel
+    path (option predict.fused = 0) to rounding and to the reference's predictions, on every small fixture -- permutation
+    group, energy-constraint coefficients, the periodic cell -- with and without energies, repeated calls, every row split."""
+    g = golden
+    m = _model(g)
+    tp = _tril_perms(g)
+    ctx.predict_upload_model(np.ascontiguousarray(m['R_desc'].T), m['R_d_desc_alpha'], tp, float(g['sig']), m.get('alphas_E'))
+    R = g['R_test'].reshape(len(g['R_test']), -1)[:B]
+    fl = cancel_floor(g)
+    ctx.set_option('predict.fused', 0)
+    E0, F0 = ctx.predict(R, _lat(g))
+    ctx.set_option('predict.fused', 1)
+    for rows in (16, 2, 5, 64):
+        ctx.set_option('predict.fused_rows', rows)
+        for rep in range(3):
+            E1, F1 = ctx.predict(R, _lat(g))
+            assert np.abs(F1 - F0).max() <= 1e-12 * np.abs(F0).max() + fl / float(m['std'])
+            # (the energy-constraint terms sum coefficients of size 1e9 in another order: 10 x the force floor)
+            assert np.abs(E1 - E0).max() <= 1e-12 * max(1.0, np.abs(E0).max()) + 10 * fl * float(g['sig']) / float(m['std'])
+    ctx.set_option('predict.fused_rows', 16)
+    E1, F1 = ctx.predict(R, _lat(g))
+    assert np.abs(F1 * m['std'] - g['F_test'][:B]).max() <= 1e-10 * np.abs(g['F_test']).max() + fl
+    assert np.abs(E1 * m['std'] + m['c'] - g['E_test'][:B]).max() <= 1e-10 * max(1.0, np.abs(g['E_test']).max()) + fl * float(g['sig'])
+    E2, F2 = ctx.predict(R, _lat(g), return_E=False)
+    assert E2 is None and np.array_equal(F2, F1)
+    ctx.set_option('predict.fused_spin', 0)  # completion through the stream instead of the polled sequence number
+    E3, F3 = ctx.predict(R, _lat(g))
+    ctx.set_option('predict.fused_spin', 1)
+    assert np.array_equal(F3, F1) and np.array_equal(E3, E1)
+
+
+def test_single_launch_prediction_aspirin_size():
+    """The shape the latency path is quoted on (N = 21, D = 210, 1000 training points; also a 27-element group at N = 12):
+    one to four queries against the oracle, 1e-10."""
+    from sgdml_amd import _lib
+
+    c = _lib.Context()
+    try:
+        for N, M, perms in ((21, 1000, None), (23, 300, None), (12, 150, 'g6')):
+            ds = orc.synth_dataset(N, M + 4, seed=4, jitter=0.3)
+            Rf = ds['R'].reshape(M + 4, -1)
+            if perms is None:
+                tp = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
+            else:
+                tp = orc.tril_perms_from_atom_perms(load('pcg_n12_p6_m200')['perms'])
+            xo, go = orc.desc_from_R(Rf[:M])
+            JA = np.random.default_rng(1).standard_normal(xo.shape)
+            c.predict_upload_model(xo, JA, tp, 20.0, None)
+            xq, gq = orc.desc_from_R(Rf[M:])
+            Eo, Fo = orc.predict_from_desc(xq, gq, xo, JA, tp, 20.0)
+            for B in (1, 2, 4):
+                if B * 3 * N > 384:
+                    continue
+                E, F = c.predict(Rf[M:M + B])
+                assert np.abs(F - Fo[:B]).max() <= 1e-10 * np.abs(Fo).max()
+                assert np.abs(E - Eo[:B]).max() <= 1e-10 * np.abs(Eo).max()
     finally:
         c.close()
 
