@@ -196,7 +196,8 @@ def make_cg_workload(ctx, n_atoms, n_train, k_inducing, sig, lam):
 
 def cg_step(ctx, wl, n_iters):
     ctx.assemble_K(wl['sig'], False, idx=wl['idx'], alloc_extra_rows=wl['m'])
-    ctx.nystroem_factor(wl['lam'], wl['idx'])
+    _, _, info = ctx.nystroem_factor(wl['lam'], wl['idx'], want_lev=False)
+    wl['precon_form'] = {0: 'stored fp64 factor', 2: 'matrix-free', 4: 'fp32 factor + Gram correction'}[info & 6]
     x, info, iters, resid = ctx.pcg(wl['lam'], False, wl['y'], rtol=0.0, maxiter=n_iters)  # rtol 0: exactly n_iters
     assert iters == n_iters, (iters, n_iters)
     return resid, {k: ctx.phase_ms(k)[0] for k in ('assemble', 'precon', 'pcg')}
@@ -216,7 +217,14 @@ def time_cg(ctx, wl, n_iters, steps, warmup, barrier):
     t1 = time.perf_counter()
     c1, b1 = ctx.comm_stats()
     phases = {k: float(np.mean([p[k] for p in ph])) for k in ph[0]}
+    # the preconditioner GEMVs' own time (HIP events around the kernels, outside the timed region): what `roofline` is quoted on
+    ctx.profile(True)
+    cg_step(ctx, wl, n_iters)
+    g_ms, g_n, g_by = ctx.kernel_stat('precon_gemv')
+    ctx.profile(False)
+    barrier()
     return {'s_per_step': (t1 - t0) / max(1, steps), 'phases_ms': phases, 'ms_per_pcg_iteration': phases['pcg'] / n_iters,
+            'gemv': {'ms_per_application': g_ms / max(1, g_n), 'bytes_per_application': g_by / max(1, g_n), 'applications': g_n},
             'resid_over_norm_y': float(resid / np.linalg.norm(wl['y'])),
             'collectives_per_step': (c1 - c0) / max(1, steps), 'collective_bytes_per_step_per_rank': (b1 - b0) / max(1, steps)}
 
@@ -317,7 +325,7 @@ def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', si
     analytic = assemble + Cholesky + solves; cg = the reference's iterative policy (leverage-score inducing points,
     Nystroem preconditioner, PCG to solver_tol = 1e-4, restarts) -- wall-clock to the converged model, phases,
     iterations, and the residual of the returned coefficients through the matrix-free operator.
-    dist_backend ('rccl' / 'host'): every rank of the initialised torch.distributed group calls this; the solve is
+    dist_backend ('rccl' / 'host'): every rank of the job calls this (host group: sgdml_amd.dist.host_group); the solve is
     sharded over them (GDMLTrain.init_distributed)."""
     from sgdml_amd.solvers.iterative import Iterative
     from sgdml_amd.train import GDMLTrain
@@ -429,7 +437,7 @@ def main():
     ap.add_argument('--no-to-tol', action='store_true', help='N>1: skip the sharded run to solver_tol')
     ap.add_argument('--to-tol-timeout', type=float, default=600.0, help='N>1: seconds the sharded run to solver_tol may take')
     ap.add_argument('--dist-chol', action='store_true', help='N>1: also time the configs[1] system through the distributed Cholesky')
-    ap.add_argument('--comm', default='auto', help="N>1: 'rccl', 'host' (gloo-staged), or auto (rccl if every rank has a GPU)")
+    ap.add_argument('--comm', default='auto', help="N>1: 'rccl', 'host' (collectives staged through the host channel), or auto (rccl if every rank has a GPU)")
     args = ap.parse_args()
 
     # ---- `--gpus N` with N > 1 and no launcher around us: become the launcher (one rank per GPU over RCCL)
@@ -463,8 +471,7 @@ def main():
 
 
 def self_launch(args):
-    """python bench.py --gpus N (N > 1) without a launcher: re-run this script under torch.distributed.run, one rank per
-    GPU on 127.0.0.1.  With fewer GPUs than ranks the run is refused unless `--comm host` asks for the functional mode
+    """python bench.py --gpus N (N > 1) without a launcher: start N copies of this script, one rank per GPU on 127.0.0.1.  With fewer GPUs than ranks the run is refused unless `--comm host` asks for the functional mode
     (ranks share GPUs, collectives staged through the host)."""
     import socket
     import subprocess
@@ -480,53 +487,68 @@ def self_launch(args):
         sys.stderr.write('bench.py: --gpus {} but {} GPU(s) visible; pass --comm host for a functional run with ranks sharing '
                          'GPUs\n'.format(args.gpus, n_dev))
         return 2
+    try:  # a child process takes the first touch of the GPU (see sgdml_amd._lib.preflight); the ranks then skip theirs
+        _lib.preflight()
+    except Exception as e:
+        sys.stderr.write('bench.py: GPU preflight: %r\n' % (e,))
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
-           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    return subprocess.call(cmd, env=env)
+    # one rank per GPU, the environment a launcher would set (what the driver's torch.distributed.run provides); the ranks
+    # rendezvous through sgdml_amd.hostchannel, so no launcher package is needed
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                   GDML_BENCH_CHILD='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        rc = p_.wait() or rc
+    return rc
 
 
 def run_sharded_cg(args, rank, world):
-    """N > 1: the configs[2] workload sharded over the ranks (one process per GPU, RCCL inside the library)."""
-    import torch  # plumbing only: rendezvous, barrier, max-reduce of the timings (CPU tensors over gloo)
-    import torch.distributed as dist
-
+    """N > 1: the configs[2] workload sharded over the ranks (one process per GPU, RCCL inside the library).  The host side
+    (rendezvous, barrier, max over ranks) is sgdml_amd.hostchannel: no PyTorch in these processes."""
     from sgdml_amd import _lib
-    from sgdml_amd.dist import init_comm_from_torch_distributed, pick_backend, probe_rccl
+    from sgdml_amd.dist import host_group, init_comm, pick_backend, probe_rccl
 
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist.init_process_group('gloo')
+    hg = host_group()
     n_dev = _lib.device_count()
     comm = args.comm
     if comm == 'auto':  # RCCL when every rank has a physical GPU of its own; ranks sharing a GPU: functional host-staged run
-        comm = pick_backend(local_rank % max(1, n_dev))
+        comm = pick_backend(local_rank % max(1, n_dev), hg)
     rccl_probe = None
     if comm == 'rccl' and args.comm == 'auto':
         # a toy sharded solve through RCCL in child processes, under a time limit, before the real ranks commit to it: a
         # node where RCCL does not come up still gets its (slower) strong-scaling line through the host-staged collectives
-        ok, rccl_probe = probe_rccl(local_rank % max(1, n_dev))
+        ok, rccl_probe = probe_rccl(local_rank % max(1, n_dev), hg)
         if not ok:
             comm = 'host'
             sys.stderr.write('bench.py: RCCL probe failed ({}); using host-staged collectives\n'.format(rccl_probe))
     ctx = _lib.Context(local_rank % max(1, n_dev))
-    init_comm_from_torch_distributed(ctx, backend=comm)
+    init_comm(ctx, group=hg, backend=comm)
 
     def barrier():
         ctx.sync()
-        dist.barrier()
+        hg.barrier()
+
+    def max_over_ranks(values):
+        every = hg.allgather_obj([float(v) for v in values])
+        return [max(e[i] for e in every) for i in range(len(values))]
 
     N, M, k = args.n_atoms, args.cg_n_train, args.cg_inducing
     wl = make_cg_workload(ctx, N, M, k, args.sig, args.lam)
     res = time_cg(ctx, wl, args.cg_iters, args.steps, args.warmup, barrier)
-    t = torch.tensor([res['s_per_step'], res['phases_ms']['assemble'], res['phases_ms']['precon'], res['phases_ms']['pcg']],
-                     dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    s_per_step, asm_ms, pre_ms, pcg_ms = [float(v) for v in t]
+    s_per_step, asm_ms, pre_ms, pcg_ms, gemv_ms = max_over_ranks(
+        [res['s_per_step'], res['phases_ms']['assemble'], res['phases_ms']['precon'], res['phases_ms']['pcg'],
+         res['gemv']['ms_per_application']])
 
-    # the configs[1] system (n = 63 000) through the distributed Cholesky over the same communicator
+    # the configs[1] system (n = 63 000) through the distributed Cholesky over the same communicator, in BOTH schedules
+    # (dist.lookahead 0 = every step in order on the compute stream, the default; 1 = one panel of look-ahead over three
+    # streams with the block broadcasts on a second communicator), so that the first hardware record compares them
     dchol = None
     try:
         if not args.dist_chol:
@@ -537,23 +559,28 @@ def run_sharded_cg(args, rank, world):
         Rc, Ec, Fc = synth_geometries(N, Mc, seed=0)
         yc = Fc.ravel() / np.std(Fc)
         xdc, gdc = ctx.desc_from_R(Rc.reshape(Mc, -1), N)
-        ctx.train_upload(xdc, gdc, np.arange(N * (N - 1) // 2, dtype=np.int64)[None])
-        ts = []
-        for rep in range(3):
-            barrier()
-            t0 = time.perf_counter()
-            a_c = ctx.dist_chol_solve(args.sig, args.lam, yc)
-            barrier()
-            ts.append(time.perf_counter() - t0)
-        tt = torch.tensor([min(ts[1:])], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ctx.predict_upload_model(xdc, np.zeros_like(xdc), np.arange(N * (N - 1) // 2, dtype=np.int64)[None], args.sig, None)
-        Kv = ctx.kernel_matvec(args.lam, False, -a_c)
+        tpc = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
+        ctx.train_upload(xdc, gdc, tpc)
         dchol = {'config': 'configs[1] system (N=21 N_train={} n={}) assembled block-row-cyclic over {} ranks and solved by '
-                           'the distributed Cholesky (gdml_dist_chol_solve)'.format(Mc, Mc * 3 * N, world),
-                 's_per_solve': float(tt[0]), 'phases_ms': {k: ctx.phase_ms(k)[0] for k in ('assemble', 'factor', 'solve')},
-                 'solve_rel_residual': float(np.linalg.norm(-Kv - yc) / np.linalg.norm(yc)),
-                 'matrix_bytes_per_rank': ctx.mem_info()[0]}
+                           'the distributed Cholesky (gdml_dist_chol_solve)'.format(Mc, Mc * 3 * N, world), 'schedules': {}}
+        for la in (0, 1):
+            ctx.set_option('dist.lookahead', la)
+            ts = []
+            for rep in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                a_c = ctx.dist_chol_solve(args.sig, args.lam, yc)
+                barrier()
+                ts.append(time.perf_counter() - t0)
+            (t_best,) = max_over_ranks([min(ts[1:])])
+            ctx.predict_upload_model(xdc, np.zeros_like(xdc), tpc, args.sig, None)
+            Kv = ctx.kernel_matvec(args.lam, False, -a_c)
+            ctx.train_upload(xdc, gdc, tpc)
+            dchol['schedules']['dist.lookahead=%d' % la] = {
+                's_per_solve': t_best, 'phases_ms': {k_: ctx.phase_ms(k_)[0] for k_ in ('assemble', 'factor', 'solve')},
+                'solve_rel_residual': float(np.linalg.norm(-Kv - yc) / np.linalg.norm(yc))}
+        ctx.set_option('dist.lookahead', 0)
+        dchol['matrix_bytes_per_rank'] = ctx.mem_info()[0]
     except Exception as e:  # the strong-scaling line must not die with an extra
         dchol = {'skipped' if not args.dist_chol else 'error': repr(e)}
     ctx.close()
@@ -584,9 +611,8 @@ def run_sharded_cg(args, rank, world):
         hung = th.is_alive()
         to_tol = {'error': 'no result within {} s'.format(args.to_tol_timeout)} if hung else box.get('r')
         if not hung and to_tol is not None and 'train_wall_s' in to_tol:
-            tw = torch.tensor([to_tol['train_wall_s']], dtype=torch.float64)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            to_tol['time_to_tol_s'] = to_tol['train_wall_s'] = float(tw[0])
+            (tw,) = max_over_ranks([to_tol['train_wall_s']])
+            to_tol['time_to_tol_s'] = to_tol['train_wall_s'] = tw
 
     one_gpu = None
     if rank == 0 and not hung:  # the 1-GPU point of the curve, same run, same GPU as rank 0
@@ -594,15 +620,21 @@ def run_sharded_cg(args, rank, world):
         wl1 = make_cg_workload(c1, N, M, k, args.sig, args.lam)
         one_gpu = time_cg(c1, wl1, args.cg_iters, 1, 1, c1.sync)
         c1.close()
+    cpu = None
+    if rank == 0 and not hung and not args.no_cpu:
+        try:
+            cpu = cpu_baseline(N, args.sig, args.lam, args.n_train)
+        except Exception as e:
+            cpu = {'error': repr(e)}
     if not hung:
-        dist.barrier()
-        dist.destroy_process_group()
+        hg.barrier()
+        hg.close()
     if rank != 0:
         if hung:
             os._exit(0)
         return None
-    tot_bytes, iter_bytes = cg_algorithmic_bytes(wl, args.cg_iters, world)
-    ach = iter_bytes / (pcg_ms / args.cg_iters * 1e-3) / 1e9
+    gemv_bytes = res['gemv']['bytes_per_application']
+    ach = gemv_bytes / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else 0.0
     return {
         'metric': 'sharded Nystroem-PCG solve wall-clock per step (K_nm rows + preconditioner + {} PCG iterations), '
                   'N_train={} {}-atom (aspirin-sized)'.format(args.cg_iters, M, N),
@@ -612,11 +644,12 @@ def run_sharded_cg(args, rank, world):
         'config': {'workload': 'aspirin-sized N=21 N_train={} iterative solver (Nystroem-preconditioned CG, k={} inducing '
                                'points, {} iterations per step), kernel rows sharded over {} GPUs with {} '
                                '(BASELINE.json configs[2])'.format(M, k, args.cg_iters, world,
-                                                                   'RCCL' if comm == 'rccl' else 'host-staged gloo collectives'),
+                                                                   'RCCL' if comm == 'rccl' else 'host-staged collectives over TCP'),
                    'n_atoms': N, 'n_train': M, 'n_inducing_points': k, 'matrix_n': wl['n'], 'precon_m': wl['m'],
                    'pcg_iterations_per_step': args.cg_iters, 'sig': args.sig, 'lam': args.lam,
                    'parallelism': 'row-sharded Nystroem factor + query-sharded mat-vec over {} ranks'.format(world),
-                   'collectives': comm, 'rccl_probe': rccl_probe},
+                   'collectives': comm, 'rccl_probe': rccl_probe, 'host_side': 'sgdml_amd.hostchannel (no PyTorch in the ranks)',
+                   'preconditioner_form': wl.get('precon_form')},
         'phases_ms': {'assemble': asm_ms, 'precon': pre_ms, 'pcg': pcg_ms},
         'ms_per_pcg_iteration': pcg_ms / args.cg_iters,
         'collectives_per_step': res['collectives_per_step'],
@@ -626,12 +659,14 @@ def run_sharded_cg(args, rank, world):
         'one_gpu': one_gpu,
         'time_to_tol': to_tol,
         'dist_cholesky': dchol,
-        'roofline': {'kernel': 'gemv_t_part_kernel + gemv_n_precon_kernel (preconditioner X^T v, X t of one PCG iteration)',
+        'roofline': {'kernel': 'gemv_t_part + gemv_n_precon kernels (the two passes over this rank\'s rows of the preconditioner '
+                               'factor in one application, incl. the m-vector all-reduce between them): ' + str(wl.get('precon_form')),
                      'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                     'traffic': None,
-                     'note': 'achieved = 2 x (n/W x m x 8 B) per iteration / whole-iteration time (mat-vec, dots and '
-                             'collectives included)'},
-        'cpu_baseline': None,
+                     'traffic': None, 'avg_application_ms': gemv_ms, 'algorithmic_bytes_per_application': gemv_bytes,
+                     'note': 'achieved = algorithmic bytes of one application (2 x n/W x m x 8 B, 4 B in the fp32 form, + the '
+                             'm x m correction) / the kernels\' own time from HIP events (gdml_kernel_stat), max over ranks: '
+                             'comparable with the N = 1 record'},
+        'cpu_baseline': cpu,
     }
 
 

@@ -54,14 +54,16 @@ class GDMLTrain(object):
         return self._ctx
 
     def init_distributed(self, group=None, backend='rccl'):
-        """Shard the iterative solver over the ranks of an initialised torch.distributed process group (one
-        process per GPU): row-sharded Nystroem factor, query-sharded kernel mat-vec, RCCL all-reduce /
-        all-gather inside the library (csrc/comm.hip).  backend='host' stages the collectives through the
-        group instead (ranks sharing a GPU).  The reference's only multi-GPU path is nn.DataParallel
-        (train.py:1463-1469).  Returns (rank, world)."""
+        """Shard the solvers over the ranks of a one-process-per-GPU job: row-sharded Nystroem factor, query-sharded kernel
+        mat-vec, block-row-cyclic Cholesky, RCCL all-reduce / all-gather inside the library (csrc/comm.hip).  `group`: the
+        host-side group that ships the RCCL id and rank 0's decisions -- None = the PyTorch-free sgdml_amd.hostchannel built
+        from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (or the default torch.distributed group when one is initialised),
+        a HostChannel, or a torch.distributed process group.  backend='host' stages the collectives through the group
+        instead (ranks sharing a GPU).  The reference's only multi-GPU path is nn.DataParallel (train.py:1463-1469).
+        Returns (rank, world)."""
         from . import dist as _dist
 
-        return _dist.init_comm_from_torch_distributed(self._context(), group=group, backend=backend)
+        return _dist.init_comm(self._context(), group=group, backend=backend)
 
     def reserve_device_memory(self, gb=None):
         """Reserve the process-level device arena once and keep it (gdml_mem_reserve): the kernel matrices of every later

@@ -14,10 +14,26 @@ sys.path.insert(0, ROOT)
 def main():
     out_path, backend = sys.argv[1], sys.argv[2]
     solver = sys.argv[3] if len(sys.argv) > 3 else 'cg'
-    import torch.distributed as dist
+    if backend == 'chan':
+        # the PyTorch-free host group (sgdml_amd.hostchannel, rendezvous from RANK / WORLD_SIZE / MASTER_*): host-staged
+        # collectives over it, no torch import in this process
+        from sgdml_amd.dist import host_group
 
-    dist.init_process_group('gloo')
-    rank, world = dist.get_rank(), dist.get_world_size()
+        hg = host_group()
+        rank, world = hg.rank, hg.world
+        all_gather, finish, backend = hg.allgather_obj, hg.close, 'host'
+    else:
+        import torch.distributed as dist
+
+        dist.init_process_group('gloo')
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def all_gather(obj):
+            every = [None] * world
+            dist.all_gather_object(every, obj)
+            return every
+
+        finish = dist.destroy_process_group
     os.environ['LOCAL_RANK'] = '0' if backend == 'host' else os.environ.get('LOCAL_RANK', '0')
 
     from sgdml_amd.train import GDMLTrain
@@ -58,13 +74,12 @@ def main():
 
         model = tr.train(task, save_progr_callback=writer)
         assert tr._context().comm_info() == (rank, world)
-        chk = [None] * world
-        dist.all_gather_object(chk, float(np.abs(model['alphas_F']).sum()))
+        chk = all_gather(float(np.abs(model['alphas_F']).sum()))
         assert len(set(chk)) == 1, chk
         if rank == 0:
             np.savez(out_path, iters=model['solver_iters'], alphas=model['alphas_F'])
         tr.__del__()
-        dist.destroy_process_group()
+        finish()
         return
     if solver in ('ecstr', 'lu'):
         from sgdml_amd.solvers.analytic import Analytic
@@ -81,8 +96,7 @@ def main():
         tr.init_distributed(backend=backend)
         model = tr.train(task)
         assert tr._context().comm_info() == (rank, world)  # the communicator is back after the redundant solve
-        chk = [None] * world
-        dist.all_gather_object(chk, float(np.abs(model['alphas_F']).sum()))
+        chk = all_gather(float(np.abs(model['alphas_F']).sum()))
         assert len(set(chk)) == 1, chk
         if rank == 0:  # what GDMLPredict reads from a model (predict.py:326-354)
             keep = {k: model[k] for k in ('z', 'R_desc', 'R_d_desc_alpha', 'sig', 'c', 'std', 'perms', 'tril_perms_lin')}
@@ -90,7 +104,7 @@ def main():
                 keep['alphas_E'] = model['alphas_E']
             np.savez(out_path, used_lu=np.array(took), **keep)
         tr.__del__()
-        dist.destroy_process_group()
+        finish()
         return
     task['inducing_pts_idxs'] = g['inducing_pts_idxs']
     # the memory model must pick the fixture's k so that the given inducing columns are used as they are
@@ -110,11 +124,12 @@ def main():
     elif rank == 0:
         np.savez(out_path, alphas=model['alphas_F'], c=model['c'], coll_calls=calls, solver=model['solver_name'])
     # a second, restart-free property: all ranks hold the same coefficients
-    chk = [None] * world
-    dist.all_gather_object(chk, float(np.abs(model['alphas_F']).sum()))
+    chk = all_gather(float(np.abs(model['alphas_F']).sum()))
     assert len(set(chk)) == 1, chk
+    if sys.argv[2] == 'chan':
+        assert 'torch' not in sys.modules  # the whole sharded solve ran without PyTorch in the process
     tr.__del__()
-    dist.destroy_process_group()
+    finish()
 
 
 if __name__ == '__main__':

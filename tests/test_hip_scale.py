@@ -232,8 +232,9 @@ def test_sharded_iterative_processes_share_one_gpu(tmp_path, world):
     assert np.array_equal(r['inducing'], g['inducing_pts_idxs'])
     assert abs(int(r['iters']) - n_ref) <= max(2, n_ref // 10), (int(r['iters']), n_ref)
     assert float(r['resid']) <= 1e-4 * float(r['norm_y'])
-    # collectives: Nystroem factor 3, then 3 per PCG iteration (+ the integration-constant / setup mat-vecs)
-    assert int(r['coll_calls']) >= 3 + 3 * int(r['iters'])
+    # collectives: Nystroem factor 2 (its leverage scores -- one more all-gather -- are only computed when a restart asks
+    # for them), then 3 per PCG iteration (+ the integration-constant / setup mat-vecs)
+    assert int(r['coll_calls']) >= 2 + 3 * int(r['iters'])
     # the model predicts like the reference's
     from sgdml_amd import _lib
     from sgdml_amd.utils.desc import Desc
@@ -250,6 +251,29 @@ def test_sharded_iterative_processes_share_one_gpu(tmp_path, world):
         assert np.abs(F[1] - F[0]).max() <= 5e-3 * np.abs(F[0]).max()
     finally:
         c.close()
+
+
+def test_sharded_iterative_without_torch(tmp_path):
+    """The same sharded solve with NO PyTorch in the processes: two plain subprocesses (no launcher), rendezvous and the
+    host-staged collectives over sgdml_amd.hostchannel (GDMLTrain.init_distributed with its default group)."""
+    g = load('pcg_n9_m400')
+    out = str(tmp_path / 'shard_chan.npz')
+    port = 28000 + (os.getpid() % 900)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   OMP_NUM_THREADS='2')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_sharded_worker.py'), out, 'chan'], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, so[-2000:] + se[-3000:]
+    r = dict(np.load(out))
+    n_ref = int(g['n_iters'])
+    assert np.array_equal(r['inducing'], g['inducing_pts_idxs'])
+    assert abs(int(r['iters']) - n_ref) <= max(2, n_ref // 10), (int(r['iters']), n_ref)
+    assert float(r['resid']) <= 1e-4 * float(r['norm_y'])
+    assert int(r['coll_calls']) >= 2 + 3 * int(r['iters'])
 
 
 def _upload_as_K(ctx, A):

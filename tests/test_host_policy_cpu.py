@@ -60,11 +60,14 @@ class OracleContext(object):
             return orc.assemble_K(self.xd, self.gd, self.lin, sig, use_E_cstr, col_idxs=np.s_[:] if idx is None else idx,
                                   alloc_extra_rows=alloc_extra_rows)
 
-    def nystroem_factor(self, lam, idx, want_factor=False):
+    def nystroem_factor(self, lam, idx, want_factor=False, want_lev=True):
         self.calls.append('nystroem')
         sig, use_E, _ = self._asm
         self._fac = orc.nystroem_factor(self.xd, self.gd, self.lin, sig, lam, np.asarray(idx), use_E)
-        return (self._fac**2).sum(0), (self._fac if want_factor else None), 0
+        return ((self._fac**2).sum(0) if want_lev else None), (self._fac if want_factor else None), 0
+
+    def nystroem_lev_scores(self):  # the scores on demand (round 5: the main build no longer returns them)
+        return (self._fac**2).sum(0)
 
     def precon_apply(self, lam, v):
         return orc.precon_apply(self._fac, lam, v)
