@@ -81,7 +81,46 @@ def pair_potential_labels(R):
     return E, F
 
 
-def cpu_baseline(n_atoms, sig, lam, full_M, M_single=100, M_threads=300):
+def start_cpu_sample(M):
+    """The CPU leg's largest sample runs WHILE the GPU works on the configs[] section (the host cores are idle then):
+    tools/cpu_baseline_full.py M in a child process -- the oracle at M training points with the BLAS / LAPACK pool on all
+    host cores.  Returns (process, output path) or None."""
+    import subprocess
+    import tempfile
+
+    try:
+        fd, path = tempfile.mkstemp(prefix='gdml_cpu_sample_', suffix='.json')
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'cpu_baseline_full.py'), str(int(M))],
+                                stdout=fd, stderr=subprocess.DEVNULL, cwd=ROOT)
+        os.close(fd)
+        return proc, path
+    except Exception:
+        return None
+
+
+def finish_cpu_sample(handle, timeout):
+    if handle is None:
+        return None
+    proc, path = handle
+    try:
+        proc.wait(timeout=timeout)
+        with open(path) as f:
+            rec = json.loads(f.read().strip().splitlines()[-1])
+        return rec
+    except Exception:
+        try:
+            proc.kill()
+        except Exception:
+            pass
+        return None
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
+def cpu_baseline(n_atoms, sig, lam, full_M, M_single=100, M_threads=300, overlapped=None):
     """The oracle (NumPy port of the reference's algorithm, kind = "port") timed on the host cores on bounded
     samples of the same workload: M_single training points on ONE thread and M_threads points with the BLAS /
     LAPACK pool unrestricted (all host cores).  MEASURED numbers are reported as they are; the extrapolation to
@@ -127,6 +166,14 @@ def cpu_baseline(n_atoms, sig, lam, full_M, M_single=100, M_threads=300):
     est1, estt = extrap(m1), extrap(mt)
     best_threads = estt <= est1
     extrapolated = min(est1, estt)
+    # the sample that ran beside the GPU work of this very run (start_cpu_sample): the largest one, hence the extrapolation
+    # this run stands on -- or, with --cpu-full, the measurement at the benchmark size itself
+    in_run = None
+    if overlapped is not None and overlapped.get('n_atoms') == n_atoms:
+        in_run = dict(overlapped, extrapolated_to_full_s=extrap(overlapped),
+                      how='tools/cpu_baseline_full.py {} in a child process while the GPU ran the configs[] section'.format(overlapped['M']))
+        if overlapped['M'] != full_M:
+            extrapolated = in_run['extrapolated_to_full_s']
     # the one run of the same code at the benchmark size (tools/cpu_baseline_full.py on the GPU box's host, committed record)
     measured_full = None
     try:
@@ -155,12 +202,17 @@ def cpu_baseline(n_atoms, sig, lam, full_M, M_single=100, M_threads=300):
                                'reference\'s assembly forks one worker per core and is FASTER than the single-process port')
     except (OSError, ValueError, KeyError):
         pass
+    full_in_run = in_run is not None and in_run['M'] == full_M
     return {
-        # headline: the MEASURED number at the benchmark size when the committed record matches this configuration; the
-        # bounded sample taken in this run and its extrapolation are the side fields
-        'value': measured_full['build_solve_s'] if measured_full is not None else extrapolated,
-        'value_is': 'measured at the benchmark size (one committed run)' if measured_full is not None else
-                    'extrapolated from the bounded sample of this run (assembly ~M^2, solve ~M^3)',
+        # headline: the number MEASURED at the benchmark size -- in this run (--cpu-full) or the committed record of the same
+        # code on the same host type; the samples taken in this run and their extrapolation are the side fields
+        'value': in_run['build_solve_s'] if full_in_run else (measured_full['build_solve_s'] if measured_full is not None else extrapolated),
+        'value_is': 'measured at the benchmark size in this run' if full_in_run else
+                    ('measured at the benchmark size (one committed run); cross-checked by this run\'s samples, see in_run_sample'
+                     if measured_full is not None else 'extrapolated from the samples of this run (assembly ~M^2, solve ~M^3)'),
+        'in_run_sample': in_run,
+        'in_run_sample_vs_committed': None if (in_run is None or measured_full is None) else
+        (in_run['build_solve_s'] if full_in_run else in_run['extrapolated_to_full_s']) / measured_full['build_solve_s'] - 1.0,
         'unit': 's',
         'cores': (measured_full['cores'] if measured_full is not None else (cores if best_threads else 1)),
         'kind': 'port',
@@ -427,6 +479,8 @@ def main():
     ap.add_argument('--sig', type=float, default=20.0)
     ap.add_argument('--lam', type=float, default=1e-10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU-baseline leg')
+    ap.add_argument('--cpu-sample', type=int, default=500, help='training points of the CPU sample that runs beside the configs[] section')
+    ap.add_argument('--cpu-full', action='store_true', help='time the CPU port at the benchmark size in this run (4-5 minutes of host time, overlapped with the GPU work)')
     ap.add_argument('--no-configs', action='store_true', help='N=1: skip the configs[0] sweep and the configs[2] point')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--separate-solve', action='store_true',
@@ -860,6 +914,8 @@ def run_analytic(args):
         'roofline': roof,
     }
     out.update(extra)
+    # the CPU leg's largest sample starts now: the headline has been timed, the host cores are idle from here on
+    cpu_handle = None if args.no_cpu else start_cpu_sample(M if args.cpu_full else min(M, args.cpu_sample))
     try:  # the metric names "predict forces/sec": the resident model at four batch sizes, with both rooflines
         ctx.profile(False)
         out['predict']['by_batch'], out['roofline_predict'] = predict_sweep(ctx, lib, Rq, N, M, 1)
@@ -913,7 +969,11 @@ def run_analytic(args):
             except Exception as e:
                 cfgs.append({'config': label, 'error': repr(e)})
         out['configs'] = cfgs
-    out['cpu_baseline'] = None if args.no_cpu else cpu_baseline(N, args.sig, args.lam, M)
+    if not args.no_cpu:
+        over = finish_cpu_sample(cpu_handle, timeout=900 if args.cpu_full else 240)
+        out['cpu_baseline'] = cpu_baseline(N, args.sig, args.lam, M, overlapped=over)
+    else:
+        out['cpu_baseline'] = None
     return out
 
 

@@ -76,7 +76,7 @@ struct gdml_ctx {
   hipStream_t stream2 = nullptr;
   hipStream_t kt_stream = nullptr;                       // stream the per-kernel timers record on (default: stream)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipEvent_t ev_la[2] = {nullptr, nullptr};  // look-ahead hand-off between the two streams
+  hipEvent_t ev_la[6] = {};  // hand-offs between the two streams (look-ahead, overlapped panel solves)
   std::string err;
   std::map<std::string, double> opts;  // tuning / ablation options (gdml_set_option); absent key = built-in default
   int64_t held = 0;

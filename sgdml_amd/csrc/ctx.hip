@@ -188,6 +188,10 @@ extern "C" int gdml_ctx_create(int device, gdml_ctx** ctx_out) {
       (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&ctx->ev_la[0], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&ctx->ev_la[1], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&ctx->ev_la[2], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&ctx->ev_la[3], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&ctx->ev_la[4], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&ctx->ev_la[5], hipEventDisableTiming)) != hipSuccess ||
       (e = hipMalloc((void**)&ctx->d_info, 64)) != hipSuccess) {
     gdml_fail(nullptr, GDML_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
     delete ctx;
@@ -219,8 +223,8 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
   if (ctx->d_info) hipFree(ctx->d_info);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  if (ctx->ev_la[0]) hipEventDestroy(ctx->ev_la[0]);
-  if (ctx->ev_la[1]) hipEventDestroy(ctx->ev_la[1]);
+  for (hipEvent_t ev : ctx->ev_la)
+    if (ev) hipEventDestroy(ev);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
