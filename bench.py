@@ -82,7 +82,8 @@ def pair_potential_labels(R):
 
 
 def start_cpu_sample(M):
-    """The CPU leg's largest sample runs WHILE the GPU works on the configs[] section (the host cores are idle then):
+    """The CPU leg's largest sample runs WHILE the GPU works on the analytic entries of the configs[] section (long kernels,
+    the host cores are idle then):
     tools/cpu_baseline_full.py M in a child process -- the oracle at M training points with the BLAS / LAPACK pool on all
     host cores.  Returns (process, output path) or None."""
     import subprocess
@@ -171,7 +172,7 @@ def cpu_baseline(n_atoms, sig, lam, full_M, M_single=100, M_threads=300, overlap
     in_run = None
     if overlapped is not None and overlapped.get('n_atoms') == n_atoms:
         in_run = dict(overlapped, extrapolated_to_full_s=extrap(overlapped),
-                      how='tools/cpu_baseline_full.py {} in a child process while the GPU ran the configs[] section'.format(overlapped['M']))
+                      how='tools/cpu_baseline_full.py {} in a child process while the GPU ran the analytic configs[] entries'.format(overlapped['M']))
         if overlapped['M'] != full_M:
             extrapolated = in_run['extrapolated_to_full_s']
     # the one run of the same code at the benchmark size (tools/cpu_baseline_full.py on the GPU box's host, committed record)
@@ -914,8 +915,7 @@ def run_analytic(args):
         'roofline': roof,
     }
     out.update(extra)
-    # the CPU leg's largest sample starts now: the headline has been timed, the host cores are idle from here on
-    cpu_handle = None if args.no_cpu else start_cpu_sample(M if args.cpu_full else min(M, args.cpu_sample))
+    cpu_handle = None
     try:  # the metric names "predict forces/sec": the resident model at four batch sizes, with both rooflines
         ctx.profile(False)
         out['predict']['by_batch'], out['roofline_predict'] = predict_sweep(ctx, lib, Rq, N, M, 1)
@@ -964,12 +964,19 @@ def run_analytic(args):
             ('configs[4] shape at the largest N_train one GPU factors directly: 100 atoms, N_train=500 (n = 150 000, 180 GB), analytic',
              dict(n_atoms=100, n_train=500, solver='analytic', sig=args.sig)),
         ):
+            if kw.get('solver') == 'analytic' and cpu_handle is None and not args.no_cpu:
+                # the CPU leg's largest sample starts here: the two analytic shapes are minutes of long GPU kernels with no
+                # host role, so the host cores are free -- beside the iterative entries above it cost their per-iteration host
+                # callbacks 20 % (measured: configs[2] 7.2 -> 8.6 s), so it does not run there
+                cpu_handle = start_cpu_sample(M if args.cpu_full else min(M, args.cpu_sample))
             try:
                 cfgs.append(solve_config(label, lam=args.lam, **kw))
             except Exception as e:
                 cfgs.append({'config': label, 'error': repr(e)})
         out['configs'] = cfgs
     if not args.no_cpu:
+        if cpu_handle is None:  # --no-configs: nothing to overlap with
+            cpu_handle = start_cpu_sample(M if args.cpu_full else min(M, args.cpu_sample))
         over = finish_cpu_sample(cpu_handle, timeout=900 if args.cpu_full else 240)
         out['cpu_baseline'] = cpu_baseline(N, args.sig, args.lam, M, overlapped=over)
     else:

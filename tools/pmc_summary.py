@@ -23,7 +23,7 @@ for k, ds in byk.items():
         if not c.startswith('_'): print('   %-28s %.4g' % (c, tot[c]))
     wc = tot.get('SQ_WAVE_CYCLES', 0)
     if wc:
-        for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY'):
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_VALU"):
             if c in tot: print('   %-28s %.1f%% of WAVE_CYCLES' % (c + '/WC', 100 * tot[c] / wc))
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in tot and 'GRBM_GUI_ACTIVE' in tot:
         # MFMA busy is summed over SIMDs (1024); GUI_ACTIVE is per-XCD-summed? report raw ratio
