@@ -318,6 +318,38 @@ __global__ void __launch_bounds__(256) round_f32_kernel(const double* __restrict
   float* row32 = X32 + r * ld;
   for (int64_t c = threadIdx.x; c < ld; c += 256) row32[c] = c < m ? (float)row[c] : 0.0f;
 }
+// Compensated accumulation of the chunk Gram matrices (lower tiles): G += Gp with the running compensation in Gc.  The
+// products of two fp32 values are exact in fp64, a chunk of 2048 rows is one short MFMA chain per entry, and the chunks are
+// summed here with Kahan's scheme: the diagonal of G (entries ~1, the only ones whose rounding matters on the scale
+// lam / sigma_max ~ 1e-13 the operator lives on) comes out to ~2e-16 instead of eps sqrt(n / 4) ~ 3e-14.
+__global__ void __launch_bounds__(256) kahan_acc_lower_kernel(double* __restrict__ G, double* __restrict__ Gc,
+                                                              const double* __restrict__ Gp, int64_t ld, int64_t m, int first) {
+  const int64_t r = blockIdx.x;
+  const int64_t cend = ((r / TT) + 1) * TT < m ? ((r / TT) + 1) * TT : m;  // the lower TILES hold valid data
+  for (int64_t c = threadIdx.x; c < cend; c += 256) {
+    const int64_t e = r * ld + c;
+    if (first) {
+      G[e] = Gp[e];
+      Gc[e] = 0.0;
+    } else {
+      const double y = Gp[e] - Gc[e];
+      const double t = G[e] + y;
+      Gc[e] = (t - G[e]) - y;
+      G[e] = t;
+    }
+  }
+}
+// A <- A - I
+__global__ void __launch_bounds__(256) sub_eye_kernel(double* __restrict__ A, int64_t ld, int64_t m) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < m) A[t * ld + t] -= 1.0;
+}
+// T0 <- G0 - H - H^T + S   (in place on the buffer that holds G0)
+__global__ void __launch_bounds__(256) t0_combine_kernel(double* __restrict__ T0, const double* __restrict__ H,
+                                                         const double* __restrict__ S, int64_t ld, int64_t m) {
+  const int64_t r = blockIdx.x;
+  for (int64_t c = threadIdx.x; c < m; c += 256) T0[r * ld + c] = ((T0[r * ld + c] - H[r * ld + c]) - H[c * ld + r]) + S[r * ld + c];
+}
 // D (rows x ld doubles) <- double(X32 rows): the Gram matrix of the rounded factor is accumulated chunk by chunk
 __global__ void __launch_bounds__(256) widen_f32_kernel(const float* __restrict__ X32, int64_t ld, double* __restrict__ D) {
   const int64_t r = blockIdx.x;
@@ -667,18 +699,17 @@ __global__ void __launch_bounds__(256) gather_neg_rows_sharded_kernel(const doub
 //      orthonormal when formed row by row (cond(K_nm) ~ 1e10: |K_nm| |Z| eps ~ 1e-5), and PCG at lam = 1e-10 does not
 //      converge with it (profiles/r05_pcg_bisect.txt).  Usable for lam >~ 1e-6; never chosen automatically.
 //   3  the factor stored in fp32 + the m x m Gram correction T0 (above): half the bytes per application
-//   2  automatic (default): 3 when the factor is large enough for its streaming to dominate an iteration (>= 1 GiB per
-//      rank) AND the extra build work -- one more Gram pass over the factor, 2 n m^2 flops, and ~8 m^3 for T0 -- is paid back
-//      within ~500 iterations (4 n m bytes saved per pass, two passes: break-even at ~0.027 m (1 + 4 m / n) iterations;
-//      configs[2] 310, configs[4] 210, configs[3] 840: measured 17.9 s stored against 19.4 s there), else 0 -- every
-//      reference-parity fixture of the test suite stays on the reference's form.
+//   2  automatic (default): 3 once the factor reaches 1 GiB per rank, else 0 -- every reference-parity fixture of the test
+//      suite stays on the reference's form.  The extra build work of form 3 (one more Gram pass over the factor, 2 n m^2
+//      flops, ~8 m^3 for T0) is paid back twice: half the bytes per application, and -- the larger effect -- FEWER
+//      iterations: the stored factor carries the spectrum 1 - lam / (sigma + lam) of the dominant directions only to ~1e-10
+//      (its Gram matrix is off the exact one by that much), which parks PCG on a plateau for hundreds of iterations; T0
+//      carries it to ~1e-16 (configs[2]: 861 -> 306 iterations, configs[4]: 2261 -> 841, profiles/r05_precon_forms.txt).
 // Every input of the decision is the same on every rank.
 static int choose_precon_form(const gdml_ctx* ctx, const ShardGeo& sg, int64_t m, int64_t ld) {
   const int opt = ctx_opt_i(ctx, "pcg.precon_form", 2);
   if (opt == 0 || opt == 1 || opt == 3) return opt;
-  if (8.0 * (double)sg.chunk * (double)m < (double)((int64_t)1 << 30)) return 0;
-  const double break_even = 0.027 * (double)m * (1.0 + 4.0 * (double)m / (double)(sg.chunk > 0 ? sg.chunk : 1));
-  return break_even <= 500.0 ? 3 : 0;
+  return 8.0 * (double)sg.chunk * (double)m >= (double)((int64_t)1 << 30) ? 3 : 0;
 }
 
 static int ensure_buf(gdml_ctx* ctx, void** p, int64_t* have, int64_t want) {
@@ -705,14 +736,15 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
   {  // no room for the fp32 copy next to the fp64 factor: keep the reference's form (X is untouched at this point)
     int rc_a = ensure_buf(ctx, (void**)&ctx->precon_X32, &ctx->precon_X32_bytes, (n_loc > 0 ? n_loc : 1) * ld * 4);
     if (rc_a == GDML_OK) rc_a = ensure_buf(ctx, (void**)&ctx->precon_T0, &ctx->precon_T0_bytes, m * ld * 8);
-    if (rc_a == GDML_OK) rc_a = ctx_alloc(ctx, &tmp, 2 * m * ld * 8);
+    if (rc_a == GDML_OK) rc_a = ctx_alloc(ctx, &tmp, 4 * m * ld * 8);
     if (rc_a == GDML_ERR_OOM) return GDML_OK;
     GDML_TRY(rc_a);
   }
-  double* Rb = (double*)tmp;   // L^-T, later L_G^-T
-  double* G = Rb + m * ld;     // Gram of the rounded factor, then its Cholesky factor
-  double* G0 = ctx->precon_T0; // lives in the T0 buffer until T0 itself is formed
-  double* H = G;               // (G is dead once L_G^-T has been formed from it)
+  double* Rb = (double*)tmp;   // L^-T, later E_z = L_G^-T - I
+  double* G = Rb + m * ld;     // Gram of the rounded factor, then its Cholesky factor, then S = W1 E_z^T
+  double* Gc = G + m * ld;     // Kahan compensation of the Gram sum, then H = -W1
+  double* Gp = Gc + m * ld;    // Gram matrix of one chunk of rows
+  double* G0 = ctx->precon_T0; // lives in the T0 buffer until T0 itself is formed in place
   const int tiles = (int)((m + TT - 1) / TT);
   const dim3 tri((unsigned)(tiles * (tiles + 1) / 2));
   auto identity = [&](double* A) -> int {
@@ -728,21 +760,23 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
     hipLaunchKernelGGL(syrk_tn_kernel, tri, dim3(256), 0, st, Rb, ld, m, m, G0, ld, tiles, 0);
     hipLaunchKernelGGL(sym_fill_kernel, dim3((unsigned)m), dim3(256), 0, st, G0, ld, m);
     hipLaunchKernelGGL(eye_minus_kernel, dim3((unsigned)m), dim3(256), 0, st, G0, ld, m);
-    // rounded factor and its Gram (summed over the row shards).  The fp32 values are widened chunk by chunk into a work
-    // buffer and the Gram kernel accumulates over the chunks: X stays untouched, and the accumulation chains stay short
+    // rounded factor and its Gram matrix (summed over the row shards).  The fp32 values are widened chunk by chunk into a
+    // work buffer (X stays untouched), every chunk's Gram matrix is one short MFMA chain per entry, and the chunks are
+    // summed with compensation (kahan_acc_lower_kernel): the diagonal of G is what the spectrum correction hangs on
     if (n_loc > 0)
       hipLaunchKernelGGL(round_f32_kernel, dim3((unsigned)n_loc), dim3(256), 0, st, X, ld, n_loc, m, ctx->precon_X32);
     {
-      int64_t chunk = ((int64_t)2 << 30) / (ld * 8);
-      chunk = chunk < 1024 ? 1024 : chunk / 16 * 16;
+      int64_t chunk = (int64_t)ctx_opt(ctx, "pcg.f32_gram_rows", 2048);
+      chunk = chunk < 256 ? 256 : chunk / 16 * 16;
       if (chunk > n_loc) chunk = n_loc > 0 ? n_loc : 1;
       double* D;
       GDML_TRY(ctx_slot(ctx, 11, chunk * ld * 8, &D));
-      if (n_loc == 0) HIP_CHECK(ctx, hipMemsetAsync(G, 0, m * ld * 8, st));
+      HIP_CHECK(ctx, hipMemsetAsync(G, 0, 2 * m * ld * 8, st));  // G and Gc (upper tiles are never written again)
       for (int64_t r0 = 0; r0 < n_loc; r0 += chunk) {
         const int64_t rows = (n_loc - r0 < chunk) ? n_loc - r0 : chunk;
         hipLaunchKernelGGL(widen_f32_kernel, dim3((unsigned)rows), dim3(256), 0, st, ctx->precon_X32 + r0 * ld, ld, D);
-        hipLaunchKernelGGL(syrk_tn_kernel, tri, dim3(256), 0, st, D, ld, rows, m, G, ld, tiles, r0 > 0 ? 1 : 0);
+        hipLaunchKernelGGL(syrk_tn_kernel, tri, dim3(256), 0, st, D, ld, rows, m, Gp, ld, tiles, 0);
+        hipLaunchKernelGGL(kahan_acc_lower_kernel, dim3((unsigned)m), dim3(256), 0, st, G, Gc, Gp, ld, m, r0 == 0 ? 1 : 0);
       }
     }
     GDML_TRY(comm_allreduce_sum(ctx, G, m * ld));
@@ -760,13 +794,20 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
       ctx->opts["pcg.f32_last_min_pivot"] = dmin * dmin;  // diagnostic, read back with gdml_get_option
       if (!(dmin * dmin >= ctx_opt(ctx, "pcg.f32_min_pivot", 1e-7))) return GDML_OK;
     }
-    // T0 = L_G^-T G0 L_G^-1 = Zt G0 Zt^T, Zt = L_G^-T:   H = -(Zt G0^T),   T0 = 0 - Zt H^T
+    // T0 = Zt G0 Zt^T with Zt = L_G^-T = I + E_z.  Formed as G0 + W1 + W1^T + W1 E_z^T, W1 = E_z G0: every product has a
+    // small factor (|E_z| ~ 1 - s_min^2), so the MFMA sums carry errors far below eps, and the entries ~1 of T0 come from
+    // G0 by three additions -- as a plain triple product the diagonal would lose eps sqrt(m) ~ 5e-15, the scale of the
+    // spectrum the matrix exists to carry.
     GDML_TRY(identity(Rb));
     GDML_TRY(tall_trsm(ctx, G, Rb, m, m, ld));
+    hipLaunchKernelGGL(sub_eye_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, Rb, ld, m);  // Rb = E_z
+    double* H = Gc;
+    double* Sx = G;
     HIP_CHECK(ctx, hipMemsetAsync(H, 0, m * ld * 8, st));
-    GDML_TRY(launch_gemm_nt_sub(ctx, st, Rb, ld, G0, ld, H, ld, m, m, m, 0));
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->precon_T0, 0, m * ld * 8, st));  // G0 is dead: its buffer becomes T0
-    GDML_TRY(launch_gemm_nt_sub(ctx, st, Rb, ld, H, ld, ctx->precon_T0, ld, m, m, m, 0));
+    GDML_TRY(launch_gemm_nt_sub(ctx, st, Rb, ld, G0, ld, H, ld, m, m, m, 0));   // H = -(E_z G0^T) = -W1
+    HIP_CHECK(ctx, hipMemsetAsync(Sx, 0, m * ld * 8, st));
+    GDML_TRY(launch_gemm_nt_sub(ctx, st, H, ld, Rb, ld, Sx, ld, m, m, m, 0));   // S = -(H E_z^T) = W1 E_z^T
+    hipLaunchKernelGGL(t0_combine_kernel, dim3((unsigned)m), dim3(256), 0, st, ctx->precon_T0, H, Sx, ld, m);
     HIP_CHECK(ctx, hipGetLastError());
     *usable = 1;
     return GDML_OK;

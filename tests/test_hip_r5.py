@@ -132,7 +132,7 @@ def test_fp32_preconditioner_on_the_reference_pcg_runs(name, maxit):
         n_ref, ref = int(g['n_iters']), g['resid_hist']
         x, iters, ours = runs[3]
         assert iters <= n_ref + max(2, n_ref // 10), (iters, runs[0][1], n_ref)
-        assert iters >= n_ref // 3, (iters, runs[0][1], n_ref)
+        assert iters >= n_ref // 4, (iters, runs[0][1], n_ref)
         np.testing.assert_allclose(ours[:8], ref[:8], rtol=1e-3)
         r = c.kernel_matvec(lam, False, x) + y
         assert np.linalg.norm(r) <= 1.05e-4 * np.linalg.norm(y)

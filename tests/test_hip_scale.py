@@ -253,16 +253,19 @@ def test_sharded_iterative_processes_share_one_gpu(tmp_path, world):
         c.close()
 
 
-def test_sharded_iterative_without_torch(tmp_path):
+@pytest.mark.parametrize('form', [2, 3])
+def test_sharded_iterative_without_torch(tmp_path, form):
     """The same sharded solve with NO PyTorch in the processes: two plain subprocesses (no launcher), rendezvous and the
-    host-staged collectives over sgdml_amd.hostchannel (GDMLTrain.init_distributed with its default group)."""
+    host-staged collectives over sgdml_amd.hostchannel (GDMLTrain.init_distributed with its default group).  form = 3: the
+    fp32 + Gram-correction preconditioner in its sharded form (row shards of X32, Gram matrix summed over the ranks, T0
+    replicated) -- converged in no more iterations than the reference."""
     g = load('pcg_n9_m400')
     out = str(tmp_path / 'shard_chan.npz')
-    port = 28000 + (os.getpid() % 900)
+    port = 28000 + (os.getpid() % 900) + 3 * form
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   OMP_NUM_THREADS='2')
+                   OMP_NUM_THREADS='2', GDML_OPTIONS='pcg.precon_form=%d' % form)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_sharded_worker.py'), out, 'chan'], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     for p in procs:
@@ -271,7 +274,10 @@ def test_sharded_iterative_without_torch(tmp_path):
     r = dict(np.load(out))
     n_ref = int(g['n_iters'])
     assert np.array_equal(r['inducing'], g['inducing_pts_idxs'])
-    assert abs(int(r['iters']) - n_ref) <= max(2, n_ref // 10), (int(r['iters']), n_ref)
+    if form == 3:
+        assert n_ref // 4 <= int(r['iters']) <= n_ref + max(2, n_ref // 10), (int(r['iters']), n_ref)
+    else:
+        assert abs(int(r['iters']) - n_ref) <= max(2, n_ref // 10), (int(r['iters']), n_ref)
     assert float(r['resid']) <= 1e-4 * float(r['norm_y'])
     assert int(r['coll_calls']) >= 2 + 3 * int(r['iters'])
 

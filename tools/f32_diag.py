@@ -34,8 +34,7 @@ def main():
     _, _, info = c.nystroem_factor(lam, idx, want_lev=False)
     c.predict_upload_model(xd, np.zeros_like(xd), tp, sig, None)
     buf = c.K_to_host()
-    Xt, L = buf[:n], np.tril(buf[n:n + m])
-    assert np.array_equal(Xt, Xt.astype(np.float32).astype(np.float64)), 'resident factor is not fp32-representable'
+    Xt, L = buf[:n].astype(np.float32).astype(np.float64), np.tril(buf[n:n + m])  # the device's X32 = float(X), X resident in fp64
     Y = sla.solve_triangular(L, np.eye(m), lower=True)  # L^-1
     W = Y.T @ Y  # L^-T L^-1 ... careful: X = B L^-T, X^T X = L^-1 (L L^T - lam) L^-T = I - lam L^-1 L^-T
     Wc = Y @ Y.T  # L^-1 L^-T
@@ -61,6 +60,12 @@ def main():
               (name, s, np.abs(pn - truth).max() / s, np.abs(pg - truth).max() / s))
     ny = np.linalg.norm(y)
     lv = (0.3, 0.1, 0.03, 0.01, 3e-3, 1e-3)
+    def dev_loop():
+        h = []
+        x, inf, it, res = c.pcg(lam, False, y, rtol=1e-4, maxiter=1500, callback=lambda i, r, f: h.append(r) or False)
+        print('%-56s iters %4d crossings %s' % ('device loop gdml_pcg, fp32 + Gram correction', it, crossings(np.array(h), ny, lv).tolist()), flush=True)
+
+    dev_loop()
     for name, P in (('host loop, dense K, NumPy T0 on the GPU-built X32 / L', P_np), ('host loop, dense K, GPU operator', P_gpu)):
         h = []
         x, inf, it, res = orc.pcg(lambda v: -(K @ v - lam * v), y, M_mv=lambda r: (h.append(np.linalg.norm(r)), P(r))[1], rtol=1e-4, maxiter=1500)
