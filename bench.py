@@ -954,6 +954,10 @@ def run_analytic(args):
             ('configs[2]: aspirin-sized N=21, N_train={} iterative solver to solver_tol 1e-4 on a synthetic trajectory '
              '(bench.synth_trajectory), device-memory budget 32 GB -> k inducing points by the memory model'.format(args.cg_n_train),
              dict(n_atoms=N, n_train=args.cg_n_train, solver='cg', max_memory=32, traj=TRAJ, sig=args.sig)),
+            ('configs[2] again with the REFERENCE\'s form of the preconditioner (pcg.precon_form = 0: the stored fp64 factor, '
+             'iterative.py:120-140) instead of the fp32 factor + Gram correction the library picks at this size',
+             dict(n_atoms=N, n_train=args.cg_n_train, solver='cg', max_memory=32, traj=TRAJ, sig=args.sig,
+                  options={'pcg.precon_form': 0})),
             ('configs[3]: N=42 with a 27-element permutation group, N_train=2000 (n = 252 000: 508 GB as a matrix), iterative '
              'solver to solver_tol 1e-4, budget 64 GB', dict(n_atoms=42, n_train=2000, perms_kind='c3x3', solver='cg', max_memory=64,
                                                             traj=TRAJ, sig=60)),
