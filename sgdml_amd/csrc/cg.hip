@@ -737,8 +737,23 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
     int rc_a = ensure_buf(ctx, (void**)&ctx->precon_X32, &ctx->precon_X32_bytes, (n_loc > 0 ? n_loc : 1) * ld * 4);
     if (rc_a == GDML_OK) rc_a = ensure_buf(ctx, (void**)&ctx->precon_T0, &ctx->precon_T0_bytes, m * ld * 8);
     if (rc_a == GDML_OK) rc_a = ctx_alloc(ctx, &tmp, 4 * m * ld * 8);
-    if (rc_a == GDML_ERR_OOM) return GDML_OK;
-    GDML_TRY(rc_a);
+    if (rc_a != GDML_OK && rc_a != GDML_ERR_OOM) return rc_a;
+    // sharded: every rank must apply the same form (row blocks of ONE operator) -- free HBM differs between the ranks, so
+    // the decision is collective: the form is kept only if the buffers fit everywhere
+    double fits = rc_a == GDML_OK ? 1.0 : 0.0;
+    if (comm_active(ctx)) {
+      double* d_flag;
+      GDML_TRY(ctx_slot(ctx, 10, 64, &d_flag));
+      HIP_CHECK(ctx, hipMemcpyAsync(d_flag, &fits, 8, hipMemcpyHostToDevice, st));
+      GDML_TRY(comm_allreduce_sum(ctx, d_flag, 1));
+      HIP_CHECK(ctx, hipMemcpyAsync(&fits, d_flag, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(ctx, hipStreamSynchronize(st));
+      fits = fits >= (double)ctx->world - 0.5 ? 1.0 : 0.0;
+    }
+    if (fits < 0.5) {
+      if (tmp) GDML_TRY(ctx_free(ctx, tmp));
+      return GDML_OK;
+    }
   }
   double* Rb = (double*)tmp;   // L^-T, later E_z = L_G^-T - I
   double* G = Rb + m * ld;     // Gram of the rounded factor, then its Cholesky factor, then S = W1 E_z^T
