@@ -118,8 +118,8 @@ class Iterative(object):
         Nothing to benchmark on the GPU -- and by default nothing is drawn: the caller's global NumPy stream is left alone,
         like the reference's own torch path does.  Only the golden tests, which replay a freshly installed reference's run
         column by column (the stream also picks the inducing columns of every restart), ask for the emulation
-        (gdml_train._emulate_ref_rng = True)."""
-        if getattr(self.gdml_train, '_emulate_ref_rng', False):
+        (GDMLTrain.emulate_reference_rng = True)."""
+        if getattr(self.gdml_train, 'emulate_reference_rng', False) or getattr(self.gdml_train, '_emulate_ref_rng', False):
             np.random.rand(n_train, dim_i)
 
     def _lev_scores(self, R_desc, R_d_desc, tril_perms_lin, sig, lam, use_E_cstr, n_inducing_pts, callback=None):

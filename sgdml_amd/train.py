@@ -36,9 +36,12 @@ class GDMLTrain(object):
         self._ctx = None
         self._force_solver = None  # testing hook: 'analytic' or 'cg' overrides the memory-based choice
         self._force_n_inducing_pts = None  # testing hook: inducing points of the iterative solver (else memory model)
-        # testing hook: spend the np.random draws the reference's CPU path spends on its worker benchmark
-        # (solvers/iterative.py::_spend_reference_benchmark_draw); off: the caller's global stream is left alone
-        self._emulate_ref_rng = False
+        # Public switch: spend the np.random draws the reference's CPU path spends on its worker benchmark before the CG
+        # loop (solvers/iterative.py::_spend_reference_benchmark_draw), so that a run under the same np.random.seed draws the
+        # inducing columns of a freshly installed reference's NumPy path.  Off by default: the caller's global stream is
+        # left alone, like the reference's own torch path does (README, "Things a user of the reference should know").
+        self.emulate_reference_rng = False
+        self._emulate_ref_rng = False  # rounds 3-4 name of the same switch (tests)
 
     def __del__(self):
         global _instance_alive
