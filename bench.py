@@ -188,12 +188,17 @@ def cpu_baseline(n_atoms, sig, lam, full_M, M_single=100, M_threads=300, overlap
     # /root/reference does not exist on the GPU box): tools/cpu_ref_vs_port.py -> per-phase ratio reference / port
     ref_vs_port = None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r04_cpu_reference_vs_port.json')) as f:
-            rv = json.load(f)
+        points = []
+        for fn in ('r04_cpu_reference_vs_port.json', 'r05_cpu_reference_vs_port_m500.json'):  # M = 250 and M = 500
+            with open(os.path.join(ROOT, 'profiles', fn)) as f:
+                points.append(json.load(f))
+        rv = points[-1]  # the larger sample is the one applied (assembly ~M^2 and solve ~M^3 weigh the phases differently)
         b = rv['best_of_layouts']
         ref_vs_port = {'assemble': b['assemble_s']['reference_over_port'], 'solve': b['solve_s']['reference_over_port'],
                        'measured_at': 'N={} M={} on {} cores of the build container, best of the two thread layouts per phase '
-                                      '(profiles/r04_cpu_reference_vs_port.json)'.format(rv['n_atoms'], rv['M'], rv['host']['nproc'])}
+                                      '(profiles/r05_cpu_reference_vs_port_m500.json)'.format(rv['n_atoms'], rv['M'], rv['host']['nproc']),
+                       'all_points': [{'M': p_['M'], 'assemble': p_['best_of_layouts']['assemble_s']['reference_over_port'],
+                                       'solve': p_['best_of_layouts']['solve_s']['reference_over_port']} for p_ in points]}
         src = measured_full if measured_full is not None else \
             {'assemble_s': (m1 if not best_threads else mt)['assemble_s'] * (full_M / float((m1 if not best_threads else mt)['M'])) ** 2,
              'solve_s': (m1 if not best_threads else mt)['solve_s'] * (full_M / float((m1 if not best_threads else mt)['M'])) ** 3}

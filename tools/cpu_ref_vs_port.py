@@ -2,7 +2,7 @@
 """The REFERENCE's CPU path timed beside the oracle (the NumPy port bench.py's cpu_baseline leg times on the GPU box) on
 identical inputs, in the two thread layouts of BASELINE.md section 3.2.  Build container only (needs /root/reference):
 
-    python tools/cpu_ref_vs_port.py [M]          -> profiles/r04_cpu_reference_vs_port.json
+    python tools/cpu_ref_vs_port.py [M]          -> profiles/r05_cpu_reference_vs_port_m<M>.json
 
   layout "blas":  one Python process, BLAS/LAPACK threads = all cores   (best for the Cholesky)
   layout "procs": reference worker pool = all cores, BLAS threads = 1    (best for the reference's assembly: it forks
@@ -104,7 +104,7 @@ def main():
     rec = {'what': 'reference (sgdml, /root/reference) vs oracle/gdml_oracle.py on identical inputs, build container',
            'n_atoms': 21, 'M': M, 'layouts': out, 'best_of_layouts': best,
            'host': {'nproc': os.cpu_count(), 'numpy': numpy.__version__, 'scipy': scipy.__version__}}
-    path = os.path.join(ROOT, 'profiles', 'r04_cpu_reference_vs_port.json')
+    path = os.path.join(ROOT, "profiles", "r05_cpu_reference_vs_port_m%d.json" % M)
     with open(path, 'w') as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec['best_of_layouts']))
