@@ -247,8 +247,10 @@ def make_cg_workload(ctx, n_atoms, n_train, k_inducing, sig, lam):
     xd, gd = ctx.desc_from_R(R.reshape(n_train, -1), n_atoms)
     ctx.train_upload(xd, gd, tp)
     ctx.predict_upload_model(xd, np.zeros_like(xd), tp, sig, None)
-    pts = np.sort(np.random.RandomState(1).choice(n_train, k_inducing, replace=False))
-    idx = (pts[:, None] * N3 + np.arange(N3)[None]).ravel().astype(np.int64)
+    # inducing COLUMNS drawn uniformly (what the reference's own first stage does, iterative.py:372-379; rounds 1-4 took all 3N
+    # columns of k random points, which gives a numerically rank-deficient K_mm -- min pivot^2 6e-9 -- that no leverage-sampled
+    # run produces and on which the fp32 form of the preconditioner declines, profiles/r05_precon_forms.txt)
+    idx = np.sort(np.random.RandomState(1).choice(n_train * N3, k_inducing * N3, replace=False)).astype(np.int64)
     return {'y': y, 'idx': idx, 'sig': sig, 'lam': lam, 'n': n_train * N3, 'm': idx.size}
 
 
