@@ -111,6 +111,11 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *                         full-line stores, row points per workgroup
  *   asm.perm_compact (1)  index-list columns: strips of the REQUESTED column atoms instead of all atoms of every point touched
  *   asm.perm_lds_rows (1) permutation entries from the LDS copy for 64 < N <= 128 (always beyond 128 atoms); 0 = two lane-held rows (A/B)
+ *   asm.perm2 (1)         molecules with a permutation group, asm.perm2_min_n (25) <= N <= 42, dense column ranges: outer products on
+ *                         the fp64 MFMA pipe, contributions of atom pairs no permutation moves summed once per block
+ *                         (csrc/assemble_perm2.hip); asm.perm2_split (1; 0 = every pair per permutation), asm.perm2_chunk (24) pair
+ *                         entries per lane and task, asm.perm2_i_chunk (16) row points per workgroup, asm.perm2_debug (0)
+ *                         timing-only ablation mask (results are wrong when set)
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
  *   gemm.nt_c (0)         non-temporal loads / stores of the C tile (after rocBLAS's Tensile kernel for this shape:
  *                         profiles/r03_vendor_kernels.txt; no gain measured)

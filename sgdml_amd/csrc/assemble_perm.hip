@@ -782,6 +782,11 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
     return gdml_fail(ctx, GDML_ERR_INVALID, "assemble_perm: the lower form needs the dense full column range");
   if (cyc_W > 0 && 3 * N > cyc_nb)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_perm: row-cyclic layout needs 3N <= %d", cyc_nb);
+  // 25 ... 42 atoms, dense columns, plain layout: the MFMA / fixed-atom-split kernel of assemble_perm2.hip
+  if (!d_jlist && !d_colmap && !use_E && cyc_W == 0 && assemble_perm2_applicable(ctx)) {
+    const int rc = assemble_perm2_launch(ctx, sig, j0, n_j, col0, K, ld, i_beg, i_end, lower ? 1 : 0, lam);
+    if (rc != GDML_ERR_UNSUPPORTED) return rc;
+  }
   PermArgs A;
   memset(&A, 0, sizeof(A));
   A.XF = ts.XF; A.GD = ts.GD; A.perm = ts.perm; A.pinv = ts.pinv;

@@ -1,0 +1,629 @@
+// Kernel-matrix assembly for molecules with a permutation group, 25 ... 42 atoms, dense column ranges (round 5).
+//
+// Reference: sgdml/train.py:97-302 (_assemble_kernel_mat_wkr), torchtools.py:110-392.  Math as in assemble_perm.hip:
+//   K_ij = sum_p [ beta_p v_p u_p^T + cn_p S_p ],   d_p = x_i - P_p x_j,   beta_p = 5 b_p,  cn_p = -(sig^2 + sig |d_p|') b_p
+//   for a column atom b and its partner m' (b != m'),  a' = pi^-1 b,  mi = pi^-1 m',  d = x_i(a', mi) - x_j(b, m'):
+//     |d_p|^2 += d^2,   u_p[b] += d G_j(b, m'),   v_p[a'] += d G_i(a', mi),   dg_p[b] += G_i(a', mi) (x) G_j(b, m')
+//   S_p[(a,.),(b,.)] = G_i(a, pi^-1 b) (x) G_j(b, pi a)  for pi a != b (the tables are 0 on their diagonals),  dg_p[b] for a = pi^-1 b.
+// assemble_perm_kernel runs this at 0.05 of HBM / 0.11 of the fp64 VALU model at N = 42, P = 27: 256-VGPR wavefronts, one
+// workgroup per CU, every operand of the 9 N^2 P outer-product and the 9 N^2 P single-term multiply-adds read from LDS.  Here:
+//   * atoms are renumbered, the ones NO permutation moves (F) first.  Descriptor entries between two such atoms contribute the
+//     same to every permutation: they are summed once per block (base pass: u0, v0, dg0, nn0), a permutation adds only the
+//     entries that touch a moved atom (configs[3]: 9 of 42 atoms move -> 0.38 of the entries);
+//   * ONE fused pass per permutation over the pairs (b, m') gives |d|^2, u, v and dg; lane = (permutation of the group of 8,
+//     slot), slot = (row b, chunk of the m' range): the loops are uniform, nothing is reduced across lanes except the chunks;
+//   * the outer products sum_p beta_p v_p u_p^T run on v_mfma_f64_16x16x4.  Tile rows / columns are relabelled so that a lane
+//     owns whole 3 x 3 atom blocks: a tile GROUP (s, t) = 16 row atoms x 16 column atoms, its 9 tiles = the (al, be)
+//     components; lane l: column atom 16 t + (l & 15), row atoms 16 s + (l >> 4) + 4 r (C layout: row (l >> 4) + 4 r).  The
+//     single terms are added to the same registers: per (row atom, column atom, permutation) two 24-byte LDS reads for 9
+//     multiply-adds -- and only in tile groups that contain a moved atom; tile groups of fixed atoms get them once with sum_p cn_p;
+//   * one workgroup = 9 wavefronts = the 3 x 3 tile groups of a (48 x 48)-atom block; it owns a column point j (its table
+//     stays in LDS) and walks over row points i; finished rows go through LDS so that every store writes whole rows.
+// Everything else (index lists, energy-constraint rows, block-cyclic layouts, other sizes) stays on assemble_perm_kernel.
+// Arithmetic pinned on the CPU: tools/perm2_emulate.py (run by the CPU test suite).
+#include "common.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int P2_NW = 9;
+constexpr int P2_T = 64 * P2_NW;
+constexpr int P2_MAXN = 42;  // LDS: two N x N x 32-byte tables + 8 permutations of V-phase results
+// LDS layout in doubles, fixed for the largest molecule (compile-time bases: no address registers held across the phases)
+constexpr int L_TI = 0, L_TJ = L_TI + 4 * P2_MAXN * P2_MAXN, L_U = L_TJ + 4 * P2_MAXN * P2_MAXN, L_V = L_U + 3 * P2_MAXN * 8,
+              L_DG = L_V + 3 * P2_MAXN * 8, L_B0 = L_DG + 9 * P2_MAXN * 8, L_NN = L_B0 + 16 * P2_MAXN, L_PERM = L_NN + 8 * P2_NW;
+
+// v from the lane with index (lane ^ 1), (lane ^ 2), (lane ^ 4), (lane ^ 8): DPP moves inside a row of 16 lanes, no LDS round trip.
+// (^ 4 as the mirror image inside 8 lanes: only for values that are already equal within each quad)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+#define P2_XOR1 0xB1       /* quad_perm [1,0,3,2] */
+#define P2_XOR2 0x4E       /* quad_perm [2,3,0,1] */
+#define P2_HALF_MIRROR 0x141
+#define P2_ROR8 0x128      /* row_ror:8 = lane ^ 8 */
+
+// exp out of line: inlined, its polynomial coefficients are hoisted out of the block loop into registers the kernel does not have
+// (they came back from scratch one by one, a serialised round trip each, every group of every block)
+__device__ __attribute__((noinline)) double p2_exp(double x) { return exp(x); }
+
+struct Perm2Args {
+  const double* TP;     // (M,N,N,4) packed per-point tables in internal numbering: [a][m] = (x(a,m), G(a,m))
+  const uint8_t* blob;  // plan: perm | pinv (internal numbering, bytes), src offsets, sigma, tasks
+  int o_src, o_sigma, o_tasks;
+  int n_tasks;
+  int64_t M;
+  int N, P, nF;
+  double sig;
+  int64_t j0, n_j, col0, i_beg, i_end;
+  int i_chunk;
+  int lower;
+  double lam;
+  double* K;
+  int64_t ld;
+  int l_task;  // LDS offset of the task descriptors in doubles (behind the byte permutation tables)
+  int dbg;  // timing-only ablation: 1 no stores, 2 no V tasks, 4 no single terms, 8 no MFMA, 16 no base pass, 32 no exp, 64 no diagonal terms,
+            // 128 no staging of the rows, 256 no image prefetch
+};
+
+__global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int N = A.N, N3 = 3 * N, NN = N * N, P = A.P, nF = A.nF;
+  double* const TI = smem + L_TI;  // [a][m] = (x_i(a,m), G_i(a,m))  internal numbering
+  double* const TJ = smem + L_TJ;
+  double* const U = smem + L_U;    // [3 b + be][8]
+  double* const V = smem + L_V;    // [3 a + al][8]
+  double* const DG = smem + L_DG;  // [9 b + k][8]
+  double* const ST = U;            // finished rows (aliases U | V | DG): [36][3N]
+  double* const B0 = smem + L_B0;  // [b][16]: u0 (3), v0 (3), dg0 (9), row part of nn0
+  double* const NNS = smem + L_NN; // [wavefront][8]
+  uint8_t* const permS = reinterpret_cast<uint8_t*>(smem + L_PERM);
+  uint8_t* const pinvS = permS + P * N;
+  uint32_t* const taskS = reinterpret_cast<uint32_t*>(smem + A.l_task);
+  const int32_t* const sigma_g = reinterpret_cast<const int32_t*>(A.blob + A.o_sigma);
+  int* const sigma = reinterpret_cast<int*>(smem + A.l_task + 2 * A.n_tasks);  // LDS copy: a global load between two row stores would wait for the stores
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t jv = blockIdx.x;
+  const int64_t jpt = A.j0 + jv;
+  const bool lower = A.lower != 0;
+  const int64_t i_lo = (lower ? jv : A.i_beg) + (int64_t)blockIdx.y * A.i_chunk;
+  const int64_t i_top = lower ? A.M : A.i_end;
+  const int64_t i_hi = (i_lo + A.i_chunk < i_top) ? i_lo + A.i_chunk : i_top;
+  if (i_lo >= i_hi) return;
+
+  const double sig = A.sig, inv_sig = 1.0 / sig;
+  const double sqrt5 = 2.23606797749978969641;
+  const double base_div = 5.0 / (3.0 * sig * sig * sig * sig);
+
+  // ---- resident tables
+  for (int e = tid; e < 2 * P * N; e += P2_T) permS[e] = A.blob[e];
+  for (int e = tid; e < N; e += P2_T) sigma[e] = sigma_g[e];
+  {
+    const uint32_t* tg = reinterpret_cast<const uint32_t*>(A.blob + A.o_tasks);
+    for (int e = tid; e < 4 * A.n_tasks; e += P2_T) taskS[e] = tg[e];
+  }
+  for (int e = tid; e < 15 * P2_MAXN * 8; e += P2_T) U[e] = 0.0;  // U | V | DG: lanes of a short last group read finite values
+  // a point's packed table (2 N^2 units of 16 bytes, already in internal order) straight into LDS: global_load_lds_dwordx4,
+  // lane-linear destination, no registers, no wait here -- the next __syncthreads() drains it
+  auto dma_table = [&](double* T, int64_t pt) {
+    const char* srcb = reinterpret_cast<const char*>(A.TP + pt * NN * 4);
+    char* dstb = reinterpret_cast<char*>(T);
+    for (int u0 = w * 64; u0 < 2 * NN; u0 += P2_T) {
+      const int u = u0 + lane;
+      if (u < 2 * NN)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcb + (int64_t)u * 16),
+                                         (__attribute__((address_space(3))) void*)(dstb + u0 * 16), 16, 0, 0);
+    }
+  };
+  dma_table(TJ, jpt);
+  dma_table(TI, i_lo);
+
+  // ---- the tile group (gs, gt) of this wavefront in the O phase.  What a lane derives from its index (column atom, row atoms)
+  // is recomputed inside each phase from an opaque copy of the index: kept alive across the phases these values (and the
+  // lane masks of their validity flags) push loop invariants of the inner loops out to scratch.
+  const int gs = w / 3, gt = w - 3 * gs;
+  const bool group_live = 16 * gs < N && 16 * gt < N;
+  const bool pureF = 16 * gs + 15 < nF && 16 * gt + 15 < nF;  // fixed atoms only: single terms once, with sum_p cn_p
+#define P2_LANE_CONSTS()                                                     \
+  int lane_o = lane;                                                         \
+  asm volatile("" : "+v"(lane_o));                                           \
+  const int g = lane_o >> 4, n = lane_o & 15;                                \
+  const int cb = 16 * gt + n;                                                \
+  const bool cb_ok = cb < N;                                                 \
+  const int cbc = cb_ok ? cb : N - 1;                                        \
+  int arc[4];                                                                \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                            \
+    const int a_ = 16 * gs + g + 4 * r;                                      \
+    arc[r] = (a_ < N) ? a_ : N - 1;                                          \
+  }
+
+  for (int64_t i = i_lo; i < i_hi; ++i) {
+    __syncthreads();  // image of point i (and the resident tables) visible; the previous block's staging is read
+    // ================= base pass: pairs of fixed atoms, once per block.  lane = (row of the task, m' mod 8)
+    double nn0 = 0.0;
+    if (nF > 0 && !(A.dbg & 16)) {
+      const int r8 = lane >> 3, c = lane & 7;
+      for (int t0 = w; 8 * t0 < nF; t0 += P2_NW) {
+        const int b = 8 * t0 + r8;
+        const bool ok = b < nF;
+        const int bc = ok ? b : 0;
+        const double* ti = TI + bc * N * 4;
+        const double* tj = TJ + bc * N * 4;
+        double s[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] = 0.0;
+        for (int m0 = 0; m0 < nF; m0 += 8) {
+          const int m = m0 + c;
+          const double lv = (ok && m < nF) ? 1.0 : 0.0;
+          const int mc = (m < nF) ? m : nF - 1;
+          const d4 a = *reinterpret_cast<const d4*>(ti + 4 * mc);
+          const d4 q = *reinterpret_cast<const d4*>(tj + 4 * mc);
+          const double d = (a.x - q.x) * lv;
+          const double g0 = a.y * lv, g1 = a.z * lv, g2 = a.w * lv;
+          s[15] += d * d;
+          s[0] += d * q.y; s[1] += d * q.z; s[2] += d * q.w;
+          s[3] += d * a.y; s[4] += d * a.z; s[5] += d * a.w;
+          s[6] += g0 * q.y; s[7] += g0 * q.z; s[8] += g0 * q.w;
+          s[9] += g1 * q.y; s[10] += g1 * q.z; s[11] += g1 * q.w;
+          s[12] += g2 * q.y; s[13] += g2 * q.z; s[14] += g2 * q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] += dpp_f64<P2_XOR1>(s[k]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] += dpp_f64<P2_XOR2>(s[k]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] += dpp_f64<P2_HALF_MIRROR>(s[k]);
+        if (ok && c == 0) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) B0[b * 16 + k] = s[k];
+        }
+      }
+      __syncthreads();
+      nn0 = wave_sum(lane < nF ? B0[lane * 16 + 15] : 0.0);
+    }
+
+    d4 acc[3][3];
+#pragma unroll
+    for (int al = 0; al < 3; ++al)
+#pragma unroll
+      for (int be = 0; be < 3; ++be) acc[al][be] = d4{0.0, 0.0, 0.0, 0.0};
+    double ctot = 0.0;
+
+    for (int g0 = 0; g0 < P; g0 += 8) {
+      const int npg = (P - g0 < 8) ? P - g0 : 8;
+      // ================= phase V: lane = (slot, permutation of the group)
+      {
+        const int pl = lane & 7, slot = lane >> 3;
+        const int p = g0 + (pl < npg ? pl : npg - 1);
+        const uint8_t* const pin = pinvS + p * N;
+        double nnl = 0.0;
+        for (int t = w; t < ((A.dbg & 2) ? 0 : A.n_tasks); t += P2_NW) {
+          const uint32_t d0 = taskS[4 * t], d1 = taskS[4 * t + 1], d2w = taskS[4 * t + 2];
+          const int mb = d2w & 0xff, me = (d2w >> 8) & 0xff, lg = (d2w >> 16) & 0xff;
+          const bool base = (d2w >> 24) != 0;
+          const int ri = slot >> lg, c = slot & ((1 << lg) - 1);
+          const unsigned long long rows = (unsigned long long)d0 | ((unsigned long long)d1 << 32);
+          const int rowb = (int)((rows >> (8 * ri)) & 0xff);
+          const bool act = rowb != 255 && pl < npg;
+          const int b = (rowb != 255) ? rowb : 0;
+          const int per = (me - mb + (1 << lg) - 1) >> lg;
+          const int m0 = mb + c * per;
+          const int m1 = (m0 + per < me) ? m0 + per : me;
+          const int ap = pin[b];
+          const double* ti = TI + ap * N * 4;
+          const double* tj = TJ + b * N * 4;
+          double nn = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0, v0 = 0.0, v1 = 0.0, v2 = 0.0;
+          double d00 = 0.0, d01 = 0.0, d02 = 0.0, d10 = 0.0, d11 = 0.0, d12 = 0.0, d20 = 0.0, d21 = 0.0, d22 = 0.0;
+          // two entries per trip: their four table reads are issued together, and the byte lookups of the NEXT two entries
+          // are requested before the multiply-adds (volatile: a plain load carried around the loop is moved back to its use)
+          typedef const volatile __attribute__((address_space(3))) uint8_t* lds_vbyte;
+          const lds_vbyte pinv_v = (lds_vbyte)pin;
+          auto mclamp = [&](int m) { return (m < N) ? m : N - 1; };
+          int miA = pinv_v[mclamp(m0)], miB = pinv_v[mclamp(m0 + 1)];
+#pragma unroll 1
+          for (int k = 0; k < per; k += 2) {
+            const int mA = m0 + k, mB = m0 + k + 1;
+            const d4 aA = *reinterpret_cast<const d4*>(ti + 4 * miA);
+            const d4 qA = *reinterpret_cast<const d4*>(tj + 4 * mclamp(mA));
+            const d4 aB = *reinterpret_cast<const d4*>(ti + 4 * miB);
+            const d4 qB = *reinterpret_cast<const d4*>(tj + 4 * mclamp(mB));
+            miA = pinv_v[mclamp(mA + 2)];
+            miB = pinv_v[mclamp(mB + 2)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const d4 a = t ? aB : aA, q = t ? qB : qA;
+              const double lv = (act && (t ? mB : mA) < m1) ? 1.0 : 0.0;  // multiplied, not branched on: the loop stays uniform
+              const double d = (a.x - q.x) * lv;
+              const double g0v = a.y * lv, g1v = a.z * lv, g2v = a.w * lv;
+              nn += d * d;
+              u0 += d * q.y; u1 += d * q.z; u2 += d * q.w;
+              v0 += d * a.y; v1 += d * a.z; v2 += d * a.w;
+              d00 += g0v * q.y; d01 += g0v * q.z; d02 += g0v * q.w;
+              d10 += g1v * q.y; d11 += g1v * q.z; d12 += g1v * q.w;
+              d20 += g2v * q.y; d21 += g2v * q.z; d22 += g2v * q.w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          nnl += nn;
+          if (lg > 0) {  // the chunks of a row sit in neighbouring slots: lane ^ 8 inside a row of 16 lanes
+            u0 += dpp_f64<P2_ROR8>(u0); u1 += dpp_f64<P2_ROR8>(u1); u2 += dpp_f64<P2_ROR8>(u2);
+            v0 += dpp_f64<P2_ROR8>(v0); v1 += dpp_f64<P2_ROR8>(v1); v2 += dpp_f64<P2_ROR8>(v2);
+            d00 += dpp_f64<P2_ROR8>(d00); d01 += dpp_f64<P2_ROR8>(d01); d02 += dpp_f64<P2_ROR8>(d02);
+            d10 += dpp_f64<P2_ROR8>(d10); d11 += dpp_f64<P2_ROR8>(d11); d12 += dpp_f64<P2_ROR8>(d12);
+            d20 += dpp_f64<P2_ROR8>(d20); d21 += dpp_f64<P2_ROR8>(d21); d22 += dpp_f64<P2_ROR8>(d22);
+          }
+          for (int s = 1; s < lg; ++s) {
+            const int off = 8 << s;
+            u0 += __shfl_xor(u0, off, 64); u1 += __shfl_xor(u1, off, 64); u2 += __shfl_xor(u2, off, 64);
+            v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64); v2 += __shfl_xor(v2, off, 64);
+            d00 += __shfl_xor(d00, off, 64); d01 += __shfl_xor(d01, off, 64); d02 += __shfl_xor(d02, off, 64);
+            d10 += __shfl_xor(d10, off, 64); d11 += __shfl_xor(d11, off, 64); d12 += __shfl_xor(d12, off, 64);
+            d20 += __shfl_xor(d20, off, 64); d21 += __shfl_xor(d21, off, 64); d22 += __shfl_xor(d22, off, 64);
+          }
+          if (act && c == 0) {
+            if (base) {  // fixed row: the permutation-independent part
+              const double* b0 = B0 + b * 16;
+              u0 += b0[0]; u1 += b0[1]; u2 += b0[2];
+              v0 += b0[3]; v1 += b0[4]; v2 += b0[5];
+              d00 += b0[6]; d01 += b0[7]; d02 += b0[8];
+              d10 += b0[9]; d11 += b0[10]; d12 += b0[11];
+              d20 += b0[12]; d21 += b0[13]; d22 += b0[14];
+            }
+            double* du = U + (3 * b) * 8 + pl;
+            du[0] = u0; du[8] = u1; du[16] = u2;
+            double* dv = V + (3 * ap) * 8 + pl;
+            dv[0] = v0; dv[8] = v1; dv[16] = v2;
+            double* dd = DG + (9 * b) * 8 + pl;
+            dd[0] = d00; dd[8] = d01; dd[16] = d02;
+            dd[24] = d10; dd[32] = d11; dd[40] = d12;
+            dd[48] = d20; dd[56] = d21; dd[64] = d22;
+          }
+        }
+        nnl += __shfl_xor(nnl, 8, 64);
+        nnl += __shfl_xor(nnl, 16, 64);
+        nnl += __shfl_xor(nnl, 32, 64);
+        if (lane < 8) NNS[w * 8 + lane] = nnl;
+      }
+      __syncthreads();
+      // ================= Matern scalars of the group (every wavefront for itself; lanes 0 .. 7 hold them)
+      double beta_v = 0.0, cn_v = 0.0;
+      {
+        double nn = nn0;
+        if (lane < 8) {
+#pragma unroll
+          for (int ww = 0; ww < P2_NW; ++ww) nn += NNS[ww * 8 + lane];
+        }
+        const double nrm = sqrt5 * sqrt(0.5 * nn);
+        const double ex = (A.dbg & 32) ? 1.0 : p2_exp(-nrm * inv_sig);
+        const double bp = ex * base_div;
+        if (lane < npg) {
+          beta_v = 5.0 * bp;
+          cn_v = -(sig * sig + sig * nrm) * bp;
+        }
+      }
+      // ================= phase O.  (No branch around a piece of code that updates the accumulators: at every such join the
+      // compiler keeps two copies of the 72 accumulator registers alive and spills; the optional parts are loops whose trip
+      // count is zero instead.)
+      {
+        P2_LANE_CONSTS();
+        const int arow = 16 * gs + n;  // row atom of the A operand
+        const bool arow_ok = arow < N;
+        const int arowc = arow_ok ? arow : N - 1;
+        auto cn_of = [&](int pl) -> double {  // lane pl's value, wave-uniform: through scalar registers
+          const long long bb = __builtin_bit_cast(long long, cn_v);
+          const int lo = __builtin_amdgcn_readlane((int)bb, pl), hi = __builtin_amdgcn_readlane((int)(bb >> 32), pl);
+          return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+        };
+        for (int pl = 0; pl < npg; ++pl) ctot += cn_of(pl);
+        // ---- single terms; the byte lookups of permutation pl + 1 are requested before the multiply-adds of permutation pl
+        {
+          const int n_sgl = (pureF || !group_live || (A.dbg & 4)) ? 0 : npg;
+          const uint8_t* pr = permS + g0 * N;
+          const uint8_t* pin = pinvS + g0 * N;
+          int ap_n = pin[cbc], pa_n0 = pr[arc[0]], pa_n1 = pr[arc[1]], pa_n2 = pr[arc[2]], pa_n3 = pr[arc[3]];
+#pragma unroll 1
+          for (int pl = 0; pl < n_sgl; ++pl) {
+            const int ap = ap_n;
+            const int pa[4] = {pa_n0, pa_n1, pa_n2, pa_n3};
+            const int adv = (pl + 1 < npg) ? N : 0;
+            pr += adv;
+            pin += adv;
+            ap_n = pin[cbc];
+            pa_n0 = pr[arc[0]]; pa_n1 = pr[arc[1]]; pa_n2 = pr[arc[2]]; pa_n3 = pr[arc[3]];
+            const double cn = cn_of(pl);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // two row atoms per batch of loads
+              double a0[2], q0[2];
+              d2 a12[2], q12[2];
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const int r = 2 * h + t;
+                const double* gi = TI + (arc[r] * N + ap) * 4;
+                const double* gj = TJ + (cbc * N + pa[r]) * 4;
+                a0[t] = gi[1];
+                a12[t] = *reinterpret_cast<const d2*>(gi + 2);
+                q0[t] = gj[1];
+                q12[t] = *reinterpret_cast<const d2*>(gj + 2);
+              }
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const int r = 2 * h + t;
+                const double w0 = cn * q0[t], w1 = cn * q12[t].x, w2 = cn * q12[t].y;
+                acc[0][0][r] += a0[t] * w0; acc[0][1][r] += a0[t] * w1; acc[0][2][r] += a0[t] * w2;
+                acc[1][0][r] += a12[t].x * w0; acc[1][1][r] += a12[t].x * w1; acc[1][2][r] += a12[t].x * w2;
+                acc[2][0][r] += a12[t].y * w0; acc[2][1][r] += a12[t].y * w1; acc[2][2][r] += a12[t].y * w2;
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        // ---- the row atom pi^-1 b of this lane's column atom gets cn dg_p[b], if it is one of the lane's four.  The target
+        // register of every permutation of the group (or none) is packed into one word first; the loop then has no LDS lookup
+        // in front of its weights, its reads do not depend on anything, two permutations are in flight.  Branch-free inside
+        // (the weight is cn in the matching register, 0 in the others); wavefronts without any such lane in the whole group
+        // (off-diagonal tile groups of fixed atoms) run zero iterations.
+        {
+          unsigned tgt = 0;  // 4 bits per permutation: 1 << r of the matching register
+          for (int pl = 0; pl < npg; ++pl) {
+            const int rr = (int)pinvS[(g0 + pl) * N + cbc] - 16 * gs - g;
+            const bool m = cb_ok && rr >= 0 && rr < 16 && (rr & 3) == 0;
+            tgt |= m ? (1u << (4 * pl + (rr >> 2))) : 0u;
+          }
+          const int n_dg = (__builtin_amdgcn_ballot_w64(tgt != 0) != 0 && !(A.dbg & 64)) ? npg : 0;
+          const double* dgb = DG + (9 * cbc) * 8;
+#pragma unroll 2
+          for (int pl = 0; pl < n_dg; ++pl) {
+            double x[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) x[k] = dgb[8 * k + pl];
+            const double cn = cn_of(pl);
+            const unsigned t4 = tgt >> (4 * pl);
+            double mw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mw[r] = ((t4 >> r) & 1u) ? cn : 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[k / 3][k % 3][r] += mw[r] * x[k];
+          }
+        }
+        // ---- the outer products last: the MFMAs are issued and the wavefront goes on to the barrier and the next V phase
+        // (which does not touch the accumulators) while they run
+        const int nks = (A.dbg & 8) ? 0 : ((npg > 4) ? 2 : 1);
+        for (int ks = 0; ks < nks; ++ks) {
+          const int plk = 4 * ks + g;
+          const double bk = __shfl(beta_v, plk, 64);
+          double av[3], bv[3];
+#pragma unroll
+          for (int al = 0; al < 3; ++al) {
+            const double x = V[(3 * arowc + al) * 8 + plk];
+            av[al] = arow_ok ? bk * x : 0.0;
+          }
+#pragma unroll
+          for (int be = 0; be < 3; ++be) {
+            const double x = U[(3 * cbc + be) * 8 + plk];
+            bv[be] = cb_ok ? x : 0.0;
+          }
+#pragma unroll
+          for (int al = 0; al < 3; ++al)
+#pragma unroll
+            for (int be = 0; be < 3; ++be) acc[al][be] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[al], bv[be], acc[al][be], 0, 0, 0);
+        }
+      }
+      __syncthreads();  // the V-phase results of this group are free
+    }
+    P2_LANE_CONSTS();
+    {  // tile groups of fixed atoms only: the single terms of all permutations at once (weight 0 elsewhere)
+      const double cw = (pureF && !(A.dbg & 4)) ? ctot : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* gi = TI + (arc[r] * N + cbc) * 4;
+        const double* gj = TJ + (cbc * N + arc[r]) * 4;
+        const double a0 = gi[1];
+        const d2 a12 = *reinterpret_cast<const d2*>(gi + 2);
+        const double q0 = gj[1];
+        const d2 q12 = *reinterpret_cast<const d2*>(gj + 2);
+        const double w0 = cw * q0, w1 = cw * q12.x, w2 = cw * q12.y;
+        acc[0][0][r] += a0 * w0; acc[0][1][r] += a0 * w1; acc[0][2][r] += a0 * w2;
+        acc[1][0][r] += a12.x * w0; acc[1][1][r] += a12.x * w1; acc[1][2][r] += a12.x * w2;
+        acc[2][0][r] += a12.y * w0; acc[2][1][r] += a12.y * w1; acc[2][2][r] += a12.y * w2;
+      }
+    }
+
+    // ================= rows out: four passes (register r of every lane = 12 row atoms = 36 rows) through LDS
+    const int sig_b = sigma[cbc];
+    const int64_t i_next = (i + 1 < i_hi) ? i + 1 : i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (r > 0) __syncthreads();  // the previous pass is stored
+      if (group_live && cb_ok && 16 * gs + g + 4 * r < N && !(A.dbg & 128)) {
+        double* dst = ST + ((gs * 4 + g) * 3) * N3 + 3 * sig_b;
+#pragma unroll
+        for (int al = 0; al < 3; ++al)
+#pragma unroll
+          for (int be = 0; be < 3; ++be) dst[al * N3 + be] = lower ? -acc[al][be][r] : acc[al][be][r];
+      }
+      __syncthreads();
+      if (r == 0 && !(A.dbg & 256)) dma_table(TI, i_next);  // every wavefront is past its last read of the current image
+      if (!(A.dbg & 1)) {
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+          const int rsl = 4 * w + k;  // 0 .. 35
+          const int ra = rsl / 3, al = rsl - 3 * ra;
+          const int a = 16 * (ra >> 2) + (ra & 3) + 4 * r;
+          if (a < N) {
+            const int orow = 3 * sigma[a] + al;
+            const int64_t grow = i * N3 + orow;
+            double* dstg = A.K + (grow - A.i_beg * N3) * A.ld + A.col0 + jv * N3;
+            const int64_t dcol = grow - (A.col0 + jv * N3);  // where the matrix diagonal crosses this row segment
+            // 3N <= 126: two stores per lane, both values read first
+            const int c1 = lane + 64;
+            const bool ok1 = c1 < N3;
+            double o0 = ST[rsl * N3 + lane];
+            double o1 = ST[rsl * N3 + (ok1 ? c1 : lane)];
+            if (lower && lane == dcol) o0 += A.lam;
+            if (lower && c1 == dcol) o1 += A.lam;
+            dstg[lane] = o0;
+            if (ok1) dstg[c1] = o1;
+          }
+        }
+      }
+    }
+  }
+}
+
+int build_dense_tables(gdml_ctx* ctx);
+
+// TP[pt][e] = (x, G) of the dense tables' entry src[e]: the per-point tables in internal numbering, one 32-byte entry per ordered pair
+__global__ void __launch_bounds__(256) perm2_pack_kernel(const double* __restrict__ XF, const double* __restrict__ GD,
+                                                         const int32_t* __restrict__ src, int64_t M, int NN, double* __restrict__ TP) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * NN) return;
+  const int64_t pt = t / NN;
+  const int e = (int)(t - pt * NN);
+  const int64_t so = pt * NN + src[e];
+  d4 v;
+  v.x = XF[so];
+  v.y = GD[so * 3];
+  v.z = GD[so * 3 + 1];
+  v.w = GD[so * 3 + 2];
+  *reinterpret_cast<d4*>(TP + t * 4) = v;
+}
+
+bool assemble_perm2_applicable(const gdml_ctx* ctx) {
+  const TrainSet& ts = ctx->ts;
+  if (!ctx_opt_i(ctx, "asm.perm2", 1)) return false;
+  return ts.P >= 2 && ts.N >= ctx_opt_i(ctx, "asm.perm2_min_n", 25) && ts.N <= P2_MAXN;
+}
+
+// Plan of the group: internal numbering (fixed atoms first), permutations in it, V-phase tasks.  Built once per training set.
+static int perm2_plan(gdml_ctx* ctx) {
+  TrainSet& ts = ctx->ts;
+  if (ts.p2) return GDML_OK;
+  const int N = ts.N, P = ts.P;
+  std::vector<int> moved(N, 0);
+  for (int p = 0; p < P; ++p)
+    for (int a = 0; a < N; ++a)
+      if (ts.h_perm[(size_t)p * N + a] != a) moved[a] = 1;
+  std::vector<int32_t> sigma;
+  for (int a = 0; a < N; ++a)
+    if (!moved[a]) sigma.push_back(a);
+  int nF = (int)sigma.size();
+  if (nF < 2 || !ctx_opt_i(ctx, "asm.perm2_split", 1)) {  // no split: natural order
+    nF = 0;
+    sigma.clear();
+    for (int a = 0; a < N; ++a) sigma.push_back(a);
+  } else {
+    for (int a = 0; a < N; ++a)
+      if (moved[a]) sigma.push_back(a);
+  }
+  std::vector<int32_t> inv(N);
+  for (int a = 0; a < N; ++a) inv[sigma[a]] = a;
+  std::vector<uint8_t> blob((size_t)2 * P * N);
+  for (int p = 0; p < P; ++p)
+    for (int a = 0; a < N; ++a) {
+      const int pa = inv[ts.h_perm[(size_t)p * N + sigma[a]]];
+      blob[(size_t)p * N + a] = (uint8_t)pa;
+      blob[(size_t)(P + p) * N + pa] = (uint8_t)a;
+    }
+  // tasks: rows of E (all partners), then rows of F (partners in E); chunks so that a lane walks <= ~12 entries
+  struct Task { uint8_t rows[8]; uint8_t mb, me, lg, base; uint32_t pad; };
+  static_assert(sizeof(Task) == 16, "task descriptor");
+  std::vector<Task> tasks;
+  auto add_rows = [&](int b0, int b1, int mb, int me, int base) {
+    if (b1 <= b0 || me <= mb) return;
+    int lg = 0;
+    while (lg < 3 && ((me - mb + (1 << lg) - 1) >> lg) > ctx_opt_i(ctx, "asm.perm2_chunk", 24)) ++lg;
+    const int rows_per = 8 >> lg;
+    for (int b = b0; b < b1; b += rows_per) {
+      Task t;
+      memset(&t, 0, sizeof(t));
+      for (int k = 0; k < 8; ++k) t.rows[k] = (k < rows_per && b + k < b1) ? (uint8_t)(b + k) : (uint8_t)255;
+      t.mb = (uint8_t)mb; t.me = (uint8_t)me; t.lg = (uint8_t)lg; t.base = (uint8_t)base;
+      tasks.push_back(t);
+    }
+  };
+  add_rows(nF, N, 0, N, 0);
+  add_rows(0, nF, nF, N, 1);
+  auto align_to = [&](size_t al) { while (blob.size() % al) blob.push_back(0); };
+  align_to(16);
+  ts.p2_o[0] = (int)blob.size();  // src
+  {
+    std::vector<int32_t> srcv((size_t)N * N);  // internal entry (a, m)  <-  dense entry (sigma m, sigma a) = G(sigma a, sigma m)
+    for (int a = 0; a < N; ++a)
+      for (int m = 0; m < N; ++m) srcv[(size_t)a * N + m] = sigma[m] * N + sigma[a];
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(srcv.data());
+    blob.insert(blob.end(), b, b + srcv.size() * 4);
+  }
+  align_to(16);
+  ts.p2_o[1] = (int)blob.size();  // sigma
+  {
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(sigma.data());
+    blob.insert(blob.end(), b, b + sigma.size() * 4);
+  }
+  align_to(16);
+  ts.p2_o[2] = (int)blob.size();  // tasks
+  {
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(tasks.data());
+    blob.insert(blob.end(), b, b + tasks.size() * sizeof(Task));
+  }
+  ts.p2_nF = nF;
+  ts.p2_ntasks = (int)tasks.size();
+  GDML_TRY(ctx_alloc(ctx, (void**)&ts.p2, (int64_t)blob.size()));
+  HIP_CHECK(ctx, hipMemcpyAsync(ts.p2, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the host vector goes out of scope
+  // the packed per-point tables (32 N^2 bytes per point)
+  const int64_t NN = (int64_t)N * N;
+  GDML_TRY(ctx_alloc(ctx, (void**)&ts.p2_TP, ts.M * NN * 32));
+  hipLaunchKernelGGL(perm2_pack_kernel, dim3(ceil_div(ts.M * NN, 256)), dim3(256), 0, ctx->stream, ts.XF, ts.GD,
+                     reinterpret_cast<const int32_t*>(ts.p2 + ts.p2_o[0]), ts.M, (int)NN, ts.p2_TP);
+  ctx->launch_counter++;
+  HIP_CHECK(ctx, hipGetLastError());
+  return GDML_OK;
+}
+
+// Column points [j0, j0 + n_j) written at col0 + 3N v, row points [i_beg, i_end); lower: A = -K + lam I, blocks j <= i.
+int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg,
+                          int64_t i_end, int lower, double lam) {
+  TrainSet& ts = ctx->ts;
+  if (n_j <= 0 || i_end <= i_beg) return GDML_OK;
+  GDML_TRY(build_dense_tables(ctx));
+  GDML_TRY(perm2_plan(ctx));
+  const int N = ts.N, P = ts.P;
+  Perm2Args A;
+  memset(&A, 0, sizeof(A));
+  A.TP = ts.p2_TP; A.blob = ts.p2;
+  A.o_src = ts.p2_o[0]; A.o_sigma = ts.p2_o[1]; A.o_tasks = ts.p2_o[2];
+  A.n_tasks = ts.p2_ntasks;
+  A.M = ts.M; A.N = N; A.P = P; A.nF = ts.p2_nF; A.sig = sig;
+  A.j0 = j0; A.n_j = n_j; A.col0 = col0; A.i_beg = i_beg; A.i_end = i_end;
+  A.lower = lower; A.lam = lam; A.K = K; A.ld = ld;
+  A.dbg = ctx_opt_i(ctx, "asm.perm2_debug", 0);
+  int o = L_PERM;
+  o += (2 * P * N + 7) / 8;
+  A.l_task = o; o += 2 * ts.p2_ntasks;
+  o += (N + 1) / 2;  // sigma
+  const size_t lds = (size_t)o * 8;
+  if (lds > (size_t)160 * 1024) return GDML_ERR_UNSUPPORTED;  // (many permutations: the byte tables) -- the general kernel
+  const int64_t n_i = i_end - i_beg;
+  int i_chunk = ctx_opt_i(ctx, "asm.perm2_i_chunk", 16);
+  if (i_chunk < 1) i_chunk = 1;
+  while (i_chunk > 2 && n_j * ((n_i + i_chunk - 1) / i_chunk) < 1024) i_chunk >>= 1;
+  A.i_chunk = i_chunk;
+  dim3 grid((unsigned)n_j, (unsigned)((n_i + i_chunk - 1) / i_chunk));
+  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int slot = ktime_begin(ctx);
+  hipLaunchKernelGGL(assemble_perm2_kernel, grid, dim3(P2_T), lds, ctx->stream, A);
+  const double blocks = lower ? 0.5 * (double)n_i * (double)(n_i + 1) : (double)n_i * (double)n_j;
+  ktime_end(ctx, slot, "assemble", 8.0 * blocks * 9.0 * N * N);
+  ctx->launch_counter++;
+  HIP_CHECK(ctx, hipGetLastError());
+  return GDML_OK;
+}

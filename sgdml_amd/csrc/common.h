@@ -53,6 +53,9 @@ struct TrainSet {
   double* XF = nullptr;      // (M,N,N)   dense x[pair(b,m)] table, m-major (assemble_wave.hip)
   double* GD = nullptr;      // (M,N,N,3) dense G(b,m) table, m-major
   double* TS = nullptr;      // (M,pitch) packed per-point image [GD | XF | x | 0-pad] staged by assemble_strip.hip
+  uint8_t* p2 = nullptr;     // plan of assemble_perm2.hip (internal atom numbering, byte permutations, V-phase tasks)
+  double* p2_TP = nullptr;   // (M,N,N,4) packed per-point tables in that numbering
+  int p2_o[3] = {0, 0, 0}, p2_nF = 0, p2_ntasks = 0;
   std::vector<int32_t> h_tp, h_perm, h_pinv;
 };
 
@@ -264,6 +267,9 @@ bool assemble_strip_applicable(const gdml_ctx* ctx);
 int assemble_strip_launch(gdml_ctx* ctx, double sig, double* K, int64_t ld, int lower, double lam);
 int assemble_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int64_t ld, int cyc_W, int cyc_rank,
                            int cyc_nb);
+bool assemble_perm2_applicable(const gdml_ctx* ctx);
+int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg,
+                          int64_t i_end, int lower, double lam);
 int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist, const int32_t* d_colmap, int64_t j0,
                          int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg, int64_t i_end, int lower, double lam,
                          int cyc_W, int cyc_rank, int cyc_nb, const int32_t* h_colmap = nullptr);

@@ -170,6 +170,10 @@ extern "C" int gdml_train_upload(gdml_ctx* ctx, const double* R_desc, const doub
   GDML_TRY(ctx_free(ctx, ts.XF));
   GDML_TRY(ctx_free(ctx, ts.GD));
   GDML_TRY(ctx_free(ctx, ts.TS));
+  GDML_TRY(ctx_free(ctx, ts.p2));
+  GDML_TRY(ctx_free(ctx, ts.p2_TP));
+  ts.p2 = nullptr;
+  ts.p2_TP = nullptr;
   ts.XF = ts.GD = ts.TS = nullptr;
   ts.x = ts.g = nullptr;
   ts.tp = ts.perm = ts.pinv = nullptr;

@@ -211,3 +211,25 @@ def test_planned_perm_assembly_data_flow_matches_the_oracle():
     perms = np.array([[0, 1, 2, 3, 4, 5, 6, 7], [1, 2, 0, 3, 4, 5, 6, 7], [2, 0, 1, 3, 4, 5, 6, 7],
                       [0, 1, 2, 4, 3, 5, 6, 7], [1, 2, 0, 4, 3, 5, 6, 7], [2, 0, 1, 4, 3, 5, 6, 7]])
     assert check(8, perms, strip=[7, 0, 3, 4, 1]) <= 1e-14
+
+
+def test_perm2_kernel_data_flow_matches_the_oracle():
+    """The arithmetic csrc/assemble_perm2.hip was written against (tools/perm2_emulate.py): atoms renumbered with the ones no
+    permutation moves first, their mutual descriptor entries summed once per block, one fused pass per permutation over the
+    entries that touch a moved atom (chunked rows, fixed-order partial sums), outer products per tile group, single terms per
+    permutation only where a moved atom is involved -- and the variant that sums the single / diagonal terms of fixed atoms once
+    per block through W[x][y] = sum of c_p over the permutations with pi_p x = y.  Against the oracle's K (train.py:165-232)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from perm2_emulate import check, plan
+
+    # two rotors in the middle of a 20-atom molecule: 6 moved atoms, 14 fixed ones; 16 x 16 tile groups: (0, 0) is not all-fixed
+    idt = np.arange(20)
+    def rot(a):
+        p = idt.copy(); p[[a, a + 1, a + 2]] = [a + 1, a + 2, a]; return p
+    r1, r2 = rot(4), rot(11)
+    perms = np.array([idt, r1, r1[r1], r2, r2[r1], r2[r1[r1]], r2[r2], r2[r2][r1], r2[r2][r1[r1]]])
+    sigma, nF, permI, pinvI = plan(perms)
+    assert nF == 14 and sorted(sigma[nF:]) == [4, 5, 6, 11, 12, 13]
+    for kw in [{}, {'split': False}, {'nchk_e': 2}, {'post': True}]:
+        assert check(20, perms, **kw) <= 1e-14, kw
