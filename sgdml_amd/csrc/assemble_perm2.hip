@@ -22,6 +22,7 @@
 // Everything else (index lists, energy-constraint rows, block-cyclic layouts, other sizes) stays on assemble_perm_kernel.
 // Arithmetic pinned on the CPU: tools/perm2_emulate.py (run by the CPU test suite).
 #include "common.h"
+#include <type_traits>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -66,6 +67,8 @@ struct Perm2Args {
   double* K;
   int64_t ld;
   int l_task;  // LDS offset of the task descriptors in doubles (behind the byte permutation tables)
+  int l_cn;    // ... of cn_p of all permutations (post mode)
+  int post, nE;  // single / diagonal terms of fixed atoms once per block (nE = moved atoms <= 16)
   int dbg;  // timing-only ablation: 1 no stores, 2 no V tasks, 4 no single terms, 8 no MFMA, 16 no base pass, 32 no exp, 64 no diagonal terms,
             // 128 no staging of the rows, 256 no image prefetch
 };
@@ -83,6 +86,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   double* const NNS = smem + L_NN; // [wavefront][8]
   uint8_t* const permS = reinterpret_cast<uint8_t*>(smem + L_PERM);
   uint8_t* const pinvS = permS + P * N;
+  double* const CN = smem + A.l_cn;
   uint32_t* const taskS = reinterpret_cast<uint32_t*>(smem + A.l_task);
   const int32_t* const sigma_g = reinterpret_cast<const int32_t*>(A.blob + A.o_sigma);
   int* const sigma = reinterpret_cast<int*>(smem + A.l_task + 2 * A.n_tasks);  // LDS copy: a global load between two row stores would wait for the stores
@@ -226,6 +230,8 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
           const lds_vbyte pinv_v = (lds_vbyte)pin;
           auto mclamp = [&](int m) { return (m < N) ? m : N - 1; };
           int miA = pinv_v[mclamp(m0)], miB = pinv_v[mclamp(m0 + 1)];
+          auto vloop = [&](auto DGc) {
+            constexpr bool WITH_DG = decltype(DGc)::value;
 #pragma unroll 1
           for (int k = 0; k < per; k += 2) {
             const int mA = m0 + k, mB = m0 + k + 1;
@@ -245,12 +251,18 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
               nn += d * d;
               u0 += d * q.y; u1 += d * q.z; u2 += d * q.w;
               v0 += d * a.y; v1 += d * a.z; v2 += d * a.w;
-              d00 += g0v * q.y; d01 += g0v * q.z; d02 += g0v * q.w;
-              d10 += g1v * q.y; d11 += g1v * q.z; d12 += g1v * q.w;
-              d20 += g2v * q.y; d21 += g2v * q.z; d22 += g2v * q.w;
+              if (WITH_DG) {
+                d00 += g0v * q.y; d01 += g0v * q.z; d02 += g0v * q.w;
+                d10 += g1v * q.y; d11 += g1v * q.z; d12 += g1v * q.w;
+                d20 += g2v * q.y; d21 += g2v * q.z; d22 += g2v * q.w;
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
           }
+          };
+          // post mode: the diagonal terms of fixed rows come out of the once-per-block pass
+          if (base && A.post) vloop(std::false_type{});
+          else vloop(std::true_type{});
           nnl += nn;
           if (lg > 0) {  // the chunks of a row sit in neighbouring slots: lane ^ 8 inside a row of 16 lanes
             u0 += dpp_f64<P2_ROR8>(u0); u1 += dpp_f64<P2_ROR8>(u1); u2 += dpp_f64<P2_ROR8>(u2);
@@ -308,6 +320,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
           cn_v = -(sig * sig + sig * nrm) * bp;
         }
       }
+      if (w == 0 && lane < npg) CN[g0 + lane] = cn_v;
       // ================= phase O.  (No branch around a piece of code that updates the accumulators: at every such join the
       // compiler keeps two copies of the 72 accumulator registers alive and spills; the optional parts are loops whose trip
       // count is zero instead.)
@@ -324,7 +337,12 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         for (int pl = 0; pl < npg; ++pl) ctot += cn_of(pl);
         // ---- single terms; the byte lookups of permutation pl + 1 are requested before the multiply-adds of permutation pl
         {
-          const int n_sgl = (pureF || !group_live || (A.dbg & 4)) ? 0 : npg;
+          // post mode: only blocks of two MOVED atoms per permutation (everything else once per block, below)
+          const bool ee_wave = group_live && 16 * gs + 15 >= nF && 16 * gt + 15 >= nF;
+          const int n_sgl = (A.dbg & 4) ? 0 : (A.post ? (ee_wave ? npg : 0) : ((pureF || !group_live) ? 0 : npg));
+          double wr[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wr[r] = (!A.post || (arc[r] >= nF && cbc >= nF)) ? 1.0 : 0.0;
           const uint8_t* pr = permS + g0 * N;
           const uint8_t* pin = pinvS + g0 * N;
           int ap_n = pin[cbc], pa_n0 = pr[arc[0]], pa_n1 = pr[arc[1]], pa_n2 = pr[arc[2]], pa_n3 = pr[arc[3]];
@@ -355,7 +373,8 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
 #pragma unroll
               for (int t = 0; t < 2; ++t) {
                 const int r = 2 * h + t;
-                const double w0 = cn * q0[t], w1 = cn * q12[t].x, w2 = cn * q12[t].y;
+                const double cnr = cn * wr[r];
+                const double w0 = cnr * q0[t], w1 = cnr * q12[t].x, w2 = cnr * q12[t].y;
                 acc[0][0][r] += a0[t] * w0; acc[0][1][r] += a0[t] * w1; acc[0][2][r] += a0[t] * w2;
                 acc[1][0][r] += a12[t].x * w0; acc[1][1][r] += a12[t].x * w1; acc[1][2][r] += a12[t].x * w2;
                 acc[2][0][r] += a12[t].y * w0; acc[2][1][r] += a12[t].y * w1; acc[2][2][r] += a12[t].y * w2;
@@ -373,7 +392,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
           unsigned tgt = 0;  // 4 bits per permutation: 1 << r of the matching register
           for (int pl = 0; pl < npg; ++pl) {
             const int rr = (int)pinvS[(g0 + pl) * N + cbc] - 16 * gs - g;
-            const bool m = cb_ok && rr >= 0 && rr < 16 && (rr & 3) == 0;
+            const bool m = cb_ok && (!A.post || cb >= nF) && rr >= 0 && rr < 16 && (rr & 3) == 0;
             tgt |= m ? (1u << (4 * pl + (rr >> 2))) : 0u;
           }
           const int n_dg = (__builtin_amdgcn_ballot_w64(tgt != 0) != 0 && !(A.dbg & 64)) ? npg : 0;
@@ -419,23 +438,123 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
       }
       __syncthreads();  // the V-phase results of this group are free
     }
+    // ================= once per block (post mode): everything a fixed atom is involved in, summed over the permutations first.
+    //   A1(a, e) = sum_p cn_p G_i(a, pi_p^-1 e),  B1(a, e) = sum_p cn_p G_j(a, pi_p e)      a fixed, e moved
+    //   single terms:   fixed x fixed  ctot G_i(a,b) (x) G_j(b,a);   fixed x moved  A1(a,b) (x) G_j(b,a);   moved x fixed  G_i(a,b) (x) B1(b,a)
+    //   diagonal term of a fixed atom:  ctot dg0[a] + sum_e A1(a, e) (x) G_j(a, e)
+    // 16 lanes per fixed atom (one per moved atom), 36 atoms per round; tables in the (now free) V-phase buffers, entries
+    // laid out like the table entries (pad, 3 values) so that the consumers read either with the same instructions.
+    double* const A1S = U;
+    double* const B1S = A1S + nF * A.nE * 4;
+    double* const FDS = B1S + nF * A.nE * 4;
+    if (A.post) {
+      const int ei = lane & 15, rs = tid >> 4, nE = A.nE;
+      // W[x][y] = sum of cn_p over the permutations with pi_p x = y (x, y moved): A1(a, e) = sum_e' G_i(a, e') W[e'][e],
+      // B1(a, e) = sum_e' G_j(a, e') W[e][e'] -- nE uniform steps without byte lookups instead of P gathers per lane
+      double* const WS = FDS + ((9 * nF + 1) & ~1);
+      for (int t = tid; t < nE * nE; t += P2_T) {
+        const int x = nF + t / nE, y = nF + t - (t / nE) * nE;
+        double wv = 0.0;
+#pragma unroll 9
+        for (int p = 0; p < P; ++p) wv += ((int)permS[p * N + x] == y) ? CN[p] : 0.0;
+        WS[t] = wv;
+      }
+      __syncthreads();
+      for (int ab = 0; ab < nF; ab += P2_T / 16) {
+        const int a = ab + rs;
+        const bool ok = a < nF && ei < nE;
+        const int ac = (a < nF) ? a : 0;
+        const int eic = (ei < nE) ? ei : 0;
+        const int e = nF + eic;
+        const double* tia = TI + (ac * N + nF) * 4;
+        const double* tja = TJ + (ac * N + nF) * 4;
+        double s10 = 0.0, s11 = 0.0, s12 = 0.0, s20 = 0.0, s21 = 0.0, s22 = 0.0;
+#pragma unroll 3
+        for (int e2 = 0; e2 < nE; ++e2) {
+          const double w1 = WS[e2 * nE + eic], w2 = WS[eic * nE + e2];
+          const double* gi = tia + 4 * e2;
+          const double* gj = tja + 4 * e2;
+          const double a0 = gi[1];
+          const d2 a12 = *reinterpret_cast<const d2*>(gi + 2);
+          const double q0 = gj[1];
+          const d2 q12 = *reinterpret_cast<const d2*>(gj + 2);
+          s10 += w1 * a0; s11 += w1 * a12.x; s12 += w1 * a12.y;
+          s20 += w2 * q0; s21 += w2 * q12.x; s22 += w2 * q12.y;
+        }
+        const double* tja0 = TJ + ac * N * 4;
+        const double* gje = tja0 + 4 * e;
+        const double okv = ok ? 1.0 : 0.0;
+        const double e0 = gje[1] * okv;
+        const d2 e12 = *reinterpret_cast<const d2*>(gje + 2);
+        const double e1 = e12.x * okv, e2 = e12.y * okv;
+        double fd[9] = {s10 * e0, s10 * e1, s10 * e2, s11 * e0, s11 * e1, s11 * e2, s12 * e0, s12 * e1, s12 * e2};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fd[k] += dpp_f64<P2_XOR1>(fd[k]);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fd[k] += dpp_f64<P2_XOR2>(fd[k]);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fd[k] += dpp_f64<P2_HALF_MIRROR>(fd[k]);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fd[k] += dpp_f64<P2_ROR8>(fd[k]);
+        if (ok) {
+          double* da = A1S + (a * nE + ei) * 4;
+          da[1] = s10; da[2] = s11; da[3] = s12;
+          double* db = B1S + (a * nE + ei) * 4;
+          db[1] = s20; db[2] = s21; db[3] = s22;
+        }
+        if (a < nF && ei == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) FDS[a * 9 + k] = fd[k] + ctot * B0[a * 16 + 6 + k];
+        }
+      }
+      __syncthreads();
+    }
     P2_LANE_CONSTS();
-    {  // tile groups of fixed atoms only: the single terms of all permutations at once (weight 0 elsewhere)
-      const double cw = (pureF && !(A.dbg & 4)) ? ctot : 0.0;
+    {  // the once-per-block single terms of this lane's four atom blocks (no post mode: tile groups of fixed atoms only, ctot)
+      const bool fb = cbc < nF;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double* gi = TI + (arc[r] * N + cbc) * 4;
-        const double* gj = TJ + (cbc * N + arc[r]) * 4;
+        const int a = arc[r];
+        const bool fa = a < nF;
+        const double* gi = TI + (a * N + cbc) * 4;
+        const double* gj = TJ + (cbc * N + a) * 4;
+        double scale = pureF ? ctot : 0.0;
+        if (A.post) {
+          gi = (fa && !fb) ? A1S + (a * A.nE + (cbc - nF)) * 4 : gi;
+          gj = (!fa && fb) ? B1S + (cbc * A.nE + (a - nF)) * 4 : gj;
+          scale = (fa && fb) ? ctot : ((!fa && !fb) ? 0.0 : 1.0);
+        }
+        if (A.dbg & 4) scale = 0.0;
         const double a0 = gi[1];
         const d2 a12 = *reinterpret_cast<const d2*>(gi + 2);
         const double q0 = gj[1];
         const d2 q12 = *reinterpret_cast<const d2*>(gj + 2);
-        const double w0 = cw * q0, w1 = cw * q12.x, w2 = cw * q12.y;
+        const double w0 = scale * q0, w1 = scale * q12.x, w2 = scale * q12.y;
         acc[0][0][r] += a0 * w0; acc[0][1][r] += a0 * w1; acc[0][2][r] += a0 * w2;
         acc[1][0][r] += a12.x * w0; acc[1][1][r] += a12.x * w1; acc[1][2][r] += a12.x * w2;
         acc[2][0][r] += a12.y * w0; acc[2][1][r] += a12.y * w1; acc[2][2][r] += a12.y * w2;
       }
+      // diagonal terms of fixed atoms (post mode): the lane that holds the block (b, b)
+      double mw[4];
+      bool anyd = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool m = A.post && cb_ok && fb && arc[r] == cbc && !(A.dbg & 64);
+        mw[r] = m ? 1.0 : 0.0;
+        anyd |= m;
+      }
+      const int n_fd = (__builtin_amdgcn_ballot_w64(anyd) != 0) ? 1 : 0;
+      for (int it = 0; it < n_fd; ++it) {
+        const double* fdp = FDS + (fb ? cbc : 0) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const double x = fdp[k];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[k / 3][k % 3][r] += mw[r] * x;
+        }
+      }
     }
+    if (A.post) __syncthreads();  // the tables are read: the staging below overwrites them
 
     // ================= rows out: four passes (register r of every lane = 12 row atoms = 36 rows) through LDS
     const int sig_b = sigma[cbc];
@@ -500,7 +619,10 @@ __global__ void __launch_bounds__(256) perm2_pack_kernel(const double* __restric
 bool assemble_perm2_applicable(const gdml_ctx* ctx) {
   const TrainSet& ts = ctx->ts;
   if (!ctx_opt_i(ctx, "asm.perm2", 1)) return false;
-  return ts.P >= 2 && ts.N >= ctx_opt_i(ctx, "asm.perm2_min_n", 25) && ts.N <= P2_MAXN;
+  // Measured (profiles/r05_assemble_perm2.txt): the per-block cost of this kernel is nearly independent of N and P (17 barriers
+  // and a dozen short dependent LDS chains per block and group with one workgroup of 9 wavefronts per CU), so it only wins where
+  // assemble_perm_kernel's N^2 P work is largest: N = 42, P = 27 1.36-1.45x; N = 36, P = 27 0.94x; P = 6 0.5-0.75x.
+  return ts.P >= ctx_opt_i(ctx, "asm.perm2_min_p", 16) && ts.N >= ctx_opt_i(ctx, "asm.perm2_min_n", 40) && ts.N <= P2_MAXN;
 }
 
 // Plan of the group: internal numbering (fixed atoms first), permutations in it, V-phase tasks.  Built once per training set.
@@ -610,6 +732,10 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
   o += (2 * P * N + 7) / 8;
   A.l_task = o; o += 2 * ts.p2_ntasks;
   o += (N + 1) / 2;  // sigma
+  A.l_cn = o; o += P;
+  A.nE = N - ts.p2_nF;
+  // post mode: 16 lanes per fixed atom in the once-per-block pass, its tables in the V-phase buffers
+  A.post = (ts.p2_nF >= 2 && A.nE <= 16 && 8 * ts.p2_nF * A.nE + 9 * ts.p2_nF + 1 + A.nE * A.nE <= 15 * P2_MAXN * 8 && ctx_opt_i(ctx, "asm.perm2_post", 1)) ? 1 : 0;
   const size_t lds = (size_t)o * 8;
   if (lds > (size_t)160 * 1024) return GDML_ERR_UNSUPPORTED;  // (many permutations: the byte tables) -- the general kernel
   const int64_t n_i = i_end - i_beg;

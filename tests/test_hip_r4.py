@@ -82,7 +82,19 @@ OPTION_SETS = [{}, {'asm.perm_level': 0}, {'asm.perm_level': 1}, {'asm.perm_leve
 @pytest.mark.parametrize('kind', ['id', 'c3xc2', 'c3^3'])
 @pytest.mark.parametrize('N', [24, 42, 65, 100])
 def test_assemble_perm_mode_matrix(N, kind):
-    _check_assembly_modes(N, M_OF_N[N], kind, OPTION_SETS)
+    # assemble_perm_kernel itself (asm.perm2 = 0: N = 42, P = 27 would otherwise go to assemble_perm2_kernel) + the default dispatch
+    _check_assembly_modes(N, M_OF_N[N], kind, [{}] + [dict(o, **{'asm.perm2': 0}) for o in OPTION_SETS])
+
+
+@pytest.mark.parametrize('N,kind', [(26, 'c3xc2'), (33, 'c2xc2'), (36, 'c3^3'), (42, 'c3^3'), (42, 'c3xc2'), (25, 'c3^3')])
+def test_assemble_perm2_mode_matrix(N, kind):
+    """csrc/assemble_perm2.hip (fp64-MFMA outer products, fixed-atom split, once-per-block single / diagonal terms of fixed atoms)
+    forced on every size it supports (by default it only takes N >= 40, P >= 16, where it is faster): the dense modes (full, lower,
+    point ranges) run on it, the others on assemble_perm_kernel; without the split, without the once-per-block pass, short and
+    unchunked rows, two row points per workgroup.  1e-12 of max|K| against the independent restatement (train.py:97-302)."""
+    force = {'asm.perm2_min_n': 25, 'asm.perm2_min_p': 2}
+    sets = [{}, {'asm.perm2_split': 0}, {'asm.perm2_post': 0}, {'asm.perm2_chunk': 5}, {'asm.perm2_chunk': 100}, {'asm.perm2_i_chunk': 2}]
+    _check_assembly_modes(N, 4 if N < 30 else 3, kind, [dict(o, **force) for o in sets])
 
 
 @pytest.mark.parametrize('N,kind', [(130, 'c3xc2'), (150, 'id'), (172, 'id'), (172, 'c3xc2')])

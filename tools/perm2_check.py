@@ -8,7 +8,17 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from asm_perm_check import check_case, time_case  # noqa: E402
+from asm_perm_check import check_case as _cc, time_case as _tc  # noqa: E402
+
+FORCE = {'asm.perm2_min_n': 25, 'asm.perm2_min_p': 2}   # by default the kernel only takes N >= 40, P >= 16
+
+
+def check_case(N, M, kind, opts):
+    return _cc(N, M, kind, dict(FORCE, **opts))
+
+
+def time_case(N, M, kind, opts, **kw):
+    return _tc(N, M, kind, dict(FORCE, **opts), **kw)
 
 
 def do_check():
@@ -17,7 +27,7 @@ def do_check():
                        (42, 11, 'c3xc2')]:
         ok &= check_case(N, M, kind, {})
     for N, M, kind in [(36, 3, 'c3^3'), (42, 3, 'c3^3')]:
-        for opts in [{'asm.perm2_split': 0}, {'asm.perm2_chunk': 5}, {'asm.perm2_chunk': 100}, {'asm.perm2_i_chunk': 2}, {'asm.perm2': 0}]:
+        for opts in [{'asm.perm2_split': 0}, {'asm.perm2_post': 0}, {'asm.perm2_chunk': 5}, {'asm.perm2_chunk': 100}, {'asm.perm2_i_chunk': 2}, {'asm.perm2': 0}]:
             ok &= check_case(N, M, kind, opts)
     print('ALL OK' if ok else 'SOME FAILED')
     return ok
@@ -25,16 +35,14 @@ def do_check():
 
 def do_time(full):
     for lower in (False, True):
-        for opts in [{'asm.perm2': 0}, {}, {'asm.perm2_split': 0}]:
+        for opts in [{'asm.perm2': 0}, {}, {'asm.perm2_post': 0}, {'asm.perm2_split': 0}]:
             time_case(42, 300, 'c3^3', opts, lower=lower, label='perm2')
     for opts in [{'asm.perm2_debug': 1}, {'asm.perm2_debug': 2}, {'asm.perm2_debug': 4}, {'asm.perm2_debug': 8}, {'asm.perm2_debug': 15},
-                 {'asm.perm2_debug': 15 + 16}, {'asm.perm2_debug': 15 + 32}, {'asm.perm2_debug': 15 + 64}, {'asm.perm2_debug': 15 + 128},
-                 {'asm.perm2_debug': 15 + 256}, {'asm.perm2_debug': 511}, {'asm.perm2_chunk': 12}]:
+                 {'asm.perm2_debug': 15 + 64}, {'asm.perm2_debug': 511}]:
         time_case(42, 300, 'c3^3', opts, label='perm2')
-    time_case(42, 300, 'c3xc2', {'asm.perm2': 0}, label='perm2')
-    time_case(42, 300, 'c3xc2', {}, label='perm2')
-    time_case(30, 400, 'c3xc2', {'asm.perm2': 0}, label='perm2')
-    time_case(30, 400, 'c3xc2', {}, label='perm2')
+    for N, M, kind in [(42, 300, 'c3xc2'), (30, 400, 'c3xc2'), (36, 350, 'c3^3')]:
+        time_case(N, M, kind, {'asm.perm2': 0}, label='perm2')
+        time_case(N, M, kind, {}, label='perm2')
     if full:
         for opts in [{'asm.perm2': 0}, {}]:
             time_case(42, 1000, 'c3^3', opts, lower=True, reps=3, label='perm2')
