@@ -111,11 +111,12 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *                         full-line stores, row points per workgroup
  *   asm.perm_compact (1)  index-list columns: strips of the REQUESTED column atoms instead of all atoms of every point touched
  *   asm.perm_lds_rows (1) permutation entries from the LDS copy for 64 < N <= 128 (always beyond 128 atoms); 0 = two lane-held rows (A/B)
- *   asm.perm2 (1)         molecules with a permutation group of at least asm.perm2_min_p (16) elements, asm.perm2_min_n (40) <= N <= 42,
- *                         dense column ranges (where it beats the general kernel: 1.4x at N = 42, P = 27): outer products on
+ *   asm.perm2 (1)         molecules with a permutation group of at least asm.perm2_min_p (6) elements, asm.perm2_min_n (36) <= N <= 42
+ *                         (groups below 16 elements: from 4 atoms more), dense column ranges -- where it beats the general kernel
+ *                         (1.8x at N = 42, P = 27): outer products on
  *                         the fp64 MFMA pipe, contributions of atom pairs no permutation moves summed once per block
  *                         (csrc/assemble_perm2.hip); asm.perm2_split (1; 0 = every pair per permutation), asm.perm2_post (1: single and diagonal
- *                         terms that involve an atom no permutation moves summed over the permutations once per block; 0 = per permutation), asm.perm2_chunk (24) pair
+ *                         terms that involve an atom no permutation moves summed over the permutations once per block; 0 = per permutation), asm.perm2_chunk (12) pair
  *                         entries per lane and task, asm.perm2_i_chunk (16) row points per workgroup, asm.perm2_debug (0)
  *                         timing-only ablation mask (results are wrong when set)
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)

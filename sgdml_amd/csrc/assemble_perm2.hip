@@ -22,6 +22,7 @@
 // Everything else (index lists, energy-constraint rows, block-cyclic layouts, other sizes) stays on assemble_perm_kernel.
 // Arithmetic pinned on the CPU: tools/perm2_emulate.py (run by the CPU test suite).
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -52,6 +53,10 @@ __device__ __forceinline__ double dpp_f64(double v) {
 // (they came back from scratch one by one, a serialised round trip each, every group of every block)
 __device__ __attribute__((noinline)) double p2_exp(double x) { return exp(x); }
 
+// Barrier between phases that only exchange LDS data: wait for this wavefront's LDS operations, not for its global stores
+// (__syncthreads() carries a vmcnt(0): in the row passes every barrier waited for the rows just stored to reach memory)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct Perm2Args {
   const double* TP;     // (M,N,N,4) packed per-point tables in internal numbering: [a][m] = (x(a,m), G(a,m))
   const uint8_t* blob;  // plan: perm | pinv (internal numbering, bytes), src offsets, sigma, tasks
@@ -69,10 +74,12 @@ struct Perm2Args {
   int l_task;  // LDS offset of the task descriptors in doubles (behind the byte permutation tables)
   int l_cn;    // ... of cn_p of all permutations (post mode)
   int post, nE;  // single / diagonal terms of fixed atoms once per block (nE = moved atoms <= 16)
+  unsigned long long* trace;  // asm.perm2_debug & 1024: shader-clock stamps of one workgroup's phases (tools/perm2_check.py trace)
   int dbg;  // timing-only ablation: 1 no stores, 2 no V tasks, 4 no single terms, 8 no MFMA, 16 no base pass, 32 no exp, 64 no diagonal terms,
             // 128 no staging of the rows, 256 no image prefetch
 };
 
+template <bool TRACE>
 __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = A.N, N3 = 3 * N, NN = N * N, P = A.P, nF = A.nF;
@@ -89,7 +96,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   double* const CN = smem + A.l_cn;
   uint32_t* const taskS = reinterpret_cast<uint32_t*>(smem + A.l_task);
   const int32_t* const sigma_g = reinterpret_cast<const int32_t*>(A.blob + A.o_sigma);
-  int* const sigma = reinterpret_cast<int*>(smem + A.l_task + 2 * A.n_tasks);  // LDS copy: a global load between two row stores would wait for the stores
+  int* const sigma = reinterpret_cast<int*>(smem + A.l_task + 2 * A.n_tasks + 2);  // LDS copy: a global load between two row stores would wait for the stores
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,6 +108,16 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   const int64_t i_hi = (i_lo + A.i_chunk < i_top) ? i_lo + A.i_chunk : i_top;
   if (i_lo >= i_hi) return;
 
+  // phase stamps of one workgroup (wavefront 0, blocks 2 and 3 of its walk): id, clock
+  const bool tracing = TRACE && A.trace != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0;
+  int trace_n = 0;
+  auto stamp = [&](int id, int64_t blk) {
+    if (TRACE && tracing && blk - i_lo >= 2 && blk - i_lo < 4 && trace_n < 250) {
+      A.trace[2 * trace_n] = (unsigned long long)id;
+      A.trace[2 * trace_n + 1] = __builtin_amdgcn_s_memtime();
+      ++trace_n;
+    }
+  };
   const double sig = A.sig, inv_sig = 1.0 / sig;
   const double sqrt5 = 2.23606797749978969641;
   const double base_div = 5.0 / (3.0 * sig * sig * sig * sig);
@@ -110,7 +127,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   for (int e = tid; e < N; e += P2_T) sigma[e] = sigma_g[e];
   {
     const uint32_t* tg = reinterpret_cast<const uint32_t*>(A.blob + A.o_tasks);
-    for (int e = tid; e < 4 * A.n_tasks; e += P2_T) taskS[e] = tg[e];
+    for (int e = tid; e < 4 * A.n_tasks + 4; e += P2_T) taskS[e] = tg[e];  // + 16 bytes: first task of every wavefront
   }
   for (int e = tid; e < 15 * P2_MAXN * 8; e += P2_T) U[e] = 0.0;  // U | V | DG: lanes of a short last group read finite values
   // a point's packed table (2 N^2 units of 16 bytes, already in internal order) straight into LDS: global_load_lds_dwordx4,
@@ -134,6 +151,12 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   const int gs = w / 3, gt = w - 3 * gs;
   const bool group_live = 16 * gs < N && 16 * gt < N;
   const bool pureF = 16 * gs + 15 < nF && 16 * gt + 15 < nF;  // fixed atoms only: single terms once, with sum_p cn_p
+// a fresh, opaque copy of the lane / thread index: what a phase derives from it (LDS addresses above all) is then not hoisted out
+// of the group / block loops into registers that live across every other phase (they ended up in scratch, and a scratch reload
+// between two global stores waits for the stores)
+#define P2_FRESH(name, expr) \
+  int name = (expr);         \
+  asm volatile("" : "+v"(name))
 #define P2_LANE_CONSTS()                                                     \
   int lane_o = lane;                                                         \
   asm volatile("" : "+v"(lane_o));                                           \
@@ -147,12 +170,69 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
     arc[r] = (a_ < N) ? a_ : N - 1;                                          \
   }
 
+  // ---- single terms cn_p G_i(a, pi^-1 b) (x) G_j(b, pi a) of this lane's four atom blocks for n_its permutations from gfirst
+  // (cnvec: lane pl holds cn of permutation gfirst + pl).  The byte lookups of permutation pl + 1 are requested before the
+  // multiply-adds of permutation pl.  Post mode: only blocks of two MOVED atoms (weight 0 elsewhere).
+  const bool ee_wave = group_live && 16 * gs + 15 >= nF && 16 * gt + 15 >= nF;  // tile group with moved rows and moved columns
+  auto run_singles = [&](d4 (&acc)[3][3], const int (&arc)[4], int cbc, int gfirst, int n_its, int npg_g, double cnvec) {
+    if (A.dbg & 4) n_its = 0;
+    double wr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wr[r] = (!A.post || (arc[r] >= nF && cbc >= nF)) ? 1.0 : 0.0;
+    const uint8_t* pr = permS + gfirst * N;
+    const uint8_t* pin = pinvS + gfirst * N;
+    int ap_n = pin[cbc], pa_n0 = pr[arc[0]], pa_n1 = pr[arc[1]], pa_n2 = pr[arc[2]], pa_n3 = pr[arc[3]];
+#pragma unroll 1
+    for (int pl = 0; pl < n_its; ++pl) {
+      const int ap = ap_n;
+      const int pa[4] = {pa_n0, pa_n1, pa_n2, pa_n3};
+      const int adv = (pl + 1 < npg_g) ? N : 0;
+      pr += adv;
+      pin += adv;
+      ap_n = pin[cbc];
+      pa_n0 = pr[arc[0]]; pa_n1 = pr[arc[1]]; pa_n2 = pr[arc[2]]; pa_n3 = pr[arc[3]];
+      double cn;
+      {
+        const long long bb = __builtin_bit_cast(long long, cnvec);
+        const int lo = __builtin_amdgcn_readlane((int)bb, pl), hi = __builtin_amdgcn_readlane((int)(bb >> 32), pl);
+        cn = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // two row atoms per batch of loads
+        double a0[2], q0[2];
+        d2 a12[2], q12[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int r = 2 * h + t;
+          const double* gi = TI + (arc[r] * N + ap) * 4;
+          const double* gj = TJ + (cbc * N + pa[r]) * 4;
+          a0[t] = gi[1];
+          a12[t] = *reinterpret_cast<const d2*>(gi + 2);
+          q0[t] = gj[1];
+          q12[t] = *reinterpret_cast<const d2*>(gj + 2);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int r = 2 * h + t;
+          const double cnr = cn * wr[r];
+          const double w0 = cnr * q0[t], w1 = cnr * q12[t].x, w2 = cnr * q12[t].y;
+          acc[0][0][r] += a0[t] * w0; acc[0][1][r] += a0[t] * w1; acc[0][2][r] += a0[t] * w2;
+          acc[1][0][r] += a12[t].x * w0; acc[1][1][r] += a12[t].x * w1; acc[1][2][r] += a12[t].x * w2;
+          acc[2][0][r] += a12[t].y * w0; acc[2][1][r] += a12[t].y * w1; acc[2][2][r] += a12[t].y * w2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
   for (int64_t i = i_lo; i < i_hi; ++i) {
     __syncthreads();  // image of point i (and the resident tables) visible; the previous block's staging is read
+    stamp(0, i);
     // ================= base pass: pairs of fixed atoms, once per block.  lane = (row of the task, m' mod 8)
     double nn0 = 0.0;
     if (nF > 0 && !(A.dbg & 16)) {
-      const int r8 = lane >> 3, c = lane & 7;
+      P2_FRESH(lane_b, threadIdx.x & 63);
+      const int r8 = lane_b >> 3, c = lane_b & 7;
       for (int t0 = w; 8 * t0 < nF; t0 += P2_NW) {
         const int b = 8 * t0 + r8;
         const bool ok = b < nF;
@@ -189,26 +269,37 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         }
       }
       __syncthreads();
-      nn0 = wave_sum(lane < nF ? B0[lane * 16 + 15] : 0.0);
+      nn0 = wave_sum(lane_b < nF ? B0[lane_b * 16 + 15] : 0.0);
     }
+    stamp(1, i);
 
     d4 acc[3][3];
 #pragma unroll
     for (int al = 0; al < 3; ++al)
 #pragma unroll
       for (int be = 0; be < 3; ++be) acc[al][be] = d4{0.0, 0.0, 0.0, 0.0};
-    double ctot = 0.0;
+    double ctot = 0.0, cn_prev = 0.0;
 
     for (int g0 = 0; g0 < P; g0 += 8) {
       const int npg = (P - g0 < 8) ? P - g0 : 8;
+      {  // post mode: the single terms of the PREVIOUS group on the wavefront with moved rows and moved columns (zero
+         // iterations on the others), while the rest of the workgroup is in this group's V phase
+        P2_LANE_CONSTS();
+        const bool go = A.post && ee_wave && g0 > 0;
+        run_singles(acc, arc, cbc, go ? g0 - 8 : 0, go ? 8 : 0, 8, cn_prev);
+      }
       // ================= phase V: lane = (slot, permutation of the group)
       {
-        const int pl = lane & 7, slot = lane >> 3;
+        P2_FRESH(lane_v, threadIdx.x & 63);
+        const int pl = lane_v & 7, slot = lane_v >> 3;
         const int p = g0 + (pl < npg ? pl : npg - 1);
         const uint8_t* const pin = pinvS + p * N;
         double nnl = 0.0;
-        for (int t = w; t < ((A.dbg & 2) ? 0 : A.n_tasks); t += P2_NW) {
-          const uint32_t d0 = taskS[4 * t], d1 = taskS[4 * t + 1], d2w = taskS[4 * t + 2];
+        const uint8_t* const wt_off = reinterpret_cast<const uint8_t*>(taskS + 4 * A.n_tasks);  // tasks are stored wavefront by wavefront
+        const int t_end = (A.dbg & 2) ? 0 : __builtin_amdgcn_readfirstlane((int)wt_off[w + 1]);
+        for (int t = __builtin_amdgcn_readfirstlane((int)wt_off[w]); t < t_end; ++t) {
+          const uint32_t d0 = __builtin_amdgcn_readfirstlane(taskS[4 * t]), d1 = __builtin_amdgcn_readfirstlane(taskS[4 * t + 1]),
+                         d2w = __builtin_amdgcn_readfirstlane(taskS[4 * t + 2]);  // wave-uniform: scalar registers
           const int mb = d2w & 0xff, me = (d2w >> 8) & 0xff, lg = (d2w >> 16) & 0xff;
           const bool base = (d2w >> 24) != 0;
           const int ri = slot >> lg, c = slot & ((1 << lg) - 1);
@@ -301,16 +392,22 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         nnl += __shfl_xor(nnl, 8, 64);
         nnl += __shfl_xor(nnl, 16, 64);
         nnl += __shfl_xor(nnl, 32, 64);
-        if (lane < 8) NNS[w * 8 + lane] = nnl;
+        if (lane_v < 8) NNS[w * 8 + lane_v] = nnl;
       }
+      stamp(2, i);
       __syncthreads();
+      stamp(3, i);
       // ================= Matern scalars of the group (every wavefront for itself; lanes 0 .. 7 hold them)
       double beta_v = 0.0, cn_v = 0.0;
       {
         double nn = nn0;
-        if (lane < 8) {
+        {
+          double pn[P2_NW];
+          P2_FRESH(lane_s, threadIdx.x & 63);
 #pragma unroll
-          for (int ww = 0; ww < P2_NW; ++ww) nn += NNS[ww * 8 + lane];
+          for (int ww = 0; ww < P2_NW; ++ww) pn[ww] = NNS[ww * 8 + (lane_s & 7)];
+#pragma unroll
+          for (int ww = 0; ww < P2_NW; ++ww) nn += pn[ww];
         }
         const double nrm = sqrt5 * sqrt(0.5 * nn);
         const double ex = (A.dbg & 32) ? 1.0 : p2_exp(-nrm * inv_sig);
@@ -321,6 +418,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         }
       }
       if (w == 0 && lane < npg) CN[g0 + lane] = cn_v;
+      stamp(4, i);
       // ================= phase O.  (No branch around a piece of code that updates the accumulators: at every such join the
       // compiler keeps two copies of the 72 accumulator registers alive and spills; the optional parts are loops whose trip
       // count is zero instead.)
@@ -335,54 +433,10 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
           return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
         };
         for (int pl = 0; pl < npg; ++pl) ctot += cn_of(pl);
-        // ---- single terms; the byte lookups of permutation pl + 1 are requested before the multiply-adds of permutation pl
-        {
-          // post mode: only blocks of two MOVED atoms per permutation (everything else once per block, below)
-          const bool ee_wave = group_live && 16 * gs + 15 >= nF && 16 * gt + 15 >= nF;
-          const int n_sgl = (A.dbg & 4) ? 0 : (A.post ? (ee_wave ? npg : 0) : ((pureF || !group_live) ? 0 : npg));
-          double wr[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) wr[r] = (!A.post || (arc[r] >= nF && cbc >= nF)) ? 1.0 : 0.0;
-          const uint8_t* pr = permS + g0 * N;
-          const uint8_t* pin = pinvS + g0 * N;
-          int ap_n = pin[cbc], pa_n0 = pr[arc[0]], pa_n1 = pr[arc[1]], pa_n2 = pr[arc[2]], pa_n3 = pr[arc[3]];
-#pragma unroll 1
-          for (int pl = 0; pl < n_sgl; ++pl) {
-            const int ap = ap_n;
-            const int pa[4] = {pa_n0, pa_n1, pa_n2, pa_n3};
-            const int adv = (pl + 1 < npg) ? N : 0;
-            pr += adv;
-            pin += adv;
-            ap_n = pin[cbc];
-            pa_n0 = pr[arc[0]]; pa_n1 = pr[arc[1]]; pa_n2 = pr[arc[2]]; pa_n3 = pr[arc[3]];
-            const double cn = cn_of(pl);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {  // two row atoms per batch of loads
-              double a0[2], q0[2];
-              d2 a12[2], q12[2];
-#pragma unroll
-              for (int t = 0; t < 2; ++t) {
-                const int r = 2 * h + t;
-                const double* gi = TI + (arc[r] * N + ap) * 4;
-                const double* gj = TJ + (cbc * N + pa[r]) * 4;
-                a0[t] = gi[1];
-                a12[t] = *reinterpret_cast<const d2*>(gi + 2);
-                q0[t] = gj[1];
-                q12[t] = *reinterpret_cast<const d2*>(gj + 2);
-              }
-#pragma unroll
-              for (int t = 0; t < 2; ++t) {
-                const int r = 2 * h + t;
-                const double cnr = cn * wr[r];
-                const double w0 = cnr * q0[t], w1 = cnr * q12[t].x, w2 = cnr * q12[t].y;
-                acc[0][0][r] += a0[t] * w0; acc[0][1][r] += a0[t] * w1; acc[0][2][r] += a0[t] * w2;
-                acc[1][0][r] += a12[t].x * w0; acc[1][1][r] += a12[t].x * w1; acc[1][2][r] += a12[t].x * w2;
-                acc[2][0][r] += a12[t].y * w0; acc[2][1][r] += a12[t].y * w1; acc[2][2][r] += a12[t].y * w2;
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
+        // ---- single terms of this group (post mode: none here -- the one wavefront that has any runs them while the others
+        // are in the NEXT group's V phase, see the top of the group loop)
+        run_singles(acc, arc, cbc, g0, A.post ? 0 : ((pureF || !group_live) ? 0 : npg), npg, cn_v);
+        stamp(5, i);
         // ---- the row atom pi^-1 b of this lane's column atom gets cn dg_p[b], if it is one of the lane's four.  The target
         // register of every permutation of the group (or none) is packed into one word first; the loop then has no LDS lookup
         // in front of its weights, its reads do not depend on anything, two permutations are in flight.  Branch-free inside
@@ -390,10 +444,14 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         // (off-diagonal tile groups of fixed atoms) run zero iterations.
         {
           unsigned tgt = 0;  // 4 bits per permutation: 1 << r of the matching register
-          for (int pl = 0; pl < npg; ++pl) {
-            const int rr = (int)pinvS[(g0 + pl) * N + cbc] - 16 * gs - g;
-            const bool m = cb_ok && (!A.post || cb >= nF) && rr >= 0 && rr < 16 && (rr & 3) == 0;
-            tgt |= m ? (1u << (4 * pl + (rr >> 2))) : 0u;
+          int apv[8];
+#pragma unroll
+          for (int pl = 0; pl < 8; ++pl) apv[pl] = pinvS[(g0 + (pl < npg ? pl : npg - 1)) * N + cbc];  // eight lookups in flight together
+#pragma unroll
+          for (int pl = 0; pl < 8; ++pl) {  // (bitwise, not short-circuit: no branch around a lookup)
+            const int rr = apv[pl] - 16 * gs - g;
+            const bool m = (pl < npg) & cb_ok & ((A.post == 0) | (cb >= nF)) & (rr >= 0) & (rr < 16) & ((rr & 3) == 0);
+            tgt |= m ? (1u << (4 * pl + ((rr >> 2) & 3))) : 0u;
           }
           const int n_dg = (__builtin_amdgcn_ballot_w64(tgt != 0) != 0 && !(A.dbg & 64)) ? npg : 0;
           const double* dgb = DG + (9 * cbc) * 8;
@@ -413,6 +471,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
               for (int r = 0; r < 4; ++r) acc[k / 3][k % 3][r] += mw[r] * x[k];
           }
         }
+        stamp(6, i);
         // ---- the outer products last: the MFMAs are issued and the wavefront goes on to the barrier and the next V phase
         // (which does not touch the accumulators) while they run
         const int nks = (A.dbg & 8) ? 0 : ((npg > 4) ? 2 : 1);
@@ -436,7 +495,15 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
             for (int be = 0; be < 3; ++be) acc[al][be] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[al], bv[be], acc[al][be], 0, 0, 0);
         }
       }
+      cn_prev = cn_v;
+      stamp(7, i);
       __syncthreads();  // the V-phase results of this group are free
+      stamp(8, i);
+    }
+    {  // post mode: single terms of the last group
+      P2_LANE_CONSTS();
+      const int g_last = ((P - 1) / 8) * 8;
+      run_singles(acc, arc, cbc, g_last, (A.post && ee_wave) ? P - g_last : 0, P - g_last, cn_prev);
     }
     // ================= once per block (post mode): everything a fixed atom is involved in, summed over the permutations first.
     //   A1(a, e) = sum_p cn_p G_i(a, pi_p^-1 e),  B1(a, e) = sum_p cn_p G_j(a, pi_p e)      a fixed, e moved
@@ -448,15 +515,26 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
     double* const B1S = A1S + nF * A.nE * 4;
     double* const FDS = B1S + nF * A.nE * 4;
     if (A.post) {
-      const int ei = lane & 15, rs = tid >> 4, nE = A.nE;
+      P2_FRESH(tid_p, threadIdx.x);
+      const int ei = tid_p & 15, rs = tid_p >> 4, nE = A.nE;
       // W[x][y] = sum of cn_p over the permutations with pi_p x = y (x, y moved): A1(a, e) = sum_e' G_i(a, e') W[e'][e],
       // B1(a, e) = sum_e' G_j(a, e') W[e][e'] -- nE uniform steps without byte lookups instead of P gathers per lane
       double* const WS = FDS + ((9 * nF + 1) & ~1);
-      for (int t = tid; t < nE * nE; t += P2_T) {
+      for (int t = tid_p; t < nE * nE; t += P2_T) {
         const int x = nF + t / nE, y = nF + t - (t / nE) * nE;
         double wv = 0.0;
-#pragma unroll 9
-        for (int p = 0; p < P; ++p) wv += ((int)permS[p * N + x] == y) ? CN[p] : 0.0;
+        for (int p0 = 0; p0 < P; p0 += 9) {  // nine lookups and nine cn_p in flight together
+          int by[9];
+          double cv[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const int p = (p0 + k < P) ? p0 + k : P - 1;
+            by[k] = permS[p * N + x];
+            cv[k] = CN[p];
+          }
+#pragma unroll
+          for (int k = 0; k < 9; ++k) wv += ((p0 + k < P) & (by[k] == y)) ? cv[k] : 0.0;
+        }
         WS[t] = wv;
       }
       __syncthreads();
@@ -503,12 +581,16 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
           db[1] = s20; db[2] = s21; db[3] = s22;
         }
         if (a < nF && ei == 0) {
+          double g0v[9];
 #pragma unroll
-          for (int k = 0; k < 9; ++k) FDS[a * 9 + k] = fd[k] + ctot * B0[a * 16 + 6 + k];
+          for (int k = 0; k < 9; ++k) g0v[k] = B0[a * 16 + 6 + k];  // (all nine in flight: a read-add-write per k is nine round trips)
+#pragma unroll
+          for (int k = 0; k < 9; ++k) FDS[a * 9 + k] = fd[k] + ctot * g0v[k];
         }
       }
       __syncthreads();
     }
+    stamp(9, i);
     P2_LANE_CONSTS();
     {  // the once-per-block single terms of this lane's four atom blocks (no post mode: tile groups of fixed atoms only, ctot)
       const bool fb = cbc < nF;
@@ -546,22 +628,25 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
       const int n_fd = (__builtin_amdgcn_ballot_w64(anyd) != 0) ? 1 : 0;
       for (int it = 0; it < n_fd; ++it) {
         const double* fdp = FDS + (fb ? cbc : 0) * 9;
+        double x[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const double x = fdp[k];
+        for (int k = 0; k < 9; ++k) x[k] = fdp[k];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[k / 3][k % 3][r] += mw[r] * x;
-        }
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[k / 3][k % 3][r] += mw[r] * x[k];
       }
     }
+    stamp(10, i);
     if (A.post) __syncthreads();  // the tables are read: the staging below overwrites them
+    stamp(11, i);
 
     // ================= rows out: four passes (register r of every lane = 12 row atoms = 36 rows) through LDS
     const int sig_b = sigma[cbc];
     const int64_t i_next = (i + 1 < i_hi) ? i + 1 : i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (r > 0) __syncthreads();  // the previous pass is stored
+      if (r > 0) lds_barrier();  // the previous pass is read out of the staging buffer (its stores may still be on their way)
       if (group_live && cb_ok && 16 * gs + g + 4 * r < N && !(A.dbg & 128)) {
         double* dst = ST + ((gs * 4 + g) * 3) * N3 + 3 * sig_b;
 #pragma unroll
@@ -569,31 +654,46 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
 #pragma unroll
           for (int be = 0; be < 3; ++be) dst[al * N3 + be] = lower ? -acc[al][be][r] : acc[al][be][r];
       }
-      __syncthreads();
+      lds_barrier();
+      stamp(12, i);
       if (r == 0 && !(A.dbg & 256)) dma_table(TI, i_next);  // every wavefront is past its last read of the current image
       if (!(A.dbg & 1)) {
-#pragma unroll 1
+        // this wavefront's four rows of the pass: row map, then all eight values, then the stores -- one LDS round trip each
+        // (3N <= 126: two stores per lane and row)
+        int arow4[4], orow4[4], otmp[4];
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int rsl = 4 * w + k;  // 0 .. 35
-          const int ra = rsl / 3, al = rsl - 3 * ra;
-          const int a = 16 * (ra >> 2) + (ra & 3) + 4 * r;
-          if (a < N) {
-            const int orow = 3 * sigma[a] + al;
-            const int64_t grow = i * N3 + orow;
+          const int ra = rsl / 3;
+          arow4[k] = 16 * (ra >> 2) + (ra & 3) + 4 * r;
+          otmp[k] = sigma[arow4[k] < N ? arow4[k] : N - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) orow4[k] = __builtin_amdgcn_readfirstlane(otmp[k]);  // wave-uniform: scalar row addresses
+        P2_FRESH(lane_r, threadIdx.x & 63);
+        const int c1 = lane_r + 64;
+        const bool ok1 = c1 < N3;
+        double o0[4], o1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rsl = 4 * w + k;
+          o0[k] = ST[rsl * N3 + lane_r];
+          o1[k] = ST[rsl * N3 + (ok1 ? c1 : lane_r)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rsl = 4 * w + k;
+          const int al = rsl - 3 * (rsl / 3);
+          if (arow4[k] < N) {
+            const int64_t grow = i * N3 + 3 * orow4[k] + al;
             double* dstg = A.K + (grow - A.i_beg * N3) * A.ld + A.col0 + jv * N3;
             const int64_t dcol = grow - (A.col0 + jv * N3);  // where the matrix diagonal crosses this row segment
-            // 3N <= 126: two stores per lane, both values read first
-            const int c1 = lane + 64;
-            const bool ok1 = c1 < N3;
-            double o0 = ST[rsl * N3 + lane];
-            double o1 = ST[rsl * N3 + (ok1 ? c1 : lane)];
-            if (lower && lane == dcol) o0 += A.lam;
-            if (lower && c1 == dcol) o1 += A.lam;
-            dstg[lane] = o0;
-            if (ok1) dstg[c1] = o1;
+            dstg[lane_r] = o0[k] + ((lower && lane_r == dcol) ? A.lam : 0.0);
+            if (ok1) dstg[c1] = o1[k] + ((lower && c1 == dcol) ? A.lam : 0.0);
           }
         }
       }
+      stamp(13, i);
     }
   }
 }
@@ -621,8 +721,10 @@ bool assemble_perm2_applicable(const gdml_ctx* ctx) {
   if (!ctx_opt_i(ctx, "asm.perm2", 1)) return false;
   // Measured (profiles/r05_assemble_perm2.txt): the per-block cost of this kernel is nearly independent of N and P (17 barriers
   // and a dozen short dependent LDS chains per block and group with one workgroup of 9 wavefronts per CU), so it only wins where
-  // assemble_perm_kernel's N^2 P work is largest: N = 42, P = 27 1.36-1.45x; N = 36, P = 27 0.94x; P = 6 0.5-0.75x.
-  return ts.P >= ctx_opt_i(ctx, "asm.perm2_min_p", 16) && ts.N >= ctx_opt_i(ctx, "asm.perm2_min_n", 40) && ts.N <= P2_MAXN;
+  // assemble_perm_kernel's N^2 P work is largest: N = 42, P = 27 1.8x; N = 36, P = 27 1.17x; N = 42, P = 6 1.15x; N = 30, P = 6 0.72x.
+  const int min_n = ctx_opt_i(ctx, "asm.perm2_min_n", 36), min_p = ctx_opt_i(ctx, "asm.perm2_min_p", 6);
+  if (ts.P < min_p || ts.N < min_n || ts.N > P2_MAXN) return false;
+  return ts.P >= 16 || ts.N >= min_n + 4 || min_n < 36;  // small groups only pay on the largest molecules
 }
 
 // Plan of the group: internal numbering (fixed atoms first), permutations in it, V-phase tasks.  Built once per training set.
@@ -662,7 +764,7 @@ static int perm2_plan(gdml_ctx* ctx) {
   auto add_rows = [&](int b0, int b1, int mb, int me, int base) {
     if (b1 <= b0 || me <= mb) return;
     int lg = 0;
-    while (lg < 3 && ((me - mb + (1 << lg) - 1) >> lg) > ctx_opt_i(ctx, "asm.perm2_chunk", 24)) ++lg;
+    while (lg < 3 && ((me - mb + (1 << lg) - 1) >> lg) > ctx_opt_i(ctx, "asm.perm2_chunk", 12)) ++lg;
     const int rows_per = 8 >> lg;
     for (int b = b0; b < b1; b += rows_per) {
       Task t;
@@ -674,6 +776,32 @@ static int perm2_plan(gdml_ctx* ctx) {
   };
   add_rows(nF, N, 0, N, 0);
   add_rows(0, nF, nF, N, 1);
+  // tasks to wavefronts, longest first onto the least loaded one (cost ~ trips of two entries + the chunk reduction); in post
+  // mode the wavefronts whose tile group has moved rows and moved columns start with the single terms of 8 permutations
+  const bool post_plan = nF >= 2 && N - nF <= 16 && ctx_opt_i(ctx, "asm.perm2_post", 1);
+  double load[P2_NW];
+  for (int w = 0; w < P2_NW; ++w) {
+    const int gs = w / 3, gt = w % 3;
+    const bool live = 16 * gs < N && 16 * gt < N;
+    load[w] = (post_plan && live && 16 * gs + 15 >= nF && 16 * gt + 15 >= nF) ? 11.0 : 0.0;
+  }
+  auto cost = [&](const Task& t) { return 0.5 * (((t.me - t.mb + (1 << t.lg) - 1) >> t.lg) + 1) + 1.0 + 0.7 * t.lg; };
+  std::stable_sort(tasks.begin(), tasks.end(), [&](const Task& a, const Task& b) { return cost(a) > cost(b); });
+  std::vector<std::vector<Task>> per_wave(P2_NW);
+  for (const Task& t : tasks) {
+    int best = 0;
+    for (int w = 1; w < P2_NW; ++w)
+      if (load[w] < load[best]) best = w;
+    per_wave[best].push_back(t);
+    load[best] += cost(t);
+  }
+  uint8_t wt_off[16] = {0};
+  tasks.clear();
+  for (int w = 0; w < P2_NW; ++w) {
+    wt_off[w] = (uint8_t)tasks.size();
+    for (const Task& t : per_wave[w]) tasks.push_back(t);
+  }
+  for (int w = P2_NW; w < 16; ++w) wt_off[w] = (uint8_t)tasks.size();
   auto align_to = [&](size_t al) { while (blob.size() % al) blob.push_back(0); };
   align_to(16);
   ts.p2_o[0] = (int)blob.size();  // src
@@ -695,6 +823,7 @@ static int perm2_plan(gdml_ctx* ctx) {
   {
     const uint8_t* b = reinterpret_cast<const uint8_t*>(tasks.data());
     blob.insert(blob.end(), b, b + tasks.size() * sizeof(Task));
+    blob.insert(blob.end(), wt_off, wt_off + 16);
   }
   ts.p2_nF = nF;
   ts.p2_ntasks = (int)tasks.size();
@@ -730,7 +859,7 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
   A.dbg = ctx_opt_i(ctx, "asm.perm2_debug", 0);
   int o = L_PERM;
   o += (2 * P * N + 7) / 8;
-  A.l_task = o; o += 2 * ts.p2_ntasks;
+  A.l_task = o; o += 2 * ts.p2_ntasks + 2;
   o += (N + 1) / 2;  // sigma
   A.l_cn = o; o += P;
   A.nE = N - ts.p2_nF;
@@ -744,9 +873,25 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
   while (i_chunk > 2 && n_j * ((n_i + i_chunk - 1) / i_chunk) < 1024) i_chunk >>= 1;
   A.i_chunk = i_chunk;
   dim3 grid((unsigned)n_j, (unsigned)((n_i + i_chunk - 1) / i_chunk));
-  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  unsigned long long* d_trace = nullptr;
+  if (A.dbg & 1024) {
+    GDML_TRY(ctx_alloc(ctx, (void**)&d_trace, 512 * 8));
+    HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, 512 * 8, ctx->stream));
+    A.trace = d_trace;
+  }
   const int slot = ktime_begin(ctx);
-  hipLaunchKernelGGL(assemble_perm2_kernel, grid, dim3(P2_T), lds, ctx->stream, A);
+  if (d_trace) hipLaunchKernelGGL(assemble_perm2_kernel<true>, grid, dim3(P2_T), lds, ctx->stream, A);
+  else hipLaunchKernelGGL(assemble_perm2_kernel<false>, grid, dim3(P2_T), lds, ctx->stream, A);
+  if (d_trace) {  // phase stamps of one workgroup: id, shader clock (100 MHz), difference to the previous stamp
+    std::vector<unsigned long long> h(512);
+    HIP_CHECK(ctx, hipMemcpyAsync(h.data(), d_trace, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 250 && h[2 * k + 1]; ++k)
+      fprintf(stderr, "perm2 trace %3d id %2llu t %llu dt %lld\n", k, h[2 * k], h[2 * k + 1], k ? (long long)(h[2 * k + 1] - h[2 * k - 1]) : 0LL);
+    GDML_TRY(ctx_free(ctx, d_trace));
+  }
   const double blocks = lower ? 0.5 * (double)n_i * (double)(n_i + 1) : (double)n_i * (double)n_j;
   ktime_end(ctx, slot, "assemble", 8.0 * blocks * 9.0 * N * N);
   ctx->launch_counter++;

@@ -52,4 +52,7 @@ if __name__ == '__main__':
     mode = sys.argv[1] if len(sys.argv) > 1 else 'check'
     if mode == 'check':
         sys.exit(0 if do_check() else 1)
+    if mode == 'trace':   # shader-clock stamps (100 MHz) of one workgroup's phases, printed by the library on stderr
+        time_case(42, 300, 'c3^3', {'asm.perm2_debug': 1024}, reps=1, label='trace')
+        sys.exit(0)
     do_time(len(sys.argv) > 2 and sys.argv[2] == 'full')
