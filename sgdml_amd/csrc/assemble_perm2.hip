@@ -197,31 +197,28 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         const int lo = __builtin_amdgcn_readlane((int)bb, pl), hi = __builtin_amdgcn_readlane((int)(bb >> 32), pl);
         cn = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
       }
+      // the operands of all four row atoms in one batch of reads (one LDS round trip per permutation)
+      double a0[4], q0[4];
+      d2 a12[4], q12[4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {  // two row atoms per batch of loads
-        double a0[2], q0[2];
-        d2 a12[2], q12[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int r = 2 * h + t;
-          const double* gi = TI + (arc[r] * N + ap) * 4;
-          const double* gj = TJ + (cbc * N + pa[r]) * 4;
-          a0[t] = gi[1];
-          a12[t] = *reinterpret_cast<const d2*>(gi + 2);
-          q0[t] = gj[1];
-          q12[t] = *reinterpret_cast<const d2*>(gj + 2);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int r = 2 * h + t;
-          const double cnr = cn * wr[r];
-          const double w0 = cnr * q0[t], w1 = cnr * q12[t].x, w2 = cnr * q12[t].y;
-          acc[0][0][r] += a0[t] * w0; acc[0][1][r] += a0[t] * w1; acc[0][2][r] += a0[t] * w2;
-          acc[1][0][r] += a12[t].x * w0; acc[1][1][r] += a12[t].x * w1; acc[1][2][r] += a12[t].x * w2;
-          acc[2][0][r] += a12[t].y * w0; acc[2][1][r] += a12[t].y * w1; acc[2][2][r] += a12[t].y * w2;
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < 4; ++r) {
+        const double* gi = TI + (arc[r] * N + ap) * 4;
+        const double* gj = TJ + (cbc * N + pa[r]) * 4;
+        a0[r] = gi[1];
+        a12[r] = *reinterpret_cast<const d2*>(gi + 2);
+        q0[r] = gj[1];
+        q12[r] = *reinterpret_cast<const d2*>(gj + 2);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double cnr = cn * wr[r];
+        const double w0 = cnr * q0[r], w1 = cnr * q12[r].x, w2 = cnr * q12[r].y;
+        acc[0][0][r] += a0[r] * w0; acc[0][1][r] += a0[r] * w1; acc[0][2][r] += a0[r] * w2;
+        acc[1][0][r] += a12[r].x * w0; acc[1][1][r] += a12[r].x * w1; acc[1][2][r] += a12[r].x * w2;
+        acc[2][0][r] += a12[r].y * w0; acc[2][1][r] += a12[r].y * w1; acc[2][2][r] += a12[r].y * w2;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -320,36 +317,43 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
           typedef const volatile __attribute__((address_space(3))) uint8_t* lds_vbyte;
           const lds_vbyte pinv_v = (lds_vbyte)pin;
           auto mclamp = [&](int m) { return (m < N) ? m : N - 1; };
-          int miA = pinv_v[mclamp(m0)], miB = pinv_v[mclamp(m0 + 1)];
+          // NB entries per trip: their 2 NB table reads are issued together, and the byte lookups of the NEXT NB entries are
+          // requested before the multiply-adds.  Rows without diagonal-term products have the registers for three entries
+          // per trip (an LDS round trip costs several hundred cycles here: fewer, fuller trips).
           auto vloop = [&](auto DGc) {
             constexpr bool WITH_DG = decltype(DGc)::value;
-#pragma unroll 1
-          for (int k = 0; k < per; k += 2) {
-            const int mA = m0 + k, mB = m0 + k + 1;
-            const d4 aA = *reinterpret_cast<const d4*>(ti + 4 * miA);
-            const d4 qA = *reinterpret_cast<const d4*>(tj + 4 * mclamp(mA));
-            const d4 aB = *reinterpret_cast<const d4*>(ti + 4 * miB);
-            const d4 qB = *reinterpret_cast<const d4*>(tj + 4 * mclamp(mB));
-            miA = pinv_v[mclamp(mA + 2)];
-            miB = pinv_v[mclamp(mB + 2)];
-            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NB = WITH_DG ? 2 : 3;
+            int mi[NB];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const d4 a = t ? aB : aA, q = t ? qB : qA;
-              const double lv = (act && (t ? mB : mA) < m1) ? 1.0 : 0.0;  // multiplied, not branched on: the loop stays uniform
-              const double d = (a.x - q.x) * lv;
-              const double g0v = a.y * lv, g1v = a.z * lv, g2v = a.w * lv;
-              nn += d * d;
-              u0 += d * q.y; u1 += d * q.z; u2 += d * q.w;
-              v0 += d * a.y; v1 += d * a.z; v2 += d * a.w;
-              if (WITH_DG) {
-                d00 += g0v * q.y; d01 += g0v * q.z; d02 += g0v * q.w;
-                d10 += g1v * q.y; d11 += g1v * q.z; d12 += g1v * q.w;
-                d20 += g2v * q.y; d21 += g2v * q.z; d22 += g2v * q.w;
+            for (int t = 0; t < NB; ++t) mi[t] = pinv_v[mclamp(m0 + t)];
+#pragma unroll 1
+            for (int k = 0; k < per; k += NB) {
+              d4 av[NB], qv[NB];
+#pragma unroll
+              for (int t = 0; t < NB; ++t) {
+                av[t] = *reinterpret_cast<const d4*>(ti + 4 * mi[t]);
+                qv[t] = *reinterpret_cast<const d4*>(tj + 4 * mclamp(m0 + k + t));
               }
+#pragma unroll
+              for (int t = 0; t < NB; ++t) mi[t] = pinv_v[mclamp(m0 + k + NB + t)];
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int t = 0; t < NB; ++t) {
+                const d4 a = av[t], q = qv[t];
+                const double lv = (act && m0 + k + t < m1) ? 1.0 : 0.0;  // multiplied, not branched on: the loop stays uniform
+                const double d = (a.x - q.x) * lv;
+                nn += d * d;
+                u0 += d * q.y; u1 += d * q.z; u2 += d * q.w;
+                v0 += d * a.y; v1 += d * a.z; v2 += d * a.w;
+                if (WITH_DG) {
+                  const double g0v = a.y * lv, g1v = a.z * lv, g2v = a.w * lv;
+                  d00 += g0v * q.y; d01 += g0v * q.z; d02 += g0v * q.w;
+                  d10 += g1v * q.y; d11 += g1v * q.z; d12 += g1v * q.w;
+                  d20 += g2v * q.y; d21 += g2v * q.z; d22 += g2v * q.w;
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-          }
           };
           // post mode: the diagonal terms of fixed rows come out of the once-per-block pass
           if (base && A.post) vloop(std::false_type{});
@@ -395,6 +399,8 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         if (lane_v < 8) NNS[w * 8 + lane_v] = nnl;
       }
       stamp(2, i);
+      if (TRACE && A.trace != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && (tid & 63) == 0 && i - i_lo == 2)
+        A.trace[600 + w * 4 + (g0 >> 3)] = __builtin_amdgcn_s_memtime();  // when every wavefront reaches the barrier after V
       __syncthreads();
       stamp(3, i);
       // ================= Matern scalars of the group (every wavefront for itself; lanes 0 .. 7 hold them)
@@ -877,19 +883,27 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
   (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   unsigned long long* d_trace = nullptr;
   if (A.dbg & 1024) {
-    GDML_TRY(ctx_alloc(ctx, (void**)&d_trace, 512 * 8));
-    HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, 512 * 8, ctx->stream));
+    GDML_TRY(ctx_alloc(ctx, (void**)&d_trace, 1024 * 8));
+    HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, 1024 * 8, ctx->stream));
     A.trace = d_trace;
   }
   const int slot = ktime_begin(ctx);
   if (d_trace) hipLaunchKernelGGL(assemble_perm2_kernel<true>, grid, dim3(P2_T), lds, ctx->stream, A);
   else hipLaunchKernelGGL(assemble_perm2_kernel<false>, grid, dim3(P2_T), lds, ctx->stream, A);
   if (d_trace) {  // phase stamps of one workgroup: id, shader clock (100 MHz), difference to the previous stamp
-    std::vector<unsigned long long> h(512);
-    HIP_CHECK(ctx, hipMemcpyAsync(h.data(), d_trace, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> h(1024);
+    HIP_CHECK(ctx, hipMemcpyAsync(h.data(), d_trace, 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 250 && h[2 * k + 1]; ++k)
       fprintf(stderr, "perm2 trace %3d id %2llu t %llu dt %lld\n", k, h[2 * k], h[2 * k + 1], k ? (long long)(h[2 * k + 1] - h[2 * k - 1]) : 0LL);
+    for (int g = 0; g < 4; ++g) {  // arrival of the nine wavefronts at the barrier behind the V phase, relative to the first one
+      unsigned long long t0 = ~0ull;
+      for (int w = 0; w < P2_NW; ++w)
+        if (h[600 + w * 4 + g] && h[600 + w * 4 + g] < t0) t0 = h[600 + w * 4 + g];
+      fprintf(stderr, "perm2 varrive group %d:", g);
+      for (int w = 0; w < P2_NW; ++w) fprintf(stderr, " w%d %lld", w, h[600 + w * 4 + g] ? (long long)(h[600 + w * 4 + g] - t0) : -1LL);
+      fprintf(stderr, "\n");
+    }
     GDML_TRY(ctx_free(ctx, d_trace));
   }
   const double blocks = lower ? 0.5 * (double)n_i * (double)(n_i + 1) : (double)n_i * (double)n_j;
