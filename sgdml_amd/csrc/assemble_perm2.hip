@@ -73,6 +73,9 @@ struct Perm2Args {
   int64_t ld;
   int l_task;  // LDS offset of the task descriptors in doubles (behind the byte permutation tables)
   int l_cn;    // ... of cn_p of all permutations (post mode)
+  int l_sigma, l_ed, l_pt;  // ... of the row map, of the per-group table of moved-atom diagonal terms, of its pair tables (bytes)
+  int es;                   // es mode (needs post): single terms of moved x moved blocks summed over the permutations by four lanes per block, once per (i, j)
+  int ed, npairs, o_pt;     // ed mode (needs post): the diagonal terms of moved atoms summed per (row atom, column atom) pair by idle lanes
   int post, nE;  // single / diagonal terms of fixed atoms once per block (nE = moved atoms <= 16)
   unsigned long long* trace;  // asm.perm2_debug & 1024: shader-clock stamps of one workgroup's phases (tools/perm2_check.py trace)
   int dbg;  // timing-only ablation: 1 no stores, 2 no V tasks, 4 no single terms, 8 no MFMA, 16 no base pass, 32 no exp, 64 no diagonal terms,
@@ -94,9 +97,12 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   uint8_t* const permS = reinterpret_cast<uint8_t*>(smem + L_PERM);
   uint8_t* const pinvS = permS + P * N;
   double* const CN = smem + A.l_cn;
+  double* const ED = smem + A.l_ed;  // [pair][9]
+  uint8_t* const pmapS = reinterpret_cast<uint8_t*>(smem + A.l_pt);  // [nE][nE] pair index or 255, then [pair][2] = (row atom, column atom)
+  uint8_t* const plistS = pmapS + A.nE * A.nE;
   uint32_t* const taskS = reinterpret_cast<uint32_t*>(smem + A.l_task);
   const int32_t* const sigma_g = reinterpret_cast<const int32_t*>(A.blob + A.o_sigma);
-  int* const sigma = reinterpret_cast<int*>(smem + A.l_task + 2 * A.n_tasks + 2);  // LDS copy: a global load between two row stores would wait for the stores
+  int* const sigma = reinterpret_cast<int*>(smem + A.l_sigma);  // LDS copy: a global load between two row stores would wait for the stores
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,6 +131,8 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   // ---- resident tables
   for (int e = tid; e < 2 * P * N; e += P2_T) permS[e] = A.blob[e];
   for (int e = tid; e < N; e += P2_T) sigma[e] = sigma_g[e];
+  if (A.ed)
+    for (int e = tid; e < A.nE * A.nE + 2 * A.npairs; e += P2_T) pmapS[e] = A.blob[A.o_pt + e];
   {
     const uint32_t* tg = reinterpret_cast<const uint32_t*>(A.blob + A.o_tasks);
     for (int e = tid; e < 4 * A.n_tasks + 4; e += P2_T) taskS[e] = tg[e];  // + 16 bytes: first task of every wavefront
@@ -222,6 +230,33 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
     }
   };
 
+  // ---- ed mode: the diagonal terms of moved atoms of one group, summed per (row atom, column atom) pair into ED by idle lanes
+  // (end of the O phase), are added by the lane that holds the pair's block -- one batch of reads per group instead of nine
+  // reads and 36 multiply-adds per permutation on the critical wavefront.  n_its = 0 or 1 (no branch around accumulator code).
+  auto add_ed = [&](d4 (&acc)[3][3], const int (&arc)[4], int cbc, int n_its) {
+    for (int it = 0; it < n_its; ++it) {
+      double mw[4];
+      int pidx[4];
+      const int cbe = (cbc >= nF) ? cbc - nF : 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ae = (arc[r] >= nF) ? arc[r] - nF : 0;
+        pidx[r] = pmapS[ae * A.nE + cbe];
+      }
+      double x[4][9];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x[r][k] = ED[(pidx[r] < A.npairs ? pidx[r] : 0) * 9 + k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mw[r] = ((arc[r] >= nF) & (cbc >= nF) & (pidx[r] < A.npairs)) ? 1.0 : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k / 3][k % 3][r] += mw[r] * x[r][k];
+    }
+  };
+
   for (int64_t i = i_lo; i < i_hi; ++i) {
     __syncthreads();  // image of point i (and the resident tables) visible; the previous block's staging is read
     stamp(0, i);
@@ -283,7 +318,9 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
          // iterations on the others), while the rest of the workgroup is in this group's V phase
         P2_LANE_CONSTS();
         const bool go = A.post && ee_wave && g0 > 0;
-        run_singles(acc, arc, cbc, go ? g0 - 8 : 0, go ? 8 : 0, 8, cn_prev);
+        const bool go_s = go && !A.es;  // es mode: the moved x moved single terms come out of the once-per-block pass too
+        run_singles(acc, arc, cbc, go_s ? g0 - 8 : 0, go_s ? 8 : 0, 8, cn_prev);
+        add_ed(acc, arc, cbc, (go && A.ed) ? 1 : 0);
       }
       // ================= phase V: lane = (slot, permutation of the group)
       {
@@ -459,7 +496,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
             const bool m = (pl < npg) & cb_ok & ((A.post == 0) | (cb >= nF)) & (rr >= 0) & (rr < 16) & ((rr & 3) == 0);
             tgt |= m ? (1u << (4 * pl + ((rr >> 2) & 3))) : 0u;
           }
-          const int n_dg = (__builtin_amdgcn_ballot_w64(tgt != 0) != 0 && !(A.dbg & 64)) ? npg : 0;
+          const int n_dg = (__builtin_amdgcn_ballot_w64(tgt != 0) != 0 && !(A.dbg & 64) && !A.ed) ? npg : 0;
           const double* dgb = DG + (9 * cbc) * 8;
 #pragma unroll 2
           for (int pl = 0; pl < n_dg; ++pl) {
@@ -501,6 +538,29 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
             for (int be = 0; be < 3; ++be) acc[al][be] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[al], bv[be], acc[al][be], 0, 0, 0);
         }
       }
+      if (A.ed && !(A.dbg & 64) && 64 * w < 9 * A.npairs) {  // (no accumulator code in here; wavefronts beyond the last pair skip it)
+        P2_FRESH(tid_e, threadIdx.x);
+        const int pair = tid_e / 9, k = tid_e - 9 * pair;
+        const bool okp = pair < A.npairs;
+        const int pc = okp ? pair : 0;
+        const int pa_ = plistS[2 * pc], pb_ = plistS[2 * pc + 1];  // row atom, column atom (internal numbers)
+        int by[8];
+        d2 dv[4];
+#pragma unroll
+        for (int pl = 0; pl < 8; ++pl) by[pl] = pinvS[(g0 + (pl < npg ? pl : npg - 1)) * N + pb_];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) dv[h] = *reinterpret_cast<const d2*>(DG + (9 * pb_ + k) * 8 + 2 * h);
+        double sum = 0.0;
+#pragma unroll
+        for (int pl = 0; pl < 8; ++pl) {
+          const long long bb = __builtin_bit_cast(long long, cn_v);
+          const int lo = __builtin_amdgcn_readlane((int)bb, pl), hi = __builtin_amdgcn_readlane((int)(bb >> 32), pl);
+          const double cn = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);  // 0 beyond the group
+          const double x = (pl & 1) ? dv[pl >> 1].y : dv[pl >> 1].x;
+          sum += (by[pl] == pa_) ? cn * x : 0.0;
+        }
+        if (okp) ED[pair * 9 + k] = sum;
+      }
       cn_prev = cn_v;
       stamp(7, i);
       __syncthreads();  // the V-phase results of this group are free
@@ -509,7 +569,8 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
     {  // post mode: single terms of the last group
       P2_LANE_CONSTS();
       const int g_last = ((P - 1) / 8) * 8;
-      run_singles(acc, arc, cbc, g_last, (A.post && ee_wave) ? P - g_last : 0, P - g_last, cn_prev);
+      run_singles(acc, arc, cbc, g_last, (A.post && ee_wave && !A.es) ? P - g_last : 0, P - g_last, cn_prev);
+      add_ed(acc, arc, cbc, (A.post && A.ed && ee_wave) ? 1 : 0);
     }
     // ================= once per block (post mode): everything a fixed atom is involved in, summed over the permutations first.
     //   A1(a, e) = sum_p cn_p G_i(a, pi_p^-1 e),  B1(a, e) = sum_p cn_p G_j(a, pi_p e)      a fixed, e moved
@@ -542,6 +603,52 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
           for (int k = 0; k < 9; ++k) wv += ((p0 + k < P) & (by[k] == y)) ? cv[k] : 0.0;
         }
         WS[t] = wv;
+      }
+      // es mode: the single terms of the nE x nE blocks of two moved atoms, four lanes per block (permutations q, q + 4, ...),
+      // two permutations per batch of reads; summed inside the quad and left in ES for the lane that holds the block
+      double* const ES = WS + ((nE * nE + 1) & ~1);
+      if (A.es) {
+        for (int t0 = 0; t0 < 4 * nE * nE; t0 += P2_T) {
+          const int t = t0 + tid_p;
+          const bool okt = t < 4 * nE * nE;
+          const int pair = okt ? (t >> 2) : 0, q = t & 3;
+          const int a = nF + pair / nE, b = nF + pair - (pair / nE) * nE;
+          const double* tia = TI + a * N * 4;
+          const double* tjb = TJ + b * N * 4;
+          double e[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) e[k] = 0.0;
+          for (int p0 = q; p0 < P; p0 += 8) {
+            double cn[2], a0[2], q0[2];
+            d2 a12[2], q12[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int p = (p0 + 4 * h < P) ? p0 + 4 * h : P - 1;
+              cn[h] = (p0 + 4 * h < P) ? CN[p] : 0.0;
+              const double* gi = tia + 4 * (int)pinvS[p * N + b];
+              const double* gj = tjb + 4 * (int)permS[p * N + a];
+              a0[h] = gi[1];
+              a12[h] = *reinterpret_cast<const d2*>(gi + 2);
+              q0[h] = gj[1];
+              q12[h] = *reinterpret_cast<const d2*>(gj + 2);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const double w0 = cn[h] * q0[h], w1 = cn[h] * q12[h].x, w2 = cn[h] * q12[h].y;
+              e[0] += a0[h] * w0; e[1] += a0[h] * w1; e[2] += a0[h] * w2;
+              e[3] += a12[h].x * w0; e[4] += a12[h].x * w1; e[5] += a12[h].x * w2;
+              e[6] += a12[h].y * w0; e[7] += a12[h].y * w1; e[8] += a12[h].y * w2;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 9; ++k) e[k] += dpp_f64<P2_XOR1>(e[k]);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) e[k] += dpp_f64<P2_XOR2>(e[k]);
+          if (okt && q == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) ES[pair * 9 + k] = e[k];
+          }
+        }
       }
       __syncthreads();
       for (int ab = 0; ab < nF; ab += P2_T / 16) {
@@ -621,6 +728,25 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         acc[0][0][r] += a0 * w0; acc[0][1][r] += a0 * w1; acc[0][2][r] += a0 * w2;
         acc[1][0][r] += a12.x * w0; acc[1][1][r] += a12.x * w1; acc[1][2][r] += a12.x * w2;
         acc[2][0][r] += a12.y * w0; acc[2][1][r] += a12.y * w1; acc[2][2][r] += a12.y * w2;
+      }
+      {  // es mode: the summed single terms of this lane's moved x moved blocks (zero iterations elsewhere)
+        const int n_es = (A.post && A.es && ee_wave) ? 1 : 0;
+        const double* const ESr = FDS + ((9 * nF + 1) & ~1) + ((A.nE * A.nE + 1) & ~1);
+        for (int it = 0; it < n_es; ++it) {
+          double x[4][9], mwe[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool m = (arc[r] >= nF) & (cbc >= nF);
+            const int pe = m ? (arc[r] - nF) * A.nE + (cbc - nF) : 0;
+            mwe[r] = m ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) x[r][k] = ESr[pe * 9 + k];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k / 3][k % 3][r] += mwe[r] * x[r][k];
+        }
       }
       // diagonal terms of fixed atoms (post mode): the lane that holds the block (b, b)
       double mw[4];
@@ -831,6 +957,31 @@ static int perm2_plan(gdml_ctx* ctx) {
     blob.insert(blob.end(), b, b + tasks.size() * sizeof(Task));
     blob.insert(blob.end(), wt_off, wt_off + 16);
   }
+  // pairs (row atom a, column atom b) of moved atoms with pi_p a = b for some p (a == b included): pair map + pair list
+  ts.p2_o[3] = (int)blob.size();
+  ts.p2_npairs = 0;
+  if (nF > 0) {
+    const int nE = N - nF;
+    std::vector<uint8_t> pmap((size_t)nE * nE, 255), plist;
+    const uint8_t* permI = blob.data();  // [p][a] internal numbering
+    for (int a = nF; a < N; ++a)
+      for (int b = nF; b < N; ++b) {
+        bool hit = false;
+        for (int p = 0; p < P && !hit; ++p) hit = permI[(size_t)p * N + a] == b;
+        if (hit && plist.size() / 2 < 255) {
+          pmap[(size_t)(a - nF) * nE + (b - nF)] = (uint8_t)(plist.size() / 2);
+          plist.push_back((uint8_t)a);
+          plist.push_back((uint8_t)b);
+        } else if (hit) {
+          plist.clear();  // too many pairs for a byte index: no ed mode
+          a = N;
+          break;
+        }
+      }
+    ts.p2_npairs = (int)(plist.size() / 2);
+    blob.insert(blob.end(), pmap.begin(), pmap.end());
+    blob.insert(blob.end(), plist.begin(), plist.end());
+  }
   ts.p2_nF = nF;
   ts.p2_ntasks = (int)tasks.size();
   GDML_TRY(ctx_alloc(ctx, (void**)&ts.p2, (int64_t)blob.size()));
@@ -863,14 +1014,31 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
   A.j0 = j0; A.n_j = n_j; A.col0 = col0; A.i_beg = i_beg; A.i_end = i_end;
   A.lower = lower; A.lam = lam; A.K = K; A.ld = ld;
   A.dbg = ctx_opt_i(ctx, "asm.perm2_debug", 0);
-  int o = L_PERM;
-  o += (2 * P * N + 7) / 8;
-  A.l_task = o; o += 2 * ts.p2_ntasks + 2;
-  o += (N + 1) / 2;  // sigma
-  A.l_cn = o; o += P;
+  // small LDS items into the two free regions: the unused rows of B0 (16 doubles per moved atom) and the tail behind the byte
+  // permutation tables
   A.nE = N - ts.p2_nF;
-  // post mode: 16 lanes per fixed atom in the once-per-block pass, its tables in the V-phase buffers
   A.post = (ts.p2_nF >= 2 && A.nE <= 16 && 8 * ts.p2_nF * A.nE + 9 * ts.p2_nF + 1 + A.nE * A.nE <= 15 * P2_MAXN * 8 && ctx_opt_i(ctx, "asm.perm2_post", 1)) ? 1 : 0;
+  A.npairs = ts.p2_npairs;
+  A.o_pt = ts.p2_o[3];
+  A.es = (A.post && 8 * ts.p2_nF * A.nE + 9 * ts.p2_nF + 2 + (9 + 1) * A.nE * A.nE + 2 <= 15 * P2_MAXN * 8 && ctx_opt_i(ctx, "asm.perm2_es", 1)) ? 1 : 0;
+  A.ed = (A.post && ts.p2_npairs > 0 && 9 * ts.p2_npairs <= P2_T && ctx_opt_i(ctx, "asm.perm2_ed", 1)) ? 1 : 0;
+  int o = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    int r1 = L_B0 + 16 * (ts.p2_nF > 0 ? ts.p2_nF : 0), r1_end = L_NN;  // free rows of B0
+    int r2 = L_PERM + (2 * P * N + 7) / 8;                                // tail
+    auto place = [&](int n) {  // first fit: B0 rows, then the tail
+      if (r1 + n <= r1_end) { const int at = r1; r1 += n; return at; }
+      const int at = r2; r2 += n; return at;
+    };
+    A.l_ed = A.ed ? place(9 * A.npairs) : 0;
+    A.l_cn = place(P);
+    A.l_task = place(2 * ts.p2_ntasks + 2);
+    A.l_sigma = place((N + 1) / 2);
+    A.l_pt = A.ed ? place((A.nE * A.nE + 2 * A.npairs + 7) / 8) : 0;
+    o = r2;
+    if ((size_t)o * 8 <= (size_t)160 * 1024 || !A.ed) break;
+    A.ed = 0;  // does not fit with the pair tables: the per-permutation diagonal terms
+  }
   const size_t lds = (size_t)o * 8;
   if (lds > (size_t)160 * 1024) return GDML_ERR_UNSUPPORTED;  // (many permutations: the byte tables) -- the general kernel
   const int64_t n_i = i_end - i_beg;
