@@ -74,6 +74,7 @@ struct Perm2Args {
   int l_task;  // LDS offset of the task descriptors in doubles (behind the byte permutation tables)
   int l_cn;    // ... of cn_p of all permutations (post mode)
   int l_sigma, l_ed, l_pt;  // ... of the row map, of the per-group table of moved-atom diagonal terms, of its pair tables (bytes)
+  int nFb;                  // fixed rows whose fixed-partner part comes from the base pass (the others ride in full-range tasks)
   int es;                   // es mode (needs post): single terms of moved x moved blocks summed over the permutations by four lanes per block, once per (i, j)
   int ed, npairs, o_pt;     // ed mode (needs post): the diagonal terms of moved atoms summed per (row atom, column atom) pair by idle lanes
   int post, nE;  // single / diagonal terms of fixed atoms once per block (nE = moved atoms <= 16)
@@ -274,20 +275,29 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         double s[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) s[k] = 0.0;
-        for (int m0 = 0; m0 < nF; m0 += 8) {
-          const int m = m0 + c;
-          const double lv = (ok && m < nF) ? 1.0 : 0.0;
-          const int mc = (m < nF) ? m : nF - 1;
-          const d4 a = *reinterpret_cast<const d4*>(ti + 4 * mc);
-          const d4 q = *reinterpret_cast<const d4*>(tj + 4 * mc);
-          const double d = (a.x - q.x) * lv;
-          const double g0 = a.y * lv, g1 = a.z * lv, g2 = a.w * lv;
-          s[15] += d * d;
-          s[0] += d * q.y; s[1] += d * q.z; s[2] += d * q.w;
-          s[3] += d * a.y; s[4] += d * a.z; s[5] += d * a.w;
-          s[6] += g0 * q.y; s[7] += g0 * q.z; s[8] += g0 * q.w;
-          s[9] += g1 * q.y; s[10] += g1 * q.z; s[11] += g1 * q.w;
-          s[12] += g2 * q.y; s[13] += g2 * q.z; s[14] += g2 * q.w;
+        for (int m0 = 0; m0 < nF; m0 += 24) {  // three entries (six table reads) per trip: an LDS round trip per entry otherwise
+          d4 av[3], qv[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int m = m0 + 8 * t + c;
+            const int mc = (m < nF) ? m : nF - 1;
+            av[t] = *reinterpret_cast<const d4*>(ti + 4 * mc);
+            qv[t] = *reinterpret_cast<const d4*>(tj + 4 * mc);
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int m = m0 + 8 * t + c;
+            const double lv = (ok && m < nF) ? 1.0 : 0.0;
+            const d4 a = av[t], q = qv[t];
+            const double d = (a.x - q.x) * lv;
+            const double g0 = a.y * lv, g1 = a.z * lv, g2 = a.w * lv;
+            s[15] += d * d;
+            s[0] += d * q.y; s[1] += d * q.z; s[2] += d * q.w;
+            s[3] += d * a.y; s[4] += d * a.z; s[5] += d * a.w;
+            s[6] += g0 * q.y; s[7] += g0 * q.z; s[8] += g0 * q.w;
+            s[9] += g1 * q.y; s[10] += g1 * q.z; s[11] += g1 * q.w;
+            s[12] += g2 * q.y; s[13] += g2 * q.z; s[14] += g2 * q.w;
+          }
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) s[k] += dpp_f64<P2_XOR1>(s[k]);
@@ -301,7 +311,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         }
       }
       __syncthreads();
-      nn0 = wave_sum(lane_b < nF ? B0[lane_b * 16 + 15] : 0.0);
+      nn0 = wave_sum(lane_b < A.nFb ? B0[lane_b * 16 + 15] : 0.0);  // (fixed rows that ride in a full-range task count their pairs there)
     }
     stamp(1, i);
 
@@ -609,7 +619,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
       double* const ES = WS + ((nE * nE + 1) & ~1);
       if (A.es) {
         for (int t0 = 0; t0 < 4 * nE * nE; t0 += P2_T) {
-          const int t = t0 + tid_p;
+          const int t = t0 + ((tid_p >= 192) ? tid_p - 192 : tid_p + P2_T - 192);  // from wavefront 3 on: 0 and 1 build W meanwhile
           const bool okt = t < 4 * nE * nE;
           const int pair = okt ? (t >> 2) : 0, q = t & 3;
           const int a = nF + pair / nE, b = nF + pair - (pair / nE) * nE;
@@ -788,7 +798,6 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
       }
       lds_barrier();
       stamp(12, i);
-      if (r == 0 && !(A.dbg & 256)) dma_table(TI, i_next);  // every wavefront is past its last read of the current image
       if (!(A.dbg & 1)) {
         // this wavefront's four rows of the pass: row map, then all eight values, then the stores -- one LDS round trip each
         // (3N <= 126: two stores per lane and row)
@@ -825,6 +834,9 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
           }
         }
       }
+      // every wavefront is past its last read of the current image since the barrier of pass 0; requested here, behind the
+      // stores of two passes (in front of them its reads delayed the stores), it has passes 2 and 3 to land
+      if (r == 1 && !(A.dbg & 256)) dma_table(TI, i_next);
       stamp(13, i);
     }
   }
@@ -906,8 +918,18 @@ static int perm2_plan(gdml_ctx* ctx) {
       tasks.push_back(t);
     }
   };
-  add_rows(nF, N, 0, N, 0);
-  add_rows(0, nF, nF, N, 1);
+  // the fixed rows beyond a multiple of 8 would be a nearly empty task of their own: if the last full-range task has spare row
+  // slots they ride there (computed like a moved row: every partner, per permutation -- the same sums)
+  int n_extra = 0;
+  {
+    int lgE = 0;
+    while (lgE < 3 && ((N + (1 << lgE) - 1) >> lgE) > ctx_opt_i(ctx, "asm.perm2_chunk", 12)) ++lgE;
+    const int rows_per = 8 >> lgE, nE_ = N - nF;
+    const int spare = (rows_per - nE_ % rows_per) % rows_per;
+    if (nF > 0 && nF % 8 != 0 && nF % 8 <= spare) n_extra = nF % 8;
+  }
+  add_rows(nF - n_extra, N, 0, N, 0);
+  add_rows(0, nF - n_extra, nF, N, 1);
   // tasks to wavefronts, longest first onto the least loaded one (cost ~ trips of two entries + the chunk reduction); in post
   // mode the wavefronts whose tile group has moved rows and moved columns start with the single terms of 8 permutations
   const bool post_plan = nF >= 2 && N - nF <= 16 && ctx_opt_i(ctx, "asm.perm2_post", 1);
@@ -915,7 +937,8 @@ static int perm2_plan(gdml_ctx* ctx) {
   for (int w = 0; w < P2_NW; ++w) {
     const int gs = w / 3, gt = w % 3;
     const bool live = 16 * gs < N && 16 * gt < N;
-    load[w] = (post_plan && live && 16 * gs + 15 >= nF && 16 * gt + 15 >= nF) ? 11.0 : 0.0;
+    // (only without es mode that wavefront still runs per-permutation single terms during the V phase)
+    load[w] = (post_plan && !ctx_opt_i(ctx, "asm.perm2_es", 1) && live && 16 * gs + 15 >= nF && 16 * gt + 15 >= nF) ? 11.0 : 0.0;
   }
   auto cost = [&](const Task& t) { return 0.5 * (((t.me - t.mb + (1 << t.lg) - 1) >> t.lg) + 1) + 1.0 + 0.7 * t.lg; };
   std::stable_sort(tasks.begin(), tasks.end(), [&](const Task& a, const Task& b) { return cost(a) > cost(b); });
@@ -983,6 +1006,7 @@ static int perm2_plan(gdml_ctx* ctx) {
     blob.insert(blob.end(), plist.begin(), plist.end());
   }
   ts.p2_nF = nF;
+  ts.p2_nFb = nF - n_extra;
   ts.p2_ntasks = (int)tasks.size();
   GDML_TRY(ctx_alloc(ctx, (void**)&ts.p2, (int64_t)blob.size()));
   HIP_CHECK(ctx, hipMemcpyAsync(ts.p2, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -1010,7 +1034,7 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
   A.TP = ts.p2_TP; A.blob = ts.p2;
   A.o_src = ts.p2_o[0]; A.o_sigma = ts.p2_o[1]; A.o_tasks = ts.p2_o[2];
   A.n_tasks = ts.p2_ntasks;
-  A.M = ts.M; A.N = N; A.P = P; A.nF = ts.p2_nF; A.sig = sig;
+  A.M = ts.M; A.N = N; A.P = P; A.nF = ts.p2_nF; A.nFb = ts.p2_nFb; A.sig = sig;
   A.j0 = j0; A.n_j = n_j; A.col0 = col0; A.i_beg = i_beg; A.i_end = i_end;
   A.lower = lower; A.lam = lam; A.K = K; A.ld = ld;
   A.dbg = ctx_opt_i(ctx, "asm.perm2_debug", 0);
