@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
           // per trip (an LDS round trip costs several hundred cycles here: fewer, fuller trips).
           auto vloop = [&](auto DGc) {
             constexpr bool WITH_DG = decltype(DGc)::value;
-            constexpr int NB = 3;
+            constexpr int NB = WITH_DG ? 2 : 3;
             int mi[NB];
 #pragma unroll
             for (int t = 0; t < NB; ++t) mi[t] = pinv_v[mclamp(m0 + t)];
