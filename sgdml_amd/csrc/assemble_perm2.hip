@@ -154,6 +154,9 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   dma_table(TJ, jpt);
   dma_table(TI, i_lo);
 
+  // this wavefront's V-phase tasks (stored wavefront by wavefront): [t_first, t_last), read once (scalar registers)
+  const int t_first = __builtin_amdgcn_readfirstlane((int)A.blob[A.o_tasks + 16 * A.n_tasks + w]);
+  const int t_last = __builtin_amdgcn_readfirstlane((int)A.blob[A.o_tasks + 16 * A.n_tasks + w + 1]);
   // ---- the tile group (gs, gt) of this wavefront in the O phase.  What a lane derives from its index (column atom, row atoms)
   // is recomputed inside each phase from an opaque copy of the index: kept alive across the phases these values (and the
   // lane masks of their validity flags) push loop invariants of the inner loops out to scratch.
@@ -339,9 +342,8 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
         const int p = g0 + (pl < npg ? pl : npg - 1);
         const uint8_t* const pin = pinvS + p * N;
         double nnl = 0.0;
-        const uint8_t* const wt_off = reinterpret_cast<const uint8_t*>(taskS + 4 * A.n_tasks);  // tasks are stored wavefront by wavefront
-        const int t_end = (A.dbg & 2) ? 0 : __builtin_amdgcn_readfirstlane((int)wt_off[w + 1]);
-        for (int t = __builtin_amdgcn_readfirstlane((int)wt_off[w]); t < t_end; ++t) {
+        const int t_end = (A.dbg & 2) ? 0 : t_last;
+        for (int t = t_first; t < t_end; ++t) {
           const uint32_t d0 = __builtin_amdgcn_readfirstlane(taskS[4 * t]), d1 = __builtin_amdgcn_readfirstlane(taskS[4 * t + 1]),
                          d2w = __builtin_amdgcn_readfirstlane(taskS[4 * t + 2]);  // wave-uniform: scalar registers
           const int mb = d2w & 0xff, me = (d2w >> 8) & 0xff, lg = (d2w >> 16) & 0xff;

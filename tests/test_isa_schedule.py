@@ -149,3 +149,34 @@ def test_predict_kernel_requests_table_rows_ahead():
     first_math = next(i for i, l in enumerate(body) if l.startswith(('v_rsq_f64', 'v_sqrt_f64', 'v_exp_f32', 'v_ldexp_f64')))
     loads_ahead = sum(1 for l in body[:first_math] if l.startswith('global_load'))
     assert loads_ahead >= 16, loads_ahead  # X and J alpha of two rows (KPL = 4: 8 loads per row)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_perm2_kernel_keeps_scratch_out_of_its_store_passes_and_inner_loops():
+    """assemble_perm2_kernel (csrc/assemble_perm2.hip) holds 72 of its 168 VGPRs as accumulators; what spills decides its speed:
+    a scratch reload between two global stores waits for the stores (vmcnt counts both), a reload in a per-group phase costs a memory
+    round trip, and LDS reads the compiler serialises ('read one value, wait, use it') cost 400-700 cycles each under load
+    (profiles/r05_assemble_perm2.txt: 125 -> 17 scratch instructions was 18.9 -> 17.5 ms; three-entry trips for every row type spill and
+    were 16.4 -> 19.2 ms).  Checked on the compiled production kernel: few scratch instructions overall, at most three behind the first
+    row store (today: two accumulator tuples reloaded for a later pass, the table pointer of the image request), LDS-only barriers between the row passes, and no chain of three or more single-read LDS round trips."""
+    ins = _kernel(_assembly('assemble_perm2'), '_Z21assemble_perm2_kernelILb0EEv9Perm2Args')
+    scratch = [k for k, l in enumerate(ins) if l.startswith('scratch_')]
+    assert len(scratch) <= 45, len(scratch)
+    stores = [k for k, l in enumerate(ins) if l.startswith('global_store')]
+    assert stores, 'no row stores found'
+    assert len([k for k in scratch if k > stores[0]]) <= 3, 'scratch traffic between / behind the row stores'
+    # the barriers between the row passes must not drain the stores: the instruction in front of an s_barrier behind the first
+    # store is `s_waitcnt lgkmcnt(0)` (lds_barrier()), never a vmcnt wait
+    for k, l in enumerate(ins):
+        if l.startswith('s_barrier') and k > stores[0]:
+            assert ins[k - 1].startswith('s_waitcnt') and 'vmcnt' not in ins[k - 1], (k, ins[k - 1])
+    # serialised LDS round trips: runs of `one LDS read -> s_waitcnt lgkmcnt(0)`
+    run, n_reads, worst = 0, 0, 0
+    for l in ins:
+        if l.startswith('ds_read') or l.startswith('ds_bpermute'):
+            n_reads += 1
+        elif l.startswith('s_waitcnt') and 'lgkmcnt(0)' in l:
+            run = run + 1 if n_reads == 1 else 0
+            worst = max(worst, run)
+            n_reads = 0
+    assert worst < 3, worst
