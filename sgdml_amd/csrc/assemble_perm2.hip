@@ -876,7 +876,17 @@ bool assemble_perm2_applicable(const gdml_ctx* ctx) {
 // Plan of the group: internal numbering (fixed atoms first), permutations in it, V-phase tasks.  Built once per training set.
 static int perm2_plan(gdml_ctx* ctx) {
   TrainSet& ts = ctx->ts;
-  if (ts.p2) return GDML_OK;
+  // the plan depends on three options; they are read at the point of use like every other one: a changed value rebuilds it
+  const int key = 1 + ctx_opt_i(ctx, "asm.perm2_split", 1) + 2 * ctx_opt_i(ctx, "asm.perm2_post", 1) + 4 * ctx_opt_i(ctx, "asm.perm2_es", 1) +
+                  8 * ctx_opt_i(ctx, "asm.perm2_chunk", 12);
+  if (ts.p2 && ts.p2_key == key) return GDML_OK;
+  if (ts.p2) {
+    GDML_TRY(ctx_free(ctx, ts.p2));
+    GDML_TRY(ctx_free(ctx, ts.p2_TP));
+    ts.p2 = nullptr;
+    ts.p2_TP = nullptr;
+  }
+  ts.p2_key = key;
   const int N = ts.N, P = ts.P;
   std::vector<int> moved(N, 0);
   for (int p = 0; p < P; ++p)

@@ -55,7 +55,7 @@ struct TrainSet {
   double* TS = nullptr;      // (M,pitch) packed per-point image [GD | XF | x | 0-pad] staged by assemble_strip.hip
   uint8_t* p2 = nullptr;     // plan of assemble_perm2.hip (internal atom numbering, byte permutations, V-phase tasks)
   double* p2_TP = nullptr;   // (M,N,N,4) packed per-point tables in that numbering
-  int p2_o[4] = {0, 0, 0, 0}, p2_nF = 0, p2_nFb = 0, p2_ntasks = 0, p2_npairs = 0;
+  int p2_o[4] = {0, 0, 0, 0}, p2_nF = 0, p2_nFb = 0, p2_ntasks = 0, p2_npairs = 0, p2_key = 0;
   std::vector<int32_t> h_tp, h_perm, h_pinv;
 };
 

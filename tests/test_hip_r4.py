@@ -105,6 +105,28 @@ def test_assembly_beyond_128_atoms(N, kind):
     _check_assembly_modes(N, 2, kind, [{}, {'asm.perm_fast_store': 0}, {'asm.perm_i_chunk': 2}, {'asm.perm_pg': 1}])
 
 
+def test_assemble_perm2_options_apply_to_the_next_call():
+    """Options are read at the point of use (include/gdml_hip.h): asm.perm2_split / _chunk / _post / _es set between two
+    calls on ONE context rebuild the kernel's plan (atom renumbering, tasks, tables) instead of being ignored."""
+    from sgdml_amd import _lib
+
+    xo, go, tp, sig, Ko, KoE = _oracle_case(42, 3, 'c3^3')
+    scale = np.abs(Ko).max()
+    c = _lib.Context()
+    try:
+        for k, v in {'asm.wave': 0, 'asm.strip': 0, 'asm.pts': 0}.items():
+            c.set_option(k, v)
+        c.train_upload(xo, go, tp)
+        for opts in [{}, {'asm.perm2_split': 0}, {'asm.perm2_split': 1, 'asm.perm2_chunk': 5}, {'asm.perm2_post': 0}, {'asm.perm2_post': 1, 'asm.perm2_es': 0},
+                     {'asm.perm2_es': 1, 'asm.perm2_chunk': 12}]:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            K = c.assemble_K(sig, False, to_host=True)
+            assert np.abs(K - Ko).max() <= 1e-12 * scale, opts
+    finally:
+        c.close()
+
+
 def _check_assembly_modes(N, M, kind, option_sets):
     from sgdml_amd import _lib
 
