@@ -118,7 +118,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *                         (csrc/assemble_perm2.hip); asm.perm2_split (1; 0 = every pair per permutation), asm.perm2_post (1: single and diagonal
  *                         terms that involve an atom no permutation moves summed over the permutations once per block; 0 = per permutation), asm.perm2_ed (1: diagonal terms of
  *                         moved atoms summed per (row atom, column atom) pair by idle lanes; needs asm.perm2_post), asm.perm2_es (1: single terms of
- *                         moved x moved blocks summed over the permutations once per block by four lanes per block; needs asm.perm2_post), asm.perm2_chunk (12) pair
+ *                         moved x moved blocks summed over the permutations once per block by four lanes per block; needs asm.perm2_post), asm.perm2_direct (1: finished rows stored straight
+ *                         from the registers, 24 bytes per lane and row; 0 = through LDS in four passes of full-row stores), asm.perm2_chunk (12) pair
  *                         entries per lane and task, asm.perm2_i_chunk (16) row points per workgroup, asm.perm2_debug (0)
  *                         timing-only ablation mask (results are wrong when set)
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)

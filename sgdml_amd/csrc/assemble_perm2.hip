@@ -83,7 +83,7 @@ struct Perm2Args {
             // 128 no staging of the rows, 256 no image prefetch
 };
 
-template <bool TRACE>
+template <bool TRACE, bool DIRECT>
 __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = A.N, N3 = 3 * N, NN = N * N, P = A.P, nF = A.nF;
@@ -782,12 +782,44 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
       }
     }
     stamp(10, i);
-    if (A.post) __syncthreads();  // the tables are read: the staging below overwrites them
+    if (A.post || DIRECT) __syncthreads();  // the tables and the image are read: staging / the next image may overwrite them
     stamp(11, i);
 
-    // ================= rows out: four passes (register r of every lane = 12 row atoms = 36 rows) through LDS
     const int sig_b = sigma[cbc];
     const int64_t i_next = (i + 1 < i_hi) ? i + 1 : i;
+    if (DIRECT) {
+      // ================= rows out, straight from the registers: a lane holds, for each of its four row atoms and three
+      // components, three consecutive doubles of one row (columns 3 sigma(b) ...).  36 eight-byte stores per lane that the L2
+      // merges into whole lines -- against four LDS staging passes with seven barriers for full-row stores: this kernel is nowhere
+      // near the store bandwidth, the passes were 15 % of a block.
+      if (!(A.dbg & 256)) dma_table(TI, i_next);
+      int sa[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sa[r] = sigma[arc[r]];
+      if (!(A.dbg & 1)) {
+        const int64_t cbase = A.col0 + jv * N3 + 3 * sig_b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (group_live && cb_ok && 16 * gs + g + 4 * r < N) {
+#pragma unroll
+            for (int al = 0; al < 3; ++al) {
+              const int64_t grow = i * N3 + 3 * sa[r] + al;
+              double* dst = A.K + (grow - A.i_beg * N3) * A.ld + cbase;
+              const int64_t dcol = grow - cbase;  // 0 .. 2 where the matrix diagonal crosses these three columns
+#pragma unroll
+              for (int be = 0; be < 3; ++be) {
+                const double o = lower ? -acc[al][be][r] : acc[al][be][r];
+                dst[be] = o + ((lower && dcol == be) ? A.lam : 0.0);
+              }
+            }
+          }
+        }
+      }
+      stamp(13, i);
+      continue;
+    }
+
+    // ================= rows out: four passes (register r of every lane = 12 row atoms = 36 rows) through LDS
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (r > 0) lds_barrier();  // the previous pass is read out of the staging buffer (its stores may still be on their way)
@@ -1083,8 +1115,11 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
   while (i_chunk > 2 && n_j * ((n_i + i_chunk - 1) / i_chunk) < 1024) i_chunk >>= 1;
   A.i_chunk = i_chunk;
   dim3 grid((unsigned)n_j, (unsigned)((n_i + i_chunk - 1) / i_chunk));
-  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool direct = ctx_opt_i(ctx, "asm.perm2_direct", 1) != 0;
+  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   unsigned long long* d_trace = nullptr;
   if (A.dbg & 1024) {
     GDML_TRY(ctx_alloc(ctx, (void**)&d_trace, 1024 * 8));
@@ -1092,8 +1127,10 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
     A.trace = d_trace;
   }
   const int slot = ktime_begin(ctx);
-  if (d_trace) hipLaunchKernelGGL(assemble_perm2_kernel<true>, grid, dim3(P2_T), lds, ctx->stream, A);
-  else hipLaunchKernelGGL(assemble_perm2_kernel<false>, grid, dim3(P2_T), lds, ctx->stream, A);
+  if (d_trace && direct) hipLaunchKernelGGL((assemble_perm2_kernel<true, true>), grid, dim3(P2_T), lds, ctx->stream, A);
+  else if (d_trace) hipLaunchKernelGGL((assemble_perm2_kernel<true, false>), grid, dim3(P2_T), lds, ctx->stream, A);
+  else if (direct) hipLaunchKernelGGL((assemble_perm2_kernel<false, true>), grid, dim3(P2_T), lds, ctx->stream, A);
+  else hipLaunchKernelGGL((assemble_perm2_kernel<false, false>), grid, dim3(P2_T), lds, ctx->stream, A);
   if (d_trace) {  // phase stamps of one workgroup: id, shader clock (100 MHz), difference to the previous stamp
     std::vector<unsigned long long> h(1024);
     HIP_CHECK(ctx, hipMemcpyAsync(h.data(), d_trace, 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));

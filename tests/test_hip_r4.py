@@ -93,7 +93,7 @@ def test_assemble_perm2_mode_matrix(N, kind):
     point ranges) run on it, the others on assemble_perm_kernel; without the split, without the once-per-block pass, short and
     unchunked rows, two row points per workgroup.  1e-12 of max|K| against the independent restatement (train.py:97-302)."""
     force = {'asm.perm2_min_n': 25, 'asm.perm2_min_p': 2}
-    sets = [{}, {'asm.perm2_split': 0}, {'asm.perm2_post': 0}, {'asm.perm2_ed': 0}, {'asm.perm2_es': 0}, {'asm.perm2_chunk': 5}, {'asm.perm2_chunk': 100}, {'asm.perm2_i_chunk': 2}]
+    sets = [{}, {'asm.perm2_split': 0}, {'asm.perm2_post': 0}, {'asm.perm2_ed': 0}, {'asm.perm2_es': 0}, {'asm.perm2_direct': 0}, {'asm.perm2_chunk': 5}, {'asm.perm2_chunk': 100}, {'asm.perm2_i_chunk': 2}]
     _check_assembly_modes(N, 4 if N < 30 else 3, kind, [dict(o, **force) for o in sets])
 
 
@@ -118,7 +118,7 @@ def test_assemble_perm2_options_apply_to_the_next_call():
             c.set_option(k, v)
         c.train_upload(xo, go, tp)
         for opts in [{}, {'asm.perm2_split': 0}, {'asm.perm2_split': 1, 'asm.perm2_chunk': 5}, {'asm.perm2_post': 0}, {'asm.perm2_post': 1, 'asm.perm2_es': 0},
-                     {'asm.perm2_es': 1, 'asm.perm2_chunk': 12}]:
+                     {'asm.perm2_es': 1, 'asm.perm2_chunk': 12}, {'asm.perm2_direct': 0}]:
             for k, v in opts.items():
                 c.set_option(k, v)
             K = c.assemble_K(sig, False, to_host=True)

@@ -27,7 +27,7 @@ def do_check():
                        (42, 11, 'c3xc2')]:
         ok &= check_case(N, M, kind, {})
     for N, M, kind in [(36, 3, 'c3^3'), (42, 3, 'c3^3')]:
-        for opts in [{'asm.perm2_split': 0}, {'asm.perm2_post': 0}, {'asm.perm2_ed': 0}, {'asm.perm2_es': 0}, {'asm.perm2_chunk': 5}, {'asm.perm2_chunk': 100}, {'asm.perm2_i_chunk': 2}, {'asm.perm2': 0}]:
+        for opts in [{'asm.perm2_split': 0}, {'asm.perm2_post': 0}, {'asm.perm2_ed': 0}, {'asm.perm2_es': 0}, {'asm.perm2_direct': 0}, {'asm.perm2_chunk': 5}, {'asm.perm2_chunk': 100}, {'asm.perm2_i_chunk': 2}, {'asm.perm2': 0}]:
             ok &= check_case(N, M, kind, opts)
     print('ALL OK' if ok else 'SOME FAILED')
     return ok
@@ -35,7 +35,7 @@ def do_check():
 
 def do_time(full):
     for lower in (False, True):
-        for opts in [{'asm.perm2': 0}, {}, {'asm.perm2_ed': 0}, {'asm.perm2_es': 0}, {'asm.perm2_post': 0}, {'asm.perm2_split': 0}]:
+        for opts in [{'asm.perm2': 0}, {}, {'asm.perm2_direct': 0}, {'asm.perm2_ed': 0}, {'asm.perm2_es': 0}, {'asm.perm2_post': 0}, {'asm.perm2_split': 0}]:
             time_case(42, 300, 'c3^3', opts, lower=lower, label='perm2')
     for opts in [{'asm.perm2_debug': 1}, {'asm.perm2_debug': 2}, {'asm.perm2_debug': 4}, {'asm.perm2_debug': 8}, {'asm.perm2_debug': 15},
                  {'asm.perm2_debug': 15 + 64}, {'asm.perm2_debug': 511}]:
@@ -44,7 +44,7 @@ def do_time(full):
         time_case(N, M, kind, {'asm.perm2': 0}, label='perm2')
         time_case(N, M, kind, {}, label='perm2')
     if full:
-        for opts in [{'asm.perm2': 0}, {}]:
+        for opts in [{'asm.perm2': 0}, {'asm.perm2_direct': 0}, {}]:
             time_case(42, 1000, 'c3^3', opts, lower=True, reps=3, label='perm2')
 
 
