@@ -5,7 +5,7 @@
 //   for a column atom b and its partner m' (b != m'),  a' = pi^-1 b,  mi = pi^-1 m',  d = x_i(a', mi) - x_j(b, m'):
 //     |d_p|^2 += d^2,   u_p[b] += d G_j(b, m'),   v_p[a'] += d G_i(a', mi),   dg_p[b] += G_i(a', mi) (x) G_j(b, m')
 //   S_p[(a,.),(b,.)] = G_i(a, pi^-1 b) (x) G_j(b, pi a)  for pi a != b (the tables are 0 on their diagonals),  dg_p[b] for a = pi^-1 b.
-// assemble_perm_kernel runs this at 0.05 of HBM / 0.11 of the fp64 VALU model at N = 42, P = 27: 256-VGPR wavefronts, one
+// assemble_perm_kernel runs this at 0.045 of HBM / 0.115 of the fp64 VALU model at N = 42, P = 27 (this kernel: 0.090 / 0.23, 2.0 x): 256-VGPR wavefronts, one
 // workgroup per CU, every operand of the 9 N^2 P outer-product and the 9 N^2 P single-term multiply-adds read from LDS.  Here:
 //   * atoms are renumbered, the ones NO permutation moves (F) first.  Descriptor entries between two such atoms contribute the
 //     same to every permutation: they are summed once per block (base pass: u0, v0, dg0, nn0), a permutation adds only the
@@ -18,7 +18,8 @@
 //     single terms are added to the same registers: per (row atom, column atom, permutation) two 24-byte LDS reads for 9
 //     multiply-adds -- and only in tile groups that contain a moved atom; tile groups of fixed atoms get them once with sum_p cn_p;
 //   * one workgroup = 9 wavefronts = the 3 x 3 tile groups of a (48 x 48)-atom block; it owns a column point j (its table
-//     stays in LDS) and walks over row points i; finished rows go through LDS so that every store writes whole rows.
+//     stays in LDS) and walks over row points i; finished rows are stored straight from the registers, 24 bytes per lane and
+//     row (DIRECT; the variant that stages them through LDS for full-row stores is kept as the A/B: 6 % slower, seven more barriers).
 // Everything else (index lists, energy-constraint rows, block-cyclic layouts, other sizes) stays on assemble_perm_kernel.
 // Arithmetic pinned on the CPU: tools/perm2_emulate.py (run by the CPU test suite).
 #include "common.h"
