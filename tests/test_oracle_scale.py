@@ -231,5 +231,5 @@ def test_perm2_kernel_data_flow_matches_the_oracle():
     perms = np.array([idt, r1, r1[r1], r2, r2[r1], r2[r1[r1]], r2[r2], r2[r2][r1], r2[r2][r1[r1]]])
     sigma, nF, permI, pinvI = plan(perms)
     assert nF == 14 and sorted(sigma[nF:]) == [4, 5, 6, 11, 12, 13]
-    for kw in [{}, {'split': False}, {'nchk_e': 2}, {'post': True}]:
+    for kw in [{}, {'split': False}, {'nchk_e': 2}, {'post': True}, {'post': True, 'es': True, 'ed': True, 'n_extra': 3}]:
         assert check(20, perms, **kw) <= 1e-14, kw

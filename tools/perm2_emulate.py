@@ -11,7 +11,10 @@ What the kernel does differently from assemble_perm_kernel (train.py:97-302, tor
     owns whole 3x3 atom blocks: tile group (s, t) = 16 row atoms x 16 column atoms, its 9 tiles are the (al, be) components;
     lane l: column atom 16 t + (l & 15), row atoms 16 s + (l >> 4) + 4 r;
   * the single terms -c_p G_i(a, pi^-1 b) (x) G_j(b, pi a) are added per permutation only in tile groups that contain a moved atom;
-    tile groups of fixed atoms only get them once with sum_p c_p.
+    tile groups of fixed atoms only get them once with sum_p c_p;
+  * post: everything a fixed atom takes part in summed over the permutations first (W[x][y] = sum of c_p with pi_p x = y, A1, B1);
+    es: the moved x moved single terms once per block as four partial sums; ed: the diagonal terms of moved atoms summed per (row,
+    column) pair over a group of 8 permutations; n_extra: fixed rows that ride in full-range tasks (their pairs leave the base norm).
   python tools/perm2_emulate.py"""
 import os
 import sys
@@ -39,7 +42,7 @@ def plan(perms):
     return sigma, nF, permI, pinvI
 
 
-def block_perm2(xi, gi, xj, gj, perms, sig, nchk_e=4, split=True, post=False):
+def block_perm2(xi, gi, xj, gj, perms, sig, nchk_e=4, split=True, post=False, es=False, ed=False, n_extra=0):
     P, N = perms.shape
     sigma, nF, permI, pinvI = plan(perms)
     if not split:
@@ -53,23 +56,26 @@ def block_perm2(xi, gi, xj, gj, perms, sig, nchk_e=4, split=True, post=False):
     XJ, GJ = XFj[np.ix_(sigma, sigma)], GSj[np.ix_(sigma, sigma)]
     # ---- base pass: pairs of fixed atoms (identity action)
     u0 = np.zeros((N, 3)); v0 = np.zeros((N, 3)); dg0 = np.zeros((N, 3, 3)); nn0 = 0.0
+    nFb = nF_eff - n_extra   # the last n_extra fixed rows ride in full-range tasks: their pairs are counted there, not in nn0
     for b in range(nF_eff):
         for m in range(nF_eff):
             d = XI[b, m] - XJ[b, m]
-            nn0 += d * d
+            if b < nFb:
+                nn0 += d * d
             u0[b] += d * GJ[b, m]
             v0[b] += d * GI[b, m]
             dg0[b] += np.outer(GI[b, m], GJ[b, m])
     acc = np.zeros((N, N, 3, 3))
     ctot = 0.0
     cns = []
+    ED = {}
     NG = (N + 15) // 16
     for p in range(P):
         pin = pinvI[p]
         U = np.zeros((N, 3)); V = np.zeros((N, 3)); DG = np.zeros((N, 3, 3)); nn = nn0
         for b in range(N):
             ap = pin[b]
-            fixed_row = b < nF_eff
+            fixed_row = b < nFb
             m0 = nF_eff if fixed_row else 0
             nchk = 1 if fixed_row else nchk_e
             cnt = N - m0
@@ -101,11 +107,20 @@ def block_perm2(xi, gi, xj, gj, perms, sig, nchk_e=4, split=True, post=False):
         if post:
             cns.append(cn)
             # per permutation only the blocks of two MOVED atoms: single terms and their diagonal terms
-            for a in range(nF_eff, N):
+            if not es:
+                for a in range(nF_eff, N):
+                    for b in range(nF_eff, N):
+                        acc[a, b] += cn * np.outer(GI[a, pin[b]], GJ[b, permI[p][a]])
+            if ed:   # summed per (row atom, column atom) pair over the group of 8 permutations, added one group late
                 for b in range(nF_eff, N):
-                    acc[a, b] += cn * np.outer(GI[a, pin[b]], GJ[b, permI[p][a]])
-            for b in range(nF_eff, N):
-                acc[pin[b], b] += cn * DG[b]
+                    ED[(pin[b], b)] = ED.get((pin[b], b), 0.0) + cn * DG[b]
+                if p % 8 == 7 or p == P - 1:
+                    for (a, b), val in ED.items():
+                        acc[a, b] += val
+                    ED.clear()
+            else:
+                for b in range(nF_eff, N):
+                    acc[pin[b], b] += cn * DG[b]
             continue
         for s in range(NG):
             for t in range(NG):
@@ -136,6 +151,13 @@ def block_perm2(xi, gi, xj, gj, perms, sig, nchk_e=4, split=True, post=False):
                 for e2 in E:
                     A1[a, e] += GI[a, e2] * W[e2, e]
                     B1[a, e] += GJ[a, e2] * W[e, e2]
+        if es:   # single terms of moved x moved blocks: four partial sums over p = q, q + 4, ... added inside the quad
+            for a in range(nF_eff, N):
+                for b in range(nF_eff, N):
+                    part = np.zeros((4, 3, 3))
+                    for p in range(P):
+                        part[p % 4] += cns[p] * np.outer(GI[a, pinvI[p][b]], GJ[b, permI[p][a]])
+                    acc[a, b] += (part[0] + part[1]) + (part[2] + part[3])
         for a in range(N):
             for b in range(N):
                 fa, fb = a < nF_eff, b < nF_eff
@@ -181,6 +203,6 @@ if __name__ == '__main__':
         rng = np.random.default_rng(N)
         rel = rng.permutation(N)
         perms = np.argsort(rel)[perms[:, rel]]
-        for kw in [{}, {'split': False}, {'nchk_e': 8}, {'post': True}]:
+        for kw in [{}, {'split': False}, {'nchk_e': 8}, {'post': True}, {'post': True, 'es': True, 'ed': True, 'n_extra': 1}]:
             print('N=%-3d P=%-2d %-6s %-18s max |K_emulated - K_oracle| / max|K| = %.1e' % (N, len(perms), kind, kw, check(N, perms, **kw)),
                   flush=True)
