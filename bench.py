@@ -379,6 +379,19 @@ def perm_group(n_atoms, kind):
     return np.array(perms)
 
 
+def assembly_kernel_name(n_atoms, n_perms):
+    """Which assembly kernel the library dispatches a dense (all columns / lower form) build of this shape to -- a label for the
+    per-config `roofline_assemble` entries; the rule itself lives in csrc/assemble.hip, assemble_perm.hip, assemble_perm2.hip
+    (tests/test_host_policy_cpu.py checks that the two agree)."""
+    if n_perms == 1 and n_atoms <= 21:
+        return 'assemble_strip_kernel' if n_atoms >= 11 else 'assemble_wave_kernel'
+    if n_perms > 1 and 8 <= n_atoms <= 24:
+        return 'assemble_pts_kernel'
+    if n_atoms <= 42 and ((n_perms >= 16 and n_atoms >= 36) or (n_perms >= 6 and n_atoms >= 40)):
+        return 'assemble_perm2_kernel (fp64-MFMA outer products, fixed-atom split; lower blocks)'
+    return 'assemble_perm_kernel'
+
+
 def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', sig=20, lam=1e-10, max_memory=None, seed=3,
                  traj=None, n_inducing=None, dist_backend=None, options=None):
     """One BASELINE configuration shape run to a SOLUTION through the drop-in GDMLTrain.train (sgdml/train.py:836-1088):
@@ -438,16 +451,7 @@ def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', si
             out['wall_minus_phases_s'] = wall - sum(ph.values()) / 1e3  # host work + allocation outside the kernels
         a_ms, a_n, a_by = ctx.kernel_stat('assemble')
         if a_ms > 0 and solver == 'analytic':
-            n_p = int(perms.shape[0])
-            # which assembly kernel the library dispatches this shape to (csrc/assemble.hip, assemble_perm.hip, assemble_perm2.hip)
-            if n_p == 1 and n_atoms <= 21:
-                a_kernel = 'assemble_strip_kernel' if n_atoms >= 11 else 'assemble_wave_kernel'
-            elif n_p > 1 and 8 <= n_atoms <= 24:
-                a_kernel = 'assemble_pts_kernel'
-            elif n_atoms <= 42 and ((n_p >= 16 and n_atoms >= 36) or (n_p >= 6 and n_atoms >= 40)):
-                a_kernel = 'assemble_perm2_kernel (fp64-MFMA outer products, fixed-atom split; lower blocks)'
-            else:
-                a_kernel = 'assemble_perm_kernel'
+            a_kernel = assembly_kernel_name(n_atoms, int(perms.shape[0]))
             out['roofline_assemble'] = {'kernel': a_kernel, 'bound': 'hbm', 'achieved': a_by / (a_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                         'frac': a_by / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'ms': a_ms / a_n,
                                         'algorithmic_bytes_per_launch': a_by / a_n,

@@ -299,3 +299,31 @@ def test_descriptors_are_reused_across_a_sigma_sweep(trainer):
                              'md5_train': 'm', 'idxs_valid': np.arange(0), 'md5_valid': 'm', 'type': 't', 'code_version': '1.0.3'},
                             'analytic', d[0], d[1], np.arange(10), 1.0, np.zeros(12 * 15))
     assert model['R_desc'].flags.writeable and np.array_equal(model['R_desc'], d[0].T)
+
+
+def test_bench_labels_follow_the_library_dispatch_of_the_perm2_kernel():
+    """bench.py names the assembly kernel of a configuration in its `roofline_assemble` entries; the dispatch itself is C++
+    (csrc/assemble_perm2.hip assemble_perm2_applicable: N <= 42, P >= asm.perm2_min_p, N >= asm.perm2_min_n, groups below 16
+    elements four atoms later).  Both are read here so that one cannot move without the other."""
+    import re
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'sgdml_amd', 'csrc', 'assemble_perm2.hip')).read()
+    min_n = int(re.search(r'"asm\.perm2_min_n",\s*(\d+)\)', src).group(1))
+    min_p = int(re.search(r'"asm\.perm2_min_p",\s*(\d+)\)', src).group(1))
+    max_n = int(re.search(r'constexpr int P2_MAXN = (\d+);', src).group(1))
+    assert 'ts.P >= 16 || ts.N >= min_n + 4' in src
+
+    def lib_rule(n, p):
+        if p < min_p or n < min_n or n > max_n:
+            return False
+        return p >= 16 or n >= min_n + 4
+
+    sys.path.insert(0, root)
+    import bench
+
+    for n in range(25, 50):
+        for p in (1, 2, 6, 12, 16, 27, 64):
+            assert bench.assembly_kernel_name(n, p).startswith('assemble_perm2_kernel') == lib_rule(n, p), (n, p)
+    assert bench.assembly_kernel_name(21, 1).startswith('assemble_strip') and bench.assembly_kernel_name(100, 1) == 'assemble_perm_kernel'
