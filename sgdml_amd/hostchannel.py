@@ -10,20 +10,160 @@ sockets: rank 0 listens, the other ranks connect (star), every operation is gath
 
 Rendezvous from the launcher's environment (torch.distributed.run, mpirun wrappers, a shell loop -- anything that sets them):
 RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT.  The channel does NOT use MASTER_PORT itself (torch.distributed.run keeps its own
-store there); it derives a port from it (GDML_CHANNEL_PORT overrides), probes a short sequence of ports on collision and
-checks a magic word on connect, so a foreign service on a port is skipped rather than talked to.
+store there); it derives a port from it (GDML_CHANNEL_PORT overrides) and probes a short sequence of ports on collision.
+
+Who may talk on that port (round 6): every connection is authenticated in both directions by an HMAC-SHA256
+challenge / response over a per-job token -- GDML_CHANNEL_TOKEN when the launcher sets one (bench.py's own launcher and the
+test launchers draw 32 random bytes per job with `new_token`); otherwise a digest of (uid, MASTER_ADDR, MASTER_PORT,
+TORCHELASTIC_RUN_ID), which keeps foreign services and other jobs out but is only as secret as those values: set the
+token for anything that is not a single trusted node.  A connection that does not complete the handshake within 2 s is
+dropped (it cannot hold up the accept loop); a claimed rank outside 1 .. world-1 or already registered is refused.
+Nothing received is ever unpickled: messages are a small tagged encoding of None / bool / int / float / str / bytes /
+tuple / list / dict / ndarray (`encode` / `decode`).
 The reference has no distributed code at all.
 """
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import time
 
 import numpy as np
 
-_MAGIC = b'GDMLCHN1'
+_MAGIC = b'GDMLCHN2'
 _PORT_TRIES = 16
+_HANDSHAKE_TIMEOUT = 2.0
+_MAX_MSG = 1 << 36
+
+
+def job_token():
+    """Per-job secret of the handshake (bytes)."""
+    env = os.environ.get('GDML_CHANNEL_TOKEN')
+    if env:
+        return env.encode()
+    ident = '%d:%s:%s:%s' % (os.getuid(), os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '29500'),
+                             os.environ.get('TORCHELASTIC_RUN_ID', ''))
+    return hashlib.sha256(ident.encode()).digest()
+
+
+def new_token():
+    """A fresh random token for a launcher to put into its children's GDML_CHANNEL_TOKEN."""
+    return os.urandom(32).hex()
+
+
+def _mac(token, *parts):
+    return hmac.new(token, b'|'.join(parts), hashlib.sha256).digest()
+
+
+# ---- tagged encoding: what the ranks exchange is ids, floats, small dicts and arrays
+
+
+def _enc(obj, out):
+    if obj is None:
+        out.append(b'N')
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b'T' if obj else b'F')
+    elif isinstance(obj, (int, np.integer)):
+        b = str(int(obj)).encode()
+        out.append(b'i' + struct.pack('<I', len(b)) + b)
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b'd' + struct.pack('<d', float(obj)))
+    elif isinstance(obj, str):
+        b = obj.encode('utf-8')
+        out.append(b's' + struct.pack('<Q', len(b)) + b)
+    elif isinstance(obj, (bytes, bytearray, memoryview)):
+        b = bytes(obj)
+        out.append(b'b' + struct.pack('<Q', len(b)) + b)
+    elif isinstance(obj, (tuple, list)):
+        out.append((b't' if isinstance(obj, tuple) else b'l') + struct.pack('<Q', len(obj)))
+        for x in obj:
+            _enc(x, out)
+    elif isinstance(obj, dict):
+        out.append(b'm' + struct.pack('<Q', len(obj)))
+        for k, v in obj.items():
+            _enc(k, out)
+            _enc(v, out)
+    elif isinstance(obj, np.ndarray):
+        if obj.dtype.hasobject:
+            raise TypeError('host channel: object arrays are not sent')
+        a = np.ascontiguousarray(obj)
+        dt = a.dtype.str.encode()
+        out.append(b'a' + struct.pack('<B', len(dt)) + dt + struct.pack('<B', a.ndim) + struct.pack('<%dq' % a.ndim, *a.shape))
+        out.append(a.tobytes())
+    else:
+        raise TypeError('host channel: cannot send a %s' % type(obj).__name__)
+
+
+def encode(obj):
+    out = []
+    _enc(obj, out)
+    return b''.join(out)
+
+
+def _dec(buf, pos):
+    tag = bytes(buf[pos:pos + 1])
+    pos += 1
+    if tag == b'N':
+        return None, pos
+    if tag in (b'T', b'F'):
+        return tag == b'T', pos
+    if tag == b'i':
+        (n,) = struct.unpack_from('<I', buf, pos)
+        return int(bytes(buf[pos + 4:pos + 4 + n]).decode()), pos + 4 + n
+    if tag == b'd':
+        return struct.unpack_from('<d', buf, pos)[0], pos + 8
+    if tag in (b's', b'b'):
+        (n,) = struct.unpack_from('<Q', buf, pos)
+        raw = bytes(buf[pos + 8:pos + 8 + n])
+        if len(raw) != n:
+            raise ValueError('host channel: truncated message')
+        return (raw.decode('utf-8') if tag == b's' else raw), pos + 8 + n
+    if tag in (b't', b'l'):
+        (n,) = struct.unpack_from('<Q', buf, pos)
+        pos += 8
+        if n > len(buf):
+            raise ValueError('host channel: bad sequence length')
+        items = []
+        for _ in range(n):
+            x, pos = _dec(buf, pos)
+            items.append(x)
+        return (tuple(items) if tag == b't' else items), pos
+    if tag == b'm':
+        (n,) = struct.unpack_from('<Q', buf, pos)
+        pos += 8
+        if n > len(buf):
+            raise ValueError('host channel: bad mapping length')
+        d = {}
+        for _ in range(n):
+            k, pos = _dec(buf, pos)
+            v, pos = _dec(buf, pos)
+            d[k] = v
+        return d, pos
+    if tag == b'a':
+        ln = buf[pos]
+        dt = np.dtype(bytes(buf[pos + 1:pos + 1 + ln]).decode())
+        if dt.hasobject:
+            raise ValueError('host channel: object arrays are not accepted')
+        pos += 1 + ln
+        nd = buf[pos]
+        shape = struct.unpack_from('<%dq' % nd, buf, pos + 1)
+        pos += 1 + 8 * nd
+        if any(x < 0 for x in shape):
+            raise ValueError('host channel: bad array shape')
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        raw = bytes(buf[pos:pos + nbytes])
+        if len(raw) != nbytes:
+            raise ValueError('host channel: truncated array')
+        return np.frombuffer(raw, dtype=dt).reshape(shape).copy(), pos + nbytes
+    raise ValueError('host channel: unknown tag %r' % tag)
+
+
+def decode(blob):
+    obj, pos = _dec(memoryview(blob), 0)
+    if pos != len(blob):
+        raise ValueError('host channel: trailing bytes in a message')
+    return obj
 
 
 def _send(sock, payload):
@@ -44,6 +184,8 @@ def _recv_exact(sock, n):
 
 def _recv(sock):
     (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    if n > _MAX_MSG:
+        raise ConnectionError('host channel: message length %d refused' % n)
     return _recv_exact(sock, n)
 
 
@@ -58,7 +200,7 @@ def channel_port(master_port):
 class HostChannel(object):
     """Star-topology channel: rank 0 holds one socket per peer, every other rank one socket to rank 0."""
 
-    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0):
+    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0, token=None):
         self.rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
         self.world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
         addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
@@ -68,6 +210,7 @@ class HostChannel(object):
         self._listener = None
         if self.world <= 1:
             return
+        token = job_token() if token is None else (token.encode() if isinstance(token, str) else bytes(token))
         if self.rank == 0:
             last = None
             for k in range(_PORT_TRIES):
@@ -83,21 +226,39 @@ class HostChannel(object):
                     ls.close()
             if self._listener is None:
                 raise OSError('host channel: no free port in [{}, {}): {}'.format(port, port + _PORT_TRIES, last))
-            self._listener.settimeout(timeout)
+            deadline = time.time() + timeout
             while len(self._peers) < self.world - 1:
-                conn, _ = self._listener.accept()
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.settimeout(timeout)
+                left = deadline - time.time()
+                if left <= 0:
+                    raise TimeoutError('host channel: %d of %d ranks connected within %.0f s'
+                                       % (len(self._peers) + 1, self.world, timeout))
+                self._listener.settimeout(left)
                 try:
-                    hello = _recv_exact(conn, len(_MAGIC) + 4)
-                except (ConnectionError, socket.timeout, OSError):
+                    conn, _ = self._listener.accept()
+                except socket.timeout:
+                    continue
+                # handshake under a SHORT timeout:
+                #   peer: magic, claimed rank, nonce_p   ->   root: nonce_r, MAC(root | rank | nonce_p)   ->   peer: MAC(peer | rank | nonce_r)
+                conn.settimeout(_HANDSHAKE_TIMEOUT)
+                try:
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    hello = _recv_exact(conn, len(_MAGIC) + 4 + 16)
+                    if hello[:len(_MAGIC)] != _MAGIC:
+                        raise ConnectionError('magic')
+                    (r,) = struct.unpack('<I', hello[len(_MAGIC):len(_MAGIC) + 4])
+                    peer_nonce = hello[len(_MAGIC) + 4:]
+                    if not (1 <= r < self.world) or r in self._peers:
+                        raise ConnectionError('rank')
+                    nonce = os.urandom(16)
+                    rb = struct.pack('<I', r)
+                    conn.sendall(nonce + _mac(token, b'root', rb, peer_nonce))
+                    reply = _recv_exact(conn, 32)
+                    if not hmac.compare_digest(reply, _mac(token, b'peer', rb, nonce)):
+                        raise ConnectionError('token')
+                    conn.sendall(_MAGIC)
+                except (ConnectionError, socket.timeout, OSError, struct.error):
                     conn.close()
                     continue
-                if hello[:len(_MAGIC)] != _MAGIC:
-                    conn.close()
-                    continue
-                (r,) = struct.unpack('<I', hello[len(_MAGIC):])
-                conn.sendall(_MAGIC)
                 conn.settimeout(None)
                 self._peers[r] = conn
         else:
@@ -105,15 +266,20 @@ class HostChannel(object):
             while self._root is None:
                 for k in range(_PORT_TRIES):
                     s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-                    s.settimeout(2.0)
+                    s.settimeout(_HANDSHAKE_TIMEOUT)
                     try:
                         s.connect((addr, port + k))
-                        s.sendall(_MAGIC + struct.pack('<I', self.rank))
-                        if _recv_exact(s, len(_MAGIC)) == _MAGIC:
-                            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                            s.settimeout(None)
-                            self._root = s
-                            break
+                        nonce = os.urandom(16)
+                        rb = struct.pack('<I', self.rank)
+                        s.sendall(_MAGIC + rb + nonce)
+                        answer = _recv_exact(s, 16 + 32)
+                        if hmac.compare_digest(answer[16:], _mac(token, b'root', rb, nonce)):  # it IS this job's rank 0
+                            s.sendall(_mac(token, b'peer', rb, answer[:16]))
+                            if _recv_exact(s, len(_MAGIC)) == _MAGIC:
+                                s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                                s.settimeout(None)
+                                self._root = s
+                                break
                     except (OSError, ConnectionError):
                         pass
                     s.close()
@@ -131,13 +297,13 @@ class HostChannel(object):
         if self.rank == 0:
             every = [obj] + [None] * (self.world - 1)
             for r, s in self._peers.items():
-                every[r] = pickle.loads(_recv(s))
-            blob = pickle.dumps(every, protocol=4)
+                every[r] = decode(_recv(s))
+            blob = encode(every)
             for s in self._peers.values():
                 _send(s, blob)
             return every
-        _send(self._root, pickle.dumps(obj, protocol=4))
-        return pickle.loads(_recv(self._root))
+        _send(self._root, encode(obj))
+        return decode(_recv(self._root))
 
     def bcast_obj(self, obj, src=0):
         if self.world <= 1:
@@ -145,11 +311,11 @@ class HostChannel(object):
         if src != 0:  # rare: route through the root
             return self.allgather_obj(obj if self.rank == src else None)[src]
         if self.rank == 0:
-            blob = pickle.dumps(obj, protocol=4)
+            blob = encode(obj)
             for s in self._peers.values():
                 _send(s, blob)
             return obj
-        return pickle.loads(_recv(self._root))
+        return decode(_recv(self._root))
 
     def barrier(self):
         self.allgather_obj(None)

@@ -8,7 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
-GOLDEN_CASES = ['n6_p1', 'n5_p4', 'n5_p2_ecstr', 'n4_p6_pbc', 'n9_p1']
+GOLDEN_CASES = ['n6_p1', 'n5_p4', 'n5_p2_ecstr', 'n4_p6_pbc', 'n9_p1', 'n10_p2_pbc']
 
 
 def pytest_configure(config):

@@ -67,6 +67,18 @@ CASES = {
         lattice=[[6.0, 0.3, 0.0], [0.0, 5.5, 0.2], [0.1, 0.0, 7.0]],
     ),
     'n9_p1': dict(N=9, M=9, perms=[list(range(9))], sig=30, E_cstr=False),
+    # round 6: a WELL-CONDITIONED periodic case (lam = 1e-4: max|J alpha| ~ 1e2..1e4, so the round-off floor of the prediction
+    # sum is <= 1e-12 and the minimum-image prologue of desc / predict is pinned at 1e-10; n4_p6_pbc stays as the
+    # ill-conditioned one).  The 5.2 .. 6.4 A cell is smaller than twice the molecule: most frames wrap several pairs.
+    'n10_p2_pbc': dict(
+        N=10,
+        M=12,
+        perms=[list(range(10)), [1, 0] + list(range(2, 10))],
+        sig=14,
+        E_cstr=False,
+        lam=1e-4,
+        lattice=[[5.6, 0.4, 0.0], [0.0, 5.2, 0.3], [0.2, 0.0, 6.4]],
+    ),
 }
 
 
@@ -74,7 +86,10 @@ def main():
     GDMLTrain, GDMLPredict, Desc, Iterative = _import_reference()
     gdml_train = GDMLTrain(max_processes=1)
 
+    only = sys.argv[1:]  # e.g. `make_golden.py n10_p2_pbc`: regenerate only the named cases
     for name, cfg in CASES.items():
+        if only and name not in only:
+            continue
         N, M = cfg['N'], cfg['M']
         seed = abs(hash(name)) % 1000 if False else sum(map(ord, name))
         np.random.seed(seed)
@@ -83,7 +98,7 @@ def main():
         R_train, E_train, F_train = R_all[:M], E_all[:M], F_all[:M]
         R_test = R_all[M:]
         perms = np.array(cfg['perms'], dtype=np.int64)
-        sig, lam = cfg['sig'], 1e-10
+        sig, lam = cfg['sig'], cfg.get('lam', 1e-10)
         use_E_cstr = cfg['E_cstr']
 
         task = {
@@ -211,6 +226,11 @@ def main():
             out['model_alphas_E'] = model['alphas_E']
         if 'lattice' in cfg:
             out['lattice'] = np.array(cfg['lattice'])
+            # how much of the case actually exercises the minimum-image convention (desc.py:44-77)
+            x_open, _ = desc.from_R(np.vstack([R_train, R_test]).reshape(M + len(R_test), -1))
+            x_pbc, _ = desc.from_R(np.vstack([R_train, R_test]).reshape(M + len(R_test), -1), lat_and_inv=lat_and_inv)
+            print('   pairs wrapped by the minimum image: %.1f %%, max|J alpha| %.3e'
+                  % (100.0 * np.mean(np.abs(x_open - x_pbc) > 1e-9), np.abs(model['R_d_desc_alpha']).max()))
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **out)
         print(name, 'n=%d' % n, 'K max', np.abs(K).max(), '->', os.path.getsize(path) // 1024, 'KiB')

@@ -1,13 +1,14 @@
 """GPU parity tests: the HIP path (through the C ABI) against the reference-generated golden
 fixtures and against the NumPy oracle on seeded inputs.  Tolerances (fp64, stated per test):
   K        : max|dK| <= 1e-12 * max|K|                       
-  solve    : ||(-K + lam I)(-alpha) - y|| / ||y|| <= 1e-8    (cond ~ 1/lam, no elementwise alpha parity)
+  solve    : ||(-K + lam I)(-alpha) - y|| / ||y|| <= 1e-10   (cond ~ 1/lam, no elementwise alpha parity)
   predict  : |dF| <= 1e-10 max|F| + cancellation floor       (see test_oracle_golden.cancel_floor)
 """
 import numpy as np
 import pytest
 
 from oracle import gdml_oracle as orc
+from tests._tol import solve_tol
 from tests.test_oracle_golden import _lat, _model, _tril_perms, cancel_floor
 
 pytestmark = pytest.mark.gpu
@@ -89,7 +90,7 @@ def test_analytic_solve(golden, ctx):
     alphas = ctx.chol_solve(g['y'])
     A = -g['K'] + lam * np.eye(g['K'].shape[0])
     r = A @ (-alphas) - g['y']
-    assert np.linalg.norm(r) / np.linalg.norm(g['y']) < 1e-8
+    assert np.linalg.norm(r) / np.linalg.norm(g['y']) < solve_tol(A, alphas, g['y'])  # 1e-10; tests/_tol.py for n4_p6_pbc
     # factor parity with LAPACK on the lower triangle
     import scipy.linalg as sla
 
@@ -656,7 +657,7 @@ def test_ase_calculator_with_stub_ase(golden, tmp_path, monkeypatch):
 @pytest.mark.parametrize('n_atoms,M', [(5, 40), (7, 110)])
 def test_chol_rhs_row_matches_separate_solve(ctx_factory, n_atoms, M):
     """gdml_chol_set_rhs: the right-hand side carried through the factorisation as an extra row gives the
-    same solution as the separate forward substitution (both to the solve tolerance 1e-8, and to each
+    same solution as the separate forward substitution (both to the solve tolerance 1e-10, and to each
     other within the conditioning of the system); spans several panels (GDML_CHOL_NB default 512: n = 2310)."""
     ds = orc.synth_dataset(n_atoms, M, seed=3)
     Rf = ds['R'].reshape(M, -1)
@@ -674,7 +675,7 @@ def test_chol_rhs_row_matches_separate_solve(ctx_factory, n_atoms, M):
     K = orc.assemble_K(xd, gd, orc.tril_perms_lin_from_tril_perms(tp), sig)
     A = -K + lam * np.eye(K.shape[0])
     for a in (a_fused, a_sep):
-        assert np.linalg.norm(A @ (-a) - y) / np.linalg.norm(y) <= 1e-8
+        assert np.linalg.norm(A @ (-a) - y) / np.linalg.norm(y) <= 1e-10
     assert np.linalg.norm(a_fused - a_sep) <= 1e-6 * np.linalg.norm(a_sep)
     # state errors
     c2 = ctx_factory()
@@ -707,7 +708,7 @@ def test_full_size_properties(ctx_factory):
     """BASELINE.json configs[1] size (N=21, N_train=1000, n=63000), size-independent properties:
     symmetry of K, agreement of the assembled rows with the matrix-free operator (two independent kernels:
     K[r,:] v == (K v)[r]), linearity of the operator, and the round trip (-K + lam I) x = y through the
-    Cholesky path.  Tolerances: 1e-12 max|K| for entries, 1e-10 relative for operator identities, 1e-8 solve."""
+    Cholesky path.  Tolerances: 1e-12 max|K| for entries, 1e-10 relative for operator identities, 1e-10 solve."""
     N, M = 21, 1000
     ds = orc.synth_dataset(N, M, seed=1, jitter=0.3)
     Rf = ds['R'].reshape(M, -1)
@@ -748,7 +749,7 @@ def test_full_size_properties(ctx_factory):
     assert c.chol_factor(lam) == 0
     x = -c.chol_solve(None)
     Ax = -c.kernel_matvec(lam, False, x)  # (-K + lam I) x
-    assert np.linalg.norm(Ax - y) / np.linalg.norm(y) <= 1e-8
+    assert np.linalg.norm(Ax - y) / np.linalg.norm(y) <= 1e-10
 
 
 def test_smallest_sizes_and_empty_batch(ctx_factory):

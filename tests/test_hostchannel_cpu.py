@@ -72,3 +72,108 @@ def test_single_rank_channel_is_trivial():
     c.allgather(buf, 4)
     assert c.allgather_obj('x') == ['x'] and c.bcast_obj(3) == 3 and c.all_max(2) == 2 and list(buf) == [0, 1, 2, 3]
     c.barrier()
+
+
+def test_message_codec_round_trip_and_refusals():
+    """Nothing that arrives is unpickled: the tagged encoding carries what the ranks exchange and nothing else."""
+    import pytest
+
+    from sgdml_amd.hostchannel import decode, encode
+
+    obj = {'rank': 3, 'id': bytes(range(128)), 'vals': [1.5, -2, None, True, ('a', 7)], 'big': 1 << 80,
+           'arr': np.arange(12.0).reshape(3, 4), 'idx': np.array([[1, 2]], dtype=np.int64), 'empty': np.zeros((0, 3)), 's': 'σ'}
+    back = decode(encode(obj))
+    assert back['rank'] == 3 and back['id'] == obj['id'] and back['vals'] == obj['vals'] and back['big'] == 1 << 80
+    assert back['arr'].dtype == np.float64 and np.array_equal(back['arr'], obj['arr']) and back['arr'].flags.writeable
+    assert back['idx'].dtype == np.int64 and back['empty'].shape == (0, 3) and back['s'] == 'σ'
+    assert isinstance(back['vals'][4], tuple)
+    with pytest.raises(TypeError):
+        encode(object())                      # arbitrary objects are not sent ...
+    with pytest.raises(TypeError):
+        encode(np.array([object()]))
+    import pickle
+    with pytest.raises(ValueError):
+        decode(pickle.dumps({'x': 1}))        # ... and a pickle is not a message
+    with pytest.raises(ValueError):
+        decode(encode([1, 2]) + b'x')
+    with pytest.raises((ValueError, struct_error())):
+        decode(encode('abcdef')[:-2])
+
+
+def struct_error():
+    import struct
+
+    return struct.error
+
+
+def test_handshake_refuses_strangers_and_is_not_held_up_by_them():
+    """Rank 0's accept loop against: a connection that says nothing (it may not hold up the real ranks beyond the 2 s
+    handshake timeout), the right magic with a bad MAC, a claimed rank out of range, and a rank that holds ANOTHER job's
+    token (never admitted, and it refuses rank 0 in turn) -- then the real rank 1 connects and the collectives work."""
+    import threading
+    import time
+
+    from sgdml_amd import hostchannel as hc
+
+    port = _free_port()
+    token, foreign = hc.new_token(), hc.new_token()
+    root = {}
+
+    def serve():
+        root['c'] = hc.HostChannel(rank=0, world=2, addr='127.0.0.1', port=port, timeout=60, token=token)
+
+    th = threading.Thread(target=serve)
+    th.start()
+    time.sleep(0.3)
+    strangers = [socket.create_connection(('127.0.0.1', port)) for _ in range(3)]
+    strangers[1].sendall(hc._MAGIC + (1).to_bytes(4, 'little') + os.urandom(16))   # right magic, cannot answer the challenge
+    strangers[2].sendall(hc._MAGIC + (7).to_bytes(4, 'little') + os.urandom(16))   # rank out of range
+    try:
+        try:
+            hc.HostChannel(rank=1, world=2, addr='127.0.0.1', port=port, timeout=1.0, token=foreign)
+            raise AssertionError('a rank with a foreign token was admitted')
+        except TimeoutError:
+            pass
+        assert 'c' not in root  # rank 0 is still waiting for ITS rank 1
+        t0 = time.time()
+        peer = hc.HostChannel(rank=1, world=2, addr='127.0.0.1', port=port, timeout=30, token=token)
+        th.join(timeout=30)
+        assert 'c' in root and time.time() - t0 < 10.0
+        box = {}
+        t2 = threading.Thread(target=lambda: box.setdefault('r', root['c'].allgather_obj({'r': 0, 'a': np.arange(3.0)})))
+        t2.start()
+        mine = peer.allgather_obj({'r': 1, 'a': np.ones(2)})
+        t2.join(timeout=30)
+        assert [x['r'] for x in mine] == [0, 1] and np.array_equal(box['r'][1]['a'], np.ones(2))
+        # a second connection that claims an already registered rank is refused as well (rank 0 no longer listens here; the
+        # duplicate check is exercised through the accept loop of a 3-rank root)
+        peer.close()
+        root['c'].close()
+    finally:
+        for s_ in strangers:
+            s_.close()
+
+
+def test_duplicate_rank_is_refused():
+    import threading
+    import time
+
+    from sgdml_amd import hostchannel as hc
+
+    port = _free_port()
+    token = hc.new_token()
+    root = {}
+    th = threading.Thread(target=lambda: root.setdefault('c', hc.HostChannel(rank=0, world=3, addr='127.0.0.1', port=port, timeout=60, token=token)))
+    th.start()
+    time.sleep(0.3)
+    first = hc.HostChannel(rank=1, world=3, addr='127.0.0.1', port=port, timeout=30, token=token)
+    try:
+        hc.HostChannel(rank=1, world=3, addr='127.0.0.1', port=port, timeout=1.0, token=token)  # same rank again
+        raise AssertionError('a duplicate rank was admitted')
+    except TimeoutError:
+        pass
+    second = hc.HostChannel(rank=2, world=3, addr='127.0.0.1', port=port, timeout=30, token=token)
+    th.join(timeout=30)
+    assert sorted(root['c']._peers) == [1, 2]
+    for c in (first, second, root['c']):
+        c.close()

@@ -3,6 +3,7 @@
 import numpy as np
 
 from oracle import gdml_oracle as orc
+from tests._tol import solve_tol
 
 
 def _lat(g):
@@ -61,7 +62,7 @@ def test_analytic_solve_residual(golden):
     alphas, _ = orc.analytic_solve(g['K'], g['y'], float(g['lam']))
     A = -g['K'] + float(g['lam']) * np.eye(g['K'].shape[0])
     r = A @ (-alphas) - g['y']
-    assert np.linalg.norm(r) / np.linalg.norm(g['y']) < 1e-8
+    assert np.linalg.norm(r) / np.linalg.norm(g['y']) < solve_tol(A, alphas, g['y'])
     # prediction parity with the reference's alphas (not elementwise alpha parity: cond ~ 1/lam)
     M = g['R_desc'].shape[0]
     tp = _tril_perms(g)
@@ -153,3 +154,20 @@ def test_pcg_matches_direct(golden):
                                     rtol=1e-6, maxiter=5000)
     assert info == 0
     assert np.linalg.norm(A @ x - g['y']) <= 1e-5 * np.linalg.norm(g['y'])
+
+
+def test_periodic_fixture_without_roundoff_floor():
+    """n10_p2_pbc (round 6, lam = 1e-4): the oracle's minimum-image descriptors and its predictions from the reference's
+    model against the reference's outputs with NO cancellation floor (the floor is 1.3e-12 on this fixture)."""
+    import os
+
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'n10_p2_pbc.npz')))
+    assert cancel_floor(g) <= 2e-12
+    M = g['R_train'].shape[0]
+    xd, jd = orc.desc_from_R(g['R_train'].reshape(M, -1), _lat(g))
+    xo, _ = orc.desc_from_R(g['R_train'].reshape(M, -1))
+    assert np.mean(np.abs(xo - xd) > 1e-9) > 0.3  # periodic in earnest
+    np.testing.assert_allclose(xd, g['R_desc'], rtol=1e-13, atol=0)
+    E, F = orc.predict(_model(g), g['R_test'].reshape(len(g['R_test']), -1))
+    assert np.abs(F - g['F_test']).max() <= 1e-10 * np.abs(g['F_test']).max()
+    assert np.abs(E - g['E_test']).max() <= 1e-10 * max(1.0, np.abs(g['E_test']).max())
