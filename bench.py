@@ -6,20 +6,22 @@ wall-clock [s] and predict forces/s at N_train=1000, aspirin-sized = 21 atoms).
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N=1: plain python)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N = 1 (headline, BASELINE.json configs[1]): one "step" = one pass of the hot path over one synthetic batch,
-all inputs resident in HBM before the timed region starts:
-    assemble -K + lam I (63 000 x 63 000 fp64, lower blocks, stays in HBM)  ->  in-place fp64 MFMA Cholesky
-    ->  triangular solves (alphas)  ->  batched force/energy prediction of B query geometries.
-  `value` = build+solve seconds.  The line also carries `configs`: configs[0]-shaped sigma sweep
-  (N=9, P=6, M=200, 9 sigmas, 1000 validation + 5000 test geometries, sgdml_amd.sweep) and the configs[2]
-  workload below measured on this one GPU (the 1-GPU point of the strong-scaling curve), and `cpu_baseline`.
+`value` measures the SAME workload for every --gpus N (--workload, default analytic), so that a driver's N = 1, 2, 4, 8 runs
+form a curve; `metric` / `config.workload` come from line_skeleton() and are identical across N:
 
-N > 1 (BASELINE.json configs[2]: aspirin N_train=5000, iterative solver sharded over the GPUs with RCCL):
-  one "step" = assemble this rank's rows of K_nm (n x m, m = 3N k inducing columns), Nystroem factor (RCCL
-  all-reduce of the m x m blocks), then a FIXED number of PCG iterations (query-sharded mat-vec + all-gather,
-  row-sharded preconditioner: all-reduce of an m-vector + all-gather).  Total work is fixed -> "strong";
-  `value` = seconds per step (max over ranks).  `one_gpu_s_per_step`: the same step unsharded on rank 0's GPU,
-  measured in the same run.  The sigma-grid replicas of round 1 (weak scaling, no collective) are gone.
+analytic (default; BASELINE.json configs[1], N = 21, N_train = 1000, n = 63 000): one "step" = one pass of the hot path over one
+synthetic batch, all inputs resident in HBM before the timed region starts:
+    assemble -K + lam I (fp64, lower blocks, stays in HBM)  ->  in-place fp64 MFMA Cholesky  ->  triangular solves (alphas)
+    [N = 1 only: -> batched force/energy prediction of B query geometries]
+  `value` = build+solve seconds.  N = 1: single-GPU factorisation; the line also carries `configs` (the configs[0]-shaped
+  sigma sweep, configs[2] / [3] / [4] to solver_tol on this one GPU), `predict`, `first_call_in_process`, `cpu_baseline`.
+  N > 1: the same system block-row-cyclic over the ranks through gdml_dist_chol_solve (RCCL broadcasts + all-gathers),
+  "scaling": "strong"; the configs[2] step and its run to solver_tol ride along (`cg`, `time_to_tol`).
+cg (BASELINE.json configs[2]: aspirin N_train=5000, iterative solver sharded over the GPUs with RCCL): one "step" = this
+  rank's rows of K_nm (n x m, m = 3N k inducing columns), Nystroem factor (RCCL all-reduce of the m x m blocks), then a
+  FIXED number of PCG iterations (query-sharded mat-vec + all-gather, row-sharded preconditioner: all-reduce of an m-vector
+  + all-gather).  `value` = seconds per step (max over ranks), any N including 1.
+Both lines carry `scale_point` (analytic seconds) and / or `scale_point_cg` under the same keys.
 
 Prints ONE JSON line (rank 0).
 """
@@ -38,6 +40,25 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_MFMA_PEAK_TF = 78.6  # MI355X fp64 matrix peak (256 CU x 4 SIMD x 2.4 GHz x 32 flop/clk)
+
+
+def line_skeleton(workload, n_atoms, n_train, world, cg_iters=None, cg_inducing=None):
+    """`metric` and `config.workload` of a bench line: ONE string per workload, the same for every number of GPUs, so that the
+    values of `--gpus 1, 2, 4, 8` form a curve (tests/test_host_policy_cpu.py).  What differs between the lines lives in
+    `n_gpus` and `config.parallelism`."""
+    if workload == 'analytic':
+        return {'metric': 'kernel-matrix build+solve wall-clock, N_train={} {}-atom (aspirin-sized)'.format(n_train, n_atoms),
+                'workload': 'aspirin-sized N={} N_train={} analytic Cholesky (BASELINE.json configs[1])'.format(n_atoms, n_train),
+                'parallelism': 'single GPU' if world == 1 else
+                               'kernel matrix block-row-cyclic over {} GPUs, distributed Cholesky (gdml_dist_chol_solve)'.format(world)}
+    if workload == 'cg':
+        return {'metric': 'sharded Nystroem-PCG solve wall-clock per step (K_nm rows + preconditioner + {} PCG iterations), '
+                          'N_train={} {}-atom (aspirin-sized)'.format(cg_iters, n_train, n_atoms),
+                'workload': 'aspirin-sized N={} N_train={} iterative solver (Nystroem-preconditioned CG, k={} inducing points, {} '
+                            'iterations per step) (BASELINE.json configs[2])'.format(n_atoms, n_train, cg_inducing, cg_iters),
+                'parallelism': 'single GPU' if world == 1 else
+                               'row-sharded Nystroem factor + query-sharded mat-vec over {} ranks'.format(world)}
+    raise ValueError(workload)
 
 
 def synth_geometries(n_atoms, n_frames, seed=0, jitter=0.3, n_conformers=4, spacing=1.4):
@@ -513,6 +534,10 @@ def main():
     ap.add_argument('--no-to-tol', action='store_true', help='N>1: skip the sharded run to solver_tol')
     ap.add_argument('--to-tol-timeout', type=float, default=600.0, help='N>1: seconds the sharded run to solver_tol may take')
     ap.add_argument('--dist-chol', action='store_true', help='N>1: also time the configs[1] system through the distributed Cholesky')
+    ap.add_argument('--workload', default='auto', choices=('auto', 'analytic', 'cg'),
+                    help="what `value` measures, the SAME for every --gpus N: analytic (default) = configs[1] build+solve (N>1: "
+                         "through the distributed Cholesky); cg = the configs[2] sharded Nystroem-PCG step")
+    ap.add_argument('--no-cg-extras', action='store_true', help='N>1 analytic: skip the configs[2] step / time-to-tol blocks')
     ap.add_argument('--comm', default='auto', help="N>1: 'rccl', 'host' (collectives staged through the host channel), or auto (rccl if every rank has a GPU)")
     args = ap.parse_args()
 
@@ -537,7 +562,11 @@ def main():
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    out = run_sharded_cg(args, rank, world) if world > 1 else run_analytic(args)
+    workload = 'analytic' if args.workload == 'auto' else args.workload
+    if world == 1 and workload == 'analytic':
+        out = run_analytic(args)
+    else:
+        out = run_multi(args, rank, world, workload)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
@@ -572,11 +601,14 @@ def self_launch(args):
         port = sk.getsockname()[1]
     # one rank per GPU, the environment a launcher would set (what the driver's torch.distributed.run provides); the ranks
     # rendezvous through sgdml_amd.hostchannel, so no launcher package is needed
+    from sgdml_amd.hostchannel import new_token
+
     procs = []
+    token = os.environ.get('GDML_CHANNEL_TOKEN') or new_token()  # per-job secret of the host channel's handshake
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
-                   GDML_BENCH_CHILD='1')
+                   GDML_BENCH_CHILD='1', GDML_CHANNEL_TOKEN=token)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for p_ in procs:
@@ -584,9 +616,12 @@ def self_launch(args):
     return rc
 
 
-def run_sharded_cg(args, rank, world):
-    """N > 1: the configs[2] workload sharded over the ranks (one process per GPU, RCCL inside the library).  The host side
-    (rendezvous, barrier, max over ranks) is sgdml_amd.hostchannel: no PyTorch in these processes."""
+def run_multi(args, rank, world, workload):
+    """N > 1 (and N = 1 with --workload cg): one process per GPU, RCCL inside the library; the host side (rendezvous, barrier,
+    max over ranks) is sgdml_amd.hostchannel: no PyTorch in these processes.
+    workload 'analytic' (default): `value` = build+solve seconds of the configs[1] system through the distributed Cholesky --
+    the SAME metric and workload string as the N = 1 line (line_skeleton), strong scaling; the configs[2] step and its run to
+    solver_tol ride along as `cg` / `time_to_tol`.  workload 'cg': `value` = seconds per configs[2] step (the round 1-5 line)."""
     from sgdml_amd import _lib
     from sgdml_amd.dist import host_group, init_comm, pick_backend, probe_rccl
 
@@ -594,18 +629,25 @@ def run_sharded_cg(args, rank, world):
     hg = host_group()
     n_dev = _lib.device_count()
     comm = args.comm
-    if comm == 'auto':  # RCCL when every rank has a physical GPU of its own; ranks sharing a GPU: functional host-staged run
-        comm = pick_backend(local_rank % max(1, n_dev), hg)
     rccl_probe = None
-    if comm == 'rccl' and args.comm == 'auto':
-        # a toy sharded solve through RCCL in child processes, under a time limit, before the real ranks commit to it: a
-        # node where RCCL does not come up still gets its (slower) strong-scaling line through the host-staged collectives
-        ok, rccl_probe = probe_rccl(local_rank % max(1, n_dev), hg)
-        if not ok:
-            comm = 'host'
-            sys.stderr.write('bench.py: RCCL probe failed ({}); using host-staged collectives\n'.format(rccl_probe))
+    if world > 1:
+        if comm == 'auto':  # RCCL when every rank has a physical GPU of its own; ranks sharing a GPU: functional host-staged run
+            comm = pick_backend(local_rank % max(1, n_dev), hg)
+        if comm == 'rccl' and args.comm == 'auto':
+            # a toy sharded solve through RCCL in child processes, under a time limit, before the real ranks commit to it: a
+            # node where RCCL does not come up still gets its (slower) strong-scaling line through the host-staged collectives
+            ok, rccl_probe = probe_rccl(local_rank % max(1, n_dev), hg)
+            if not ok:
+                comm = 'host'
+                sys.stderr.write('bench.py: RCCL probe failed ({}); using host-staged collectives\n'.format(rccl_probe))
+    else:
+        comm = 'none'
     ctx = _lib.Context(local_rank % max(1, n_dev))
-    init_comm(ctx, group=hg, backend=comm)
+    rccl_ranks_seen = None
+    if world > 1:
+        init_comm(ctx, group=hg, backend=comm)
+        rccl_ranks_seen = ctx.get_option('comm.rccl_ranks')  # ncclCommCount of the communicator the library built (None: host-staged)
+        rccl_ranks_seen = None if rccl_ranks_seen is None else int(rccl_ranks_seen)
 
     def barrier():
         ctx.sync()
@@ -616,58 +658,92 @@ def run_sharded_cg(args, rank, world):
         return [max(e[i] for e in every) for i in range(len(values))]
 
     N, M, k = args.n_atoms, args.cg_n_train, args.cg_inducing
-    wl = make_cg_workload(ctx, N, M, k, args.sig, args.lam)
-    res = time_cg(ctx, wl, args.cg_iters, args.steps, args.warmup, barrier)
-    s_per_step, asm_ms, pre_ms, pcg_ms, gemv_ms = max_over_ranks(
-        [res['s_per_step'], res['phases_ms']['assemble'], res['phases_ms']['precon'], res['phases_ms']['pcg'],
-         res['gemv']['ms_per_application']])
+    with_cg = workload == 'cg' or not args.no_cg_extras
+    with_chol = world > 1 and (workload == 'analytic' or args.dist_chol)
 
-    # the configs[1] system (n = 63 000) through the distributed Cholesky over the same communicator, in BOTH schedules
-    # (dist.lookahead 0 = every step in order on the compute stream, the default; 1 = one panel of look-ahead over three
-    # streams with the block broadcasts on a second communicator), so that the first hardware record compares them
+    # ---- configs[1] (n = 63 000) through the distributed Cholesky over the communicator: the `value` of the default N > 1
+    # line.  Timed like the N = 1 headline: W untimed solves, then K solves between barriers, max over ranks; one solve =
+    # assemble this rank's row blocks of A = -K + lam I + factor + both substitutions.  Default schedule (dist.lookahead
+    # unset: one panel of look-ahead from two ranks on), then the other schedule for comparison (3 repetitions).
     dchol = None
-    try:
-        if not args.dist_chol:
-            # opt-in: the RCCL branch of the distributed Cholesky has never run on more than one physical GPU (its test is
-            # skipped on one-GPU boxes); a hang there would take the strong-scaling line above with it
-            raise RuntimeError('not run (pass --dist-chol)')
-        Mc = args.n_train
-        Rc, Ec, Fc = synth_geometries(N, Mc, seed=0)
-        yc = Fc.ravel() / np.std(Fc)
-        xdc, gdc = ctx.desc_from_R(Rc.reshape(Mc, -1), N)
-        tpc = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
-        ctx.train_upload(xdc, gdc, tpc)
-        dchol = {'config': 'configs[1] system (N=21 N_train={} n={}) assembled block-row-cyclic over {} ranks and solved by '
-                           'the distributed Cholesky (gdml_dist_chol_solve)'.format(Mc, Mc * 3 * N, world), 'schedules': {}}
-        for la in (0, 1):
-            ctx.set_option('dist.lookahead', la)
+    if with_chol:
+        try:
+            Mc = args.n_train
+            Rc, Ec, Fc = synth_geometries(N, Mc, seed=0)
+            yc = Fc.ravel() / np.std(Fc)
+            xdc, gdc = ctx.desc_from_R(Rc.reshape(Mc, -1), N)
+            tpc = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
+            ctx.train_upload(xdc, gdc, tpc)
+            for _ in range(max(1, args.warmup) if workload == 'analytic' else 1):
+                ctx.dist_chol_solve(args.sig, args.lam, yc)
+            ctx.profile(True)
+            barrier()
+            t0 = time.perf_counter()
+            ph = []
+            n_steps = args.steps if workload == 'analytic' else 2
+            for _ in range(n_steps):
+                a_c = ctx.dist_chol_solve(args.sig, args.lam, yc)
+                ph.append({k_: ctx.phase_ms(k_)[0] for k_ in ('assemble', 'factor', 'solve')})
+            barrier()
+            wall = (time.perf_counter() - t0) / max(1, n_steps)
+            g_ms, g_n, g_fl = ctx.kernel_stat('gemm_nt_sub')
+            ctx.profile(False)
+            (wall, g_ms_max) = max_over_ranks([wall, g_ms])
+            phases = {k_: max_over_ranks([float(np.mean([p_[k_] for p_ in ph]))])[0] for k_ in ph[0]}
+            ctx.predict_upload_model(xdc, np.zeros_like(xdc), tpc, args.sig, None)
+            Kv = ctx.kernel_matvec(args.lam, False, -a_c)
+            resid = float(np.linalg.norm(-Kv - yc) / np.linalg.norm(yc))
+            ctx.train_upload(xdc, gdc, tpc)
+            ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+            dchol = {'s_per_solve': wall, 'build_solve_s': (phases['assemble'] + phases['factor'] + phases['solve']) / 1e3,
+                     'phases_ms': phases, 'solve_rel_residual': resid, 'matrix_n': Mc * 3 * N,
+                     'matrix_bytes_per_rank': ctx.mem_info()[0],
+                     'schedule': 'dist.lookahead default (1 from two ranks on)',
+                     'roofline': {'kernel': 'gemm_nt_sub_kernel (fp64 MFMA trailing updates of this rank\'s row blocks, K = 512, '
+                                            'block-cyclic lower tile predicate)', 'bound': 'mfma', 'achieved': ach,
+                                  'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': ach / FP64_MFMA_PEAK_TF, 'traffic': None,
+                                  'launches': g_n, 'avg_launch_ms': g_ms / max(1, g_n), 'rank': 0,
+                                  'kernel_ms_per_solve_max_over_ranks': g_ms_max / max(1, n_steps)},
+                     'other_schedule': {}}
+            la_default = 1 if world > 1 else 0
+            ctx.set_option('dist.lookahead', 1 - la_default)
             ts = []
             for rep in range(3):
                 barrier()
                 t0 = time.perf_counter()
-                a_c = ctx.dist_chol_solve(args.sig, args.lam, yc)
+                ctx.dist_chol_solve(args.sig, args.lam, yc)
                 barrier()
                 ts.append(time.perf_counter() - t0)
             (t_best,) = max_over_ranks([min(ts[1:])])
-            ctx.predict_upload_model(xdc, np.zeros_like(xdc), tpc, args.sig, None)
-            Kv = ctx.kernel_matvec(args.lam, False, -a_c)
-            ctx.train_upload(xdc, gdc, tpc)
-            dchol['schedules']['dist.lookahead=%d' % la] = {
-                's_per_solve': t_best, 'phases_ms': {k_: ctx.phase_ms(k_)[0] for k_ in ('assemble', 'factor', 'solve')},
-                'solve_rel_residual': float(np.linalg.norm(-Kv - yc) / np.linalg.norm(yc))}
-        ctx.set_option('dist.lookahead', 0)
-        dchol['matrix_bytes_per_rank'] = ctx.mem_info()[0]
-    except Exception as e:  # the strong-scaling line must not die with an extra
-        dchol = {'skipped' if not args.dist_chol else 'error': repr(e)}
+            dchol['other_schedule'] = {'dist.lookahead': 1 - la_default, 's_per_solve': t_best}
+            ctx.set_option('dist.lookahead', la_default)
+        except Exception as e:  # a line must still be printed
+            dchol = {'error': repr(e)}
+
+    # ---- configs[2]: K_nm rows + preconditioner + a fixed number of PCG iterations
+    res = wl = None
+    s_per_step = asm_ms = pre_ms = pcg_ms = gemv_ms = None
+    if with_cg:
+        try:
+            wl = make_cg_workload(ctx, N, M, k, args.sig, args.lam)
+            res = time_cg(ctx, wl, args.cg_iters, args.steps if workload == 'cg' else 2, args.warmup if workload == 'cg' else 1, barrier)
+            s_per_step, asm_ms, pre_ms, pcg_ms, gemv_ms = max_over_ranks(
+                [res['s_per_step'], res['phases_ms']['assemble'], res['phases_ms']['precon'], res['phases_ms']['pcg'],
+                 res['gemv']['ms_per_application']])
+        except Exception as e:
+            if workload == 'cg':
+                raise
+            res = None
+            wl = {'error': repr(e)}
     ctx.close()
 
     # the same workload as the 1-GPU configs[2] entry run to solver_tol through GDMLTrain.train, sharded over the ranks
     # (leverage-sampled inducing points, the reference's restart policy): what a SCALE record means as a SOLVE
     to_tol = None
     hung = False
-    if not args.no_to_tol:
-        # in a worker thread under a time limit: this leg builds a second communicator and runs ~900 sharded iterations;
-        # should a collective ever hang on some node, the strong-scaling line above must still be printed (the main
+    if with_cg and not args.no_to_tol:
+        # in a worker thread under a time limit: this leg builds a second communicator and runs several hundred sharded
+        # iterations; should a collective ever hang on some node, the line above must still be printed (the main
         # thread gives up waiting, reports it, and the process leaves through os._exit)
         import threading
 
@@ -677,7 +753,7 @@ def run_sharded_cg(args, rank, world):
             try:
                 box['r'] = solve_config('configs[2] to solver_tol 1e-4, sharded over {} ranks'.format(world), N, M, solver='cg',
                                         max_memory=32, traj={'n_modes': 8, 'amp': 0.15, 'noise': 0.01}, sig=args.sig,
-                                        lam=args.lam, dist_backend=comm)
+                                        lam=args.lam, dist_backend=comm if world > 1 else None)
             except Exception as e:
                 box['r'] = {'error': repr(e)}
 
@@ -691,7 +767,7 @@ def run_sharded_cg(args, rank, world):
             to_tol['time_to_tol_s'] = to_tol['train_wall_s'] = tw
 
     one_gpu = None
-    if rank == 0 and not hung:  # the 1-GPU point of the curve, same run, same GPU as rank 0
+    if rank == 0 and not hung and world > 1 and res is not None:  # the 1-GPU point of the configs[2] curve, same run, rank 0's GPU
         c1 = _lib.Context(local_rank % max(1, n_dev))
         wl1 = make_cg_workload(c1, N, M, k, args.sig, args.lam)
         one_gpu = time_cg(c1, wl1, args.cg_iters, 1, 1, c1.sync)
@@ -709,41 +785,65 @@ def run_sharded_cg(args, rank, world):
         if hung:
             os._exit(0)
         return None
-    gemv_bytes = res['gemv']['bytes_per_application']
-    ach = gemv_bytes / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else 0.0
-    return {
-        'metric': 'sharded Nystroem-PCG solve wall-clock per step (K_nm rows + preconditioner + {} PCG iterations), '
-                  'N_train={} {}-atom (aspirin-sized)'.format(args.cg_iters, M, N),
-        'value': s_per_step, 'unit': 's', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': s_per_step * 1e3, 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None,
-        'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'aspirin-sized N=21 N_train={} iterative solver (Nystroem-preconditioned CG, k={} inducing '
-                               'points, {} iterations per step), kernel rows sharded over {} GPUs with {} '
-                               '(BASELINE.json configs[2])'.format(M, k, args.cg_iters, world,
-                                                                   'RCCL' if comm == 'rccl' else 'host-staged collectives over TCP'),
-                   'n_atoms': N, 'n_train': M, 'n_inducing_points': k, 'matrix_n': wl['n'], 'precon_m': wl['m'],
-                   'pcg_iterations_per_step': args.cg_iters, 'sig': args.sig, 'lam': args.lam,
-                   'parallelism': 'row-sharded Nystroem factor + query-sharded mat-vec over {} ranks'.format(world),
-                   'collectives': comm, 'rccl_probe': rccl_probe, 'host_side': 'sgdml_amd.hostchannel (no PyTorch in the ranks)',
-                   'preconditioner_form': wl.get('precon_form')},
-        'phases_ms': {'assemble': asm_ms, 'precon': pre_ms, 'pcg': pcg_ms},
-        'ms_per_pcg_iteration': pcg_ms / args.cg_iters,
-        'collectives_per_step': res['collectives_per_step'],
-        'collective_bytes_per_step_per_rank': res['collective_bytes_per_step_per_rank'],
-        'resid_over_norm_y': res['resid_over_norm_y'],
-        'one_gpu_s_per_step': None if one_gpu is None else one_gpu['s_per_step'],
-        'one_gpu': one_gpu,
-        'time_to_tol': to_tol,
-        'dist_cholesky': dchol,
-        'roofline': {'kernel': 'gemv_t_part + gemv_n_precon kernels (the two passes over this rank\'s rows of the preconditioner '
-                               'factor in one application, incl. the m-vector all-reduce between them): ' + str(wl.get('precon_form')),
-                     'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                     'traffic': None, 'avg_application_ms': gemv_ms, 'algorithmic_bytes_per_application': gemv_bytes,
-                     'note': 'achieved = algorithmic bytes of one application (2 x n/W x m x 8 B, 4 B in the fp32 form, + the '
-                             'm x m correction) / the kernels\' own time from HIP events (gdml_kernel_stat), max over ranks: '
-                             'comparable with the N = 1 record'},
-        'cpu_baseline': cpu,
-    }
+    comm_name = {'rccl': 'RCCL', 'host': 'host-staged collectives over TCP', 'none': 'none (one rank)'}[comm]
+    cg_block = None
+    if res is not None:
+        gemv_bytes = res['gemv']['bytes_per_application']
+        ach = gemv_bytes / (gemv_ms * 1e-3) / 1e9 if gemv_ms and gemv_ms > 0 else 0.0
+        cg_block = {
+            'workload': line_skeleton('cg', N, M, world, args.cg_iters, k)['workload'],
+            's_per_step': s_per_step, 'phases_ms': {'assemble': asm_ms, 'precon': pre_ms, 'pcg': pcg_ms},
+            'ms_per_pcg_iteration': pcg_ms / args.cg_iters, 'n_inducing_points': k, 'matrix_n': wl['n'], 'precon_m': wl['m'],
+            'pcg_iterations_per_step': args.cg_iters, 'preconditioner_form': wl.get('precon_form'),
+            'collectives_per_step': res['collectives_per_step'],
+            'collective_bytes_per_step_per_rank': res['collective_bytes_per_step_per_rank'],
+            'resid_over_norm_y': res['resid_over_norm_y'],
+            'one_gpu_s_per_step': None if one_gpu is None else one_gpu['s_per_step'], 'one_gpu': one_gpu,
+            'roofline': {'kernel': 'gemv_t_part + gemv_n_precon kernels (the two passes over this rank\'s rows of the preconditioner '
+                                   'factor in one application, incl. the m-vector all-reduce between them): ' + str(wl.get('precon_form')),
+                         'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                         'traffic': None, 'avg_application_ms': gemv_ms, 'algorithmic_bytes_per_application': gemv_bytes,
+                         'note': 'achieved = algorithmic bytes of one application (2 x n/W x m x 8 B, 4 B in the fp32 form, + the '
+                                 'm x m correction) / the kernels\' own time from HIP events (gdml_kernel_stat), max over ranks: '
+                                 'comparable with the N = 1 record'}}
+    elif wl is not None:
+        cg_block = wl  # {'error': ...}
+    sk = line_skeleton(workload, N, args.n_train if workload == 'analytic' else M, world, args.cg_iters, k)
+    common = {'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': False, 'scaling': 'strong',
+              'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic'}
+    cfg = {'workload': sk['workload'], 'n_atoms': N, 'sig': args.sig, 'lam': args.lam, 'parallelism': sk['parallelism'],
+           'collectives': comm, 'collectives_name': comm_name, 'rccl_probe': rccl_probe, 'rccl_ranks_seen': rccl_ranks_seen,
+           'host_side': 'sgdml_amd.hostchannel (no PyTorch in the ranks)'}
+    if workload == 'analytic':
+        ok = isinstance(dchol, dict) and 'build_solve_s' in dchol
+        if ok and not dchol['solve_rel_residual'] < 1e-10:
+            raise SystemExit('bench: residual of the timed distributed solve is %.3e (> 1e-10): refusing to report' % dchol['solve_rel_residual'])
+        cfg.update({'n_train': args.n_train, 'n_perms': 1, 'matrix_n': args.n_train * 3 * N})
+        out = dict(common, metric=sk['metric'], value=dchol['build_solve_s'] if ok else None, unit='s',
+                   ms_per_step=dchol['s_per_solve'] * 1e3 if ok else None, config=cfg,
+                   phases_ms=dchol.get('phases_ms') if ok else None, solve_rel_residual=dchol.get('solve_rel_residual') if ok else None,
+                   roofline=dchol.get('roofline') if ok else None, dist_cholesky=dchol, cg=cg_block, time_to_tol=to_tol,
+                   cpu_baseline=cpu)
+        out['scale_point'] = {'workload': sk['workload'], 'seconds': out['value'], 'n_gpus': world,
+                              'roofline_frac': None if not ok else dchol['roofline']['frac']}
+        if cg_block is not None and 's_per_step' in cg_block:
+            out['scale_point_cg'] = {'workload': cg_block['workload'], 'seconds': cg_block['s_per_step'], 'n_gpus': world,
+                                     'time_to_tol_s': None if not isinstance(to_tol, dict) else to_tol.get('time_to_tol_s', to_tol.get('train_wall_s'))}
+        return out
+    cfg.update({'n_train': M, 'n_inducing_points': k, 'matrix_n': wl['n'], 'precon_m': wl['m'],
+                'pcg_iterations_per_step': args.cg_iters, 'preconditioner_form': wl.get('precon_form')})
+    out = dict(common, metric=sk['metric'], value=s_per_step, unit='s', ms_per_step=s_per_step * 1e3, config=cfg,
+               phases_ms=cg_block['phases_ms'], ms_per_pcg_iteration=cg_block['ms_per_pcg_iteration'],
+               collectives_per_step=cg_block['collectives_per_step'],
+               collective_bytes_per_step_per_rank=cg_block['collective_bytes_per_step_per_rank'],
+               resid_over_norm_y=cg_block['resid_over_norm_y'], one_gpu_s_per_step=cg_block['one_gpu_s_per_step'], one_gpu=one_gpu,
+               time_to_tol=to_tol, dist_cholesky=dchol, roofline=cg_block['roofline'], cpu_baseline=cpu)
+    out['scale_point_cg'] = {'workload': cg_block['workload'], 'seconds': s_per_step, 'n_gpus': world,
+                             'time_to_tol_s': None if not isinstance(to_tol, dict) else to_tol.get('time_to_tol_s', to_tol.get('train_wall_s'))}
+    if isinstance(dchol, dict) and 'build_solve_s' in dchol:
+        out['scale_point'] = {'workload': line_skeleton('analytic', N, args.n_train, world)['workload'], 'seconds': dchol['build_solve_s'],
+                              'n_gpus': world, 'roofline_frac': dchol['roofline']['frac']}
+    return out
 
 
 def predict_sweep(ctx, lib, Rq_all, N, M, P, n_dev_reps=20):
@@ -811,11 +911,14 @@ def run_analytic(args):
     y_std = np.std(y)
     y /= y_std
 
+    t_first = time.perf_counter()
     ctx = _lib.Context(0)
+    first_call = {'context_s': time.perf_counter() - t_first}
     tp = np.zeros((1, N * (N - 1) // 2), dtype=np.int64)
     tp[0] = np.arange(tp.shape[1])
     xd, gd = ctx.desc_from_R(Rf[:M], N)
     ctx.train_upload(xd, gd, tp)  # resident before timing
+    first_call['descriptors_and_upload_s'] = time.perf_counter() - t_first - first_call['context_s']
     # query geometries resident in HBM
     dR, dE, dF = C.c_void_p(), C.c_void_p(), C.c_void_p()
     lib = ctx._lib
@@ -851,7 +954,18 @@ def run_analytic(args):
         return alphas
 
     step.first = True
-    for _ in range(args.warmup):
+    # what the FIRST build+solve of a process costs (`first_call_in_process`, beside the steady-state `value`): code-object
+    # loading at first launch, the 31.8 GB hipMalloc of the matrix, the model upload
+    t_fs = time.perf_counter()
+    n_warm = args.warmup
+    if n_warm > 0:
+        step(False)
+        ctx.sync()
+        n_warm -= 1
+        first_call['first_step_s'] = time.perf_counter() - t_fs
+        first_call['first_build_solve_s'] = sum(ctx.phase_ms(k_)[0] for k_ in ('assemble', 'factor', 'solve')) / 1e3
+        first_call['process_start_to_first_solution_s'] = time.perf_counter() - t_first
+    for _ in range(n_warm):
         step(False)
     if not args.no_profile:
         ctx.profile(True)
@@ -910,8 +1024,9 @@ def run_analytic(args):
             extra['predict_kernel'] = {'kernel': 'predict_kernel', 'avg_launch_ms': p_ms / max(1, p_n),
                                        'algorithmic_TFLOPs': p_fl / (p_ms * 1e-3) / 1e12}
     chol_tf = (n**3 / 3.0) / (np.mean(phases['factor']) * 1e-3) / 1e12
+    sk = line_skeleton('analytic', N, M, 1)
     out = {
-        'metric': 'kernel-matrix build+solve wall-clock, N_train={} {}-atom (aspirin-sized)'.format(M, N),
+        'metric': sk['metric'],
         'value': build_solve_ms / 1e3,
         'unit': 's',
         'n_gpus': 1,
@@ -923,10 +1038,8 @@ def run_analytic(args):
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': 'aspirin-sized N=21 N_train={} analytic Cholesky, 1xMI355X '
-                               '(BASELINE.json configs[1])'.format(M),
-                   'n_atoms': N, 'n_train': M, 'n_perms': 1, 'sig': sig, 'lam': args.lam,
-                   'matrix_n': n, 'query_batch': B, 'parallelism': 'single GPU'},
+        'config': {'workload': sk['workload'], 'n_atoms': N, 'n_train': M, 'n_perms': 1, 'sig': sig, 'lam': args.lam,
+                   'matrix_n': n, 'query_batch': B, 'parallelism': sk['parallelism']},
         'phases_ms': {k: float(np.mean(v)) for k, v in phases.items()},
         'cholesky_info': info_last[0],
         'solve_rel_residual': resid,
@@ -936,6 +1049,12 @@ def run_analytic(args):
         'roofline': roof,
     }
     out.update(extra)
+    out['first_call_in_process'] = dict(first_call, note='context creation, descriptors + upload, then the first step (warm-up, untimed): '
+                                        'first_build_solve_s are its device phases (first_step_s - that = hipMalloc of the matrix, code-object '
+                                        'loading, model upload); `value` is the steady state')
+    # the point this line contributes to a `--gpus 1, 2, 4, 8` curve (same keys in the N > 1 line)
+    out['scale_point'] = {'workload': sk['workload'], 'seconds': out['value'], 'n_gpus': 1,
+                          'roofline_frac': None if roof is None else roof['frac']}
     cpu_handle = None
     try:  # the metric names "predict forces/sec": the resident model at four batch sizes, with both rooflines
         ctx.profile(False)
@@ -999,6 +1118,11 @@ def run_analytic(args):
             except Exception as e:
                 cfgs.append({'config': label, 'error': repr(e)})
         out['configs'] = cfgs
+        for c_ in cfgs:  # the configs[2] point of this one-GPU run, under the key the N > 1 lines use
+            if isinstance(c_, dict) and str(c_.get('config', '')).startswith('configs[2]: ') and 'train_wall_s' in c_:
+                out['scale_point_cg'] = {'workload': 'configs[2] to solver_tol 1e-4 through GDMLTrain.train', 'seconds': None,
+                                         'n_gpus': 1, 'time_to_tol_s': c_['train_wall_s']}
+                break
     if not args.no_cpu:
         if cpu_handle is None:  # --no-configs: nothing to overlap with
             cpu_handle = start_cpu_sample(M if args.cpu_full else min(M, args.cpu_sample))

@@ -123,6 +123,9 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *                         entries per lane and task, asm.perm2_i_chunk (16) row points per workgroup, asm.perm2_debug (0)
  *                         timing-only ablation mask (results are wrong when set)
  *   gemm.debug (0)        ablation mask of the GEMM kernel (separate instantiation; 0 = production kernel)
+ *   gemm.persist (0)      1: fused trailing updates of at least four rounds run as 2 resident workgroups per CU that pull tiles
+ *                         from per-XCD counters (round 6; measured 1.5 % slower than one workgroup per tile: off)
+ *   gemm.trace (0)        k > 0: the k-th fused launch runs the traced instantiation and leaves gemm_trace.bin (tools/gemm_trace.py)
  *   gemm.nt_c (0)         non-temporal loads / stores of the C tile (after rocBLAS's Tensile kernel for this shape:
  *                         profiles/r03_vendor_kernels.txt; no gain measured)
  *   gemm.lds16 (3)        fused GEMM launches: 3 = the production loop (16-byte LDS layout, operand pairs of the next half k-tile
@@ -147,9 +150,10 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   lu.nb (64)            panel width of the LU fallback
  *   comm.force_collectives (0)  issue collectives even for world == 1 without a communicator (tests)
  *   dist.nb (512)         row-block size of the distributed Cholesky (multiple of 128)
- *   dist.lookahead (0)    distributed Cholesky: 1 = one panel of look-ahead over three streams (block broadcasts on a second
- *                         communicator); 0 = every step in order on the compute stream.  Off until the three-stream RCCL
- *                         schedule has run on more than one physical GPU
+ *   dist.lookahead (1 from two ranks on, else 0)  distributed Cholesky: 1 = one panel of look-ahead over three streams (block
+ *                         broadcasts on a second communicator); 0 = every step in order on the compute stream
+ *   dist.force_panels (0) 1: a one-rank gdml_dist_chol_solve keeps the K = 512 panel schedule of the distributed code instead of
+ *                         the single-GPU factorisation it otherwise degenerates to (tests / probes)
  *   nys.force_qr (0)      take the alternative (QR-equivalent) branch of the second Nystroem factorisation (tests)
  *   nys.force_fail (0)    treat the first k attempts of the jitter-stabilised Cholesky of K_mm as failed (tests)
  *   pcg.depth (2)         PCG iterations queued ahead of the host's convergence test / callback (0 = synchronous)

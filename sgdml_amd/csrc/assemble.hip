@@ -272,6 +272,7 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
     GDML_TRY(ctx_free(ctx, ctx->K));
     ctx->K = nullptr;
     ctx->precon = nullptr;
+    precon_release_aux(ctx);  // the auxiliary buffers of a preconditioner that lived in the old matrix go with it
   }
   if (!ctx->K) {
     GDML_TRY(ctx_alloc(ctx, (void**)&ctx->K, tot_rows * ld * 8));

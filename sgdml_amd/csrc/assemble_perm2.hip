@@ -912,14 +912,17 @@ static int perm2_plan(gdml_ctx* ctx) {
   // the plan depends on three options; they are read at the point of use like every other one: a changed value rebuilds it
   const int key = 1 + ctx_opt_i(ctx, "asm.perm2_split", 1) + 2 * ctx_opt_i(ctx, "asm.perm2_post", 1) + 4 * ctx_opt_i(ctx, "asm.perm2_es", 1) +
                   8 * ctx_opt_i(ctx, "asm.perm2_chunk", 12);
-  if (ts.p2 && ts.p2_key == key) return GDML_OK;
-  if (ts.p2) {
-    GDML_TRY(ctx_free(ctx, ts.p2));
-    GDML_TRY(ctx_free(ctx, ts.p2_TP));
+  if (ts.p2 && ts.p2_TP && ts.p2_key == key) return GDML_OK;
+  // (a plan is valid only with BOTH buffers and the packed tables in place: p2_key is set last, a failure on the way
+  //  leaves no half-built plan behind for the next assembly to launch on)
+  auto drop = [&]() {
+    if (ts.p2) ctx_free(ctx, ts.p2);
+    if (ts.p2_TP) ctx_free(ctx, ts.p2_TP);
     ts.p2 = nullptr;
     ts.p2_TP = nullptr;
-  }
-  ts.p2_key = key;
+    ts.p2_key = 0;
+  };
+  drop();
   const int N = ts.N, P = ts.P;
   std::vector<int> moved(N, 0);
   for (int p = 0; p < P; ++p)
@@ -1053,16 +1056,24 @@ static int perm2_plan(gdml_ctx* ctx) {
   ts.p2_nF = nF;
   ts.p2_nFb = nF - n_extra;
   ts.p2_ntasks = (int)tasks.size();
-  GDML_TRY(ctx_alloc(ctx, (void**)&ts.p2, (int64_t)blob.size()));
-  HIP_CHECK(ctx, hipMemcpyAsync(ts.p2, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
-  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the host vector goes out of scope
-  // the packed per-point tables (32 N^2 bytes per point)
   const int64_t NN = (int64_t)N * N;
-  GDML_TRY(ctx_alloc(ctx, (void**)&ts.p2_TP, ts.M * NN * 32));
-  hipLaunchKernelGGL(perm2_pack_kernel, dim3(ceil_div(ts.M * NN, 256)), dim3(256), 0, ctx->stream, ts.XF, ts.GD,
-                     reinterpret_cast<const int32_t*>(ts.p2 + ts.p2_o[0]), ts.M, (int)NN, ts.p2_TP);
-  ctx->launch_counter++;
-  HIP_CHECK(ctx, hipGetLastError());
+  int rc = ctx_alloc(ctx, (void**)&ts.p2, (int64_t)blob.size());
+  if (rc == GDML_OK) rc = ctx_alloc(ctx, (void**)&ts.p2_TP, ts.M * NN * 32);  // the packed per-point tables (32 N^2 bytes per point)
+  if (rc == GDML_OK && (hipMemcpyAsync(ts.p2, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx->stream) != hipSuccess))  // (the host vector goes out of scope)
+    rc = gdml_fail(ctx, GDML_ERR_HIP, "perm2_plan: upload of the plan failed");
+  if (rc == GDML_OK) {
+    hipLaunchKernelGGL(perm2_pack_kernel, dim3(ceil_div(ts.M * NN, 256)), dim3(256), 0, ctx->stream, ts.XF, ts.GD,
+                       reinterpret_cast<const int32_t*>(ts.p2 + ts.p2_o[0]), ts.M, (int)NN, ts.p2_TP);
+    ctx->launch_counter++;
+    if (hipGetLastError() != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "perm2_plan: table packing failed to launch");
+  }
+  if (rc != GDML_OK) {
+    drop();
+    // no memory for the extra tables: not an error of the assembly -- the general kernel needs none of them
+    return rc == GDML_ERR_OOM ? GDML_ERR_UNSUPPORTED : rc;
+  }
+  ts.p2_key = key;
   return GDML_OK;
 }
 

@@ -304,10 +304,16 @@ __global__ void __launch_bounds__(256) precon_finish_kernel(const double* __rest
 // from X is its column SPACE to an angle theta with theta^2 sigma_max << lam (fp32: 6e-8), and the spectrum
 // 1 - lam / (sigma_i + lam) on it -- which no rounded X can carry (1 - 1e-12), and which the stored fp64 factor itself only
 // holds to ~1e-10 (profiles/r05_pcg_bisect.txt).  So X is rounded to fp32 (half the bytes) and the spectrum is put back
-// by an m x m matrix:   P v = (X32 T0 X32^T v - v) / lam,   T0 = L_G^-T G0 L_G^-1,
-// G = X32^T X32 = L_G L_G^T (fp64 Gram of the rounded factor: X32 L_G^-T is orthonormal to rounding), G0 = I - lam L^-1 L^-T
-// = the Gram of the exact factor (L L^T = K_nm^T K_nm + lam I, iterative.py:293-306).  In exact arithmetic and without
-// rounding this IS (X X^T v - v)/lam; with it, it is the exact Woodbury inverse of a Nystroem approximation on range(X32).
+// by an m x m matrix:   P v = (X32 T0 X32^T v - v) / lam,   T0 = L_G^-T M0 L_G^-1,
+// G = X32^T X32 = L_G L_G^T (fp64 Gram of the rounded factor: Q32 = X32 L_G^-T is orthonormal to rounding), and M0 the
+// exact factor's operator in ITS orthonormal basis: X = Q L0^T with L0 L0^T = G0 = X^T X = I - lam L^-1 L^-T (the Gram of the
+// exact factor; L L^T = K_nm^T K_nm + lam I, iterative.py:293-306), so X X^T = Q (L0^T L0) Q^T and M0 = L0^T L0.
+// In exact arithmetic and without rounding (X32 = X, L_G = L0: T0 = I) this IS (X X^T v - v)/lam; with it, it is that
+// operator carried over to range(X32).  Round 5 used G0 = L0 L0^T in the place of M0 = L0^T L0: the same eigenvalues on
+// eigenvectors rotated by O(1 - s_min^2) inside range(X) -- invisible at lam = 1e-10 on well-supported inducing columns
+// (s^2 ~ 1 - 1e-10), 3 % of the operator on the round-6 fixture n10_p2_pbc (lam = 1e-4, s_min^2 = 0.06), where the test
+// that compares the forms found it.  M0 = G0 + (C^T C - C C^T) with C = I - L0: the difference is second order in C, so
+// the entries ~1 of G0 (the spectrum 1 - lam / (sigma + lam) the form exists to carry) are never re-rounded.
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // X32 <- float(X); pad columns [m, ld) of X32 <- 0.  X itself stays as it is (leverage scores, fall-back to the fp64 form)
@@ -369,6 +375,12 @@ __global__ void __launch_bounds__(256) sym_fill_kernel(double* __restrict__ A, i
 __global__ void __launch_bounds__(256) eye_minus_kernel(double* __restrict__ A, int64_t ld, int64_t m) {
   const int64_t r = blockIdx.x;
   for (int64_t c = threadIdx.x; c < m; c += 256) A[r * ld + c] = (c == r ? 1.0 : 0.0) - A[r * ld + c];
+}
+// C <- I - L (lower triangle incl. the diagonal of L), 0 above the diagonal and in the pad columns [m, ld)
+__global__ void __launch_bounds__(256) eye_minus_lower_kernel(const double* __restrict__ L, double* __restrict__ C, int64_t ld,
+                                                              int64_t m) {
+  const int64_t r = blockIdx.x;
+  for (int64_t c = threadIdx.x; c < ld; c += 256) C[r * ld + c] = c > r || c >= m ? 0.0 : (c == r ? 1.0 : 0.0) - L[r * ld + c];
 }
 // t_part[rc][c] = sum_{r in chunk rc} X32[r][c] v[r]: a thread owns four adjacent columns (16-byte loads); products and
 // sums in fp64 (the fp32 values are exact doubles).  The sums are COMPENSATED (Kahan): what the operator needs from
@@ -712,6 +724,20 @@ static int choose_precon_form(const gdml_ctx* ctx, const ShardGeo& sg, int64_t m
   return 8.0 * (double)sg.chunk * (double)m >= (double)((int64_t)1 << 30) ? 3 : 0;
 }
 
+// fp32 copy and Gram correction of form 3, the matrix-free form's Z: released when the form is rejected and when the
+// matrix buffer they belong to changes size (assemble.hip) -- not on every assembly: PCG restarts re-factor at one size
+void precon_release_f32(gdml_ctx* ctx) {
+  if (ctx->precon_X32) ctx_free(ctx, ctx->precon_X32);
+  if (ctx->precon_T0) ctx_free(ctx, ctx->precon_T0);
+  ctx->precon_X32 = nullptr; ctx->precon_X32_bytes = 0;
+  ctx->precon_T0 = nullptr; ctx->precon_T0_bytes = 0;
+}
+void precon_release_aux(gdml_ctx* ctx) {
+  precon_release_f32(ctx);
+  if (ctx->precon_Z) ctx_free(ctx, ctx->precon_Z);
+  ctx->precon_Z = nullptr; ctx->precon_Z_bytes = 0;
+}
+
 static int ensure_buf(gdml_ctx* ctx, void** p, int64_t* have, int64_t want) {
   if (*have >= want) return GDML_OK;
   if (*p) GDML_TRY(ctx_free(ctx, *p));
@@ -737,9 +763,10 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
     int rc_a = ensure_buf(ctx, (void**)&ctx->precon_X32, &ctx->precon_X32_bytes, (n_loc > 0 ? n_loc : 1) * ld * 4);
     if (rc_a == GDML_OK) rc_a = ensure_buf(ctx, (void**)&ctx->precon_T0, &ctx->precon_T0_bytes, m * ld * 8);
     if (rc_a == GDML_OK) rc_a = ctx_alloc(ctx, &tmp, 4 * m * ld * 8);
-    if (rc_a != GDML_OK && rc_a != GDML_ERR_OOM) return rc_a;
     // sharded: every rank must apply the same form (row blocks of ONE operator) -- free HBM differs between the ranks, so
-    // the decision is collective: the form is kept only if the buffers fit everywhere
+    // the decision is collective: the form is kept only if the buffers fit everywhere.  EVERY local outcome goes through
+    // the collective first (a rank that returned early on a non-OOM error left the others hanging in it); the error is
+    // reported afterwards.
     double fits = rc_a == GDML_OK ? 1.0 : 0.0;
     if (comm_active(ctx)) {
       double* d_flag;
@@ -751,8 +778,9 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
       fits = fits >= (double)ctx->world - 0.5 ? 1.0 : 0.0;
     }
     if (fits < 0.5) {
-      if (tmp) GDML_TRY(ctx_free(ctx, tmp));
-      return GDML_OK;
+      if (tmp) ctx_free(ctx, tmp);
+      precon_release_f32(ctx);  // a partly allocated form (X32 fits, T0 or the work space does not) holds no memory
+      return (rc_a != GDML_OK && rc_a != GDML_ERR_OOM) ? rc_a : GDML_OK;
     }
   }
   double* Rb = (double*)tmp;   // L^-T, later E_z = L_G^-T - I
@@ -809,7 +837,20 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
       ctx->opts["pcg.f32_last_min_pivot"] = dmin * dmin;  // diagnostic, read back with gdml_get_option
       if (!(dmin * dmin >= ctx_opt(ctx, "pcg.f32_min_pivot", 1e-7))) return GDML_OK;
     }
-    // T0 = Zt G0 Zt^T with Zt = L_G^-T = I + E_z.  Formed as G0 + W1 + W1^T + W1 E_z^T, W1 = E_z G0: every product has a
+    // G0 <- M0 = L0^T L0 = G0 + (C^T C - C C^T), C = I - L0, L0 L0^T = G0 (see the derivation above build_f32_form's kernels)
+    {
+      HIP_CHECK(ctx, hipMemcpyAsync(Gp, G0, m * ld * 8, hipMemcpyDeviceToDevice, st));
+      int inf0 = 0;
+      const int rc0 = chol_factor_device(ctx, Gp, m, ld, &inf0);
+      if (rc0 == GDML_ERR_NOT_PD || inf0 != 0) return GDML_OK;  // (cannot happen for a Gram matrix that passed the pivot test above)
+      GDML_TRY(rc0);
+      hipLaunchKernelGGL(eye_minus_lower_kernel, dim3((unsigned)m), dim3(256), 0, st, Gp, Rb, ld, m);
+      hipLaunchKernelGGL(syrk_tn_kernel, tri, dim3(256), 0, st, Rb, ld, m, m, Gc, ld, tiles, 0);  // C^T C (lower tiles)
+      hipLaunchKernelGGL(sym_fill_kernel, dim3((unsigned)m), dim3(256), 0, st, Gc, ld, m);
+      GDML_TRY(launch_gemm_nt_sub(ctx, st, Rb, ld, Rb, ld, Gc, ld, m, m, m, 0));                   // - C C^T
+      hipLaunchKernelGGL(vec_axpy_kernel, dim3(ceil_div(m * ld, 256)), dim3(256), 0, st, G0, Gc, 1.0, m * ld);
+    }
+    // T0 = Zt M0 Zt^T with Zt = L_G^-T = I + E_z.  Formed as G0 + W1 + W1^T + W1 E_z^T, W1 = E_z G0: every product has a
     // small factor (|E_z| ~ 1 - s_min^2), so the MFMA sums carry errors far below eps, and the entries ~1 of T0 come from
     // G0 by three additions -- as a plain triple product the diagonal would lose eps sqrt(m) ~ 5e-15, the scale of the
     // spectrum the matrix exists to carry.
@@ -829,6 +870,7 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
   };
   int rc = body();
   int rc2 = ctx_free(ctx, tmp);
+  if (rc != GDML_OK || !*usable) precon_release_f32(ctx);  // rejected form: the fp64 factor is what stays resident
   return rc != GDML_OK ? rc : rc2;
 }
 

@@ -80,10 +80,18 @@ struct GemmArgs {
   double* C2;
   int64_t M2, N2, K2;
   int tiles2;
+  // persistent launch (gemm_nt_sub_persist_kernel): 8 tile counters, one per XCD, 64 bytes apart; total work items
+  unsigned* queue;
+  int64_t n_items;
+  // option gemm.trace (tools/gemm_trace.py): per-tile shader-clock stamps of the traced instantiation, 8 words per workgroup
+  unsigned long long* trace;
 };
 
 template <bool PIPE, bool CACC, int CKS = GEMM_COMMIT_KS>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g);
+__global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_trace_kernel(GemmArgs g);
+template <int CKS, int FLAGS = 2>
+__global__ void __launch_bounds__(256, 2) gemm_nt_sub_persist_kernel(GemmArgs g);
 
 template <bool FULL>
 __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int64_t ld,
@@ -118,10 +126,12 @@ __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int
 // that a lane's four k of a tile are contiguous.
 // Full tiles, 16-byte aligned: wave-uniform base (tile corner + k offset: SGPRs) + the thread's constant 32-bit byte offsets
 // (row * ld + kc of its four chunks; a tile spans < 2^31 bytes): saddr-form loads, no 64-bit address arithmetic per k-tile.
-__device__ __forceinline__ void gemm_load_tile_u(const double* __restrict__ base, const unsigned (&off)[4], d2 (&r)[4]) {
-  // the base IS wave uniform; say so (the divergence analysis does not see it through the tile arithmetic) and keep the
-  // pointer in the global address space (a generic pointer rebuilt from integers becomes FLAT loads, which also count on
-  // lgkmcnt): scalar base + 32-bit lane offset = saddr-form global_load_dwordx4
+// Full tiles, 16-byte aligned: wave-uniform base (tile corner + k offset) + the thread's constant 32-bit byte offsets (row * ld + kc
+// of its four chunks; a tile spans < 2^31 bytes).  Round 6 measured the same loads as BUFFER loads (tile corner in a resource, lane
+// offset as voffset, k offset as soffset: no 64-bit lane arithmetic at all): 2.0-2.2 % SLOWER factorisation on two boxes
+// (profiles/r06_gemm_variants.txt); and issuing them 16 MFMAs later (after the first MFMA group): +5.8 % -- the 48 MFMAs
+// between issue and LDS commit are needed.
+__device__ __forceinline__ void gemm_load_tile_g(const double* __restrict__ base, const unsigned (&off)[4], d2 (&r)[4]) {
   typedef const __attribute__((address_space(1))) char* gcptr;
   typedef const __attribute__((address_space(1))) d2* gd2ptr;
   const uint64_t p = reinterpret_cast<uint64_t>(base);
@@ -153,11 +163,19 @@ __device__ __forceinline__ void gemm_store_tile(double* __restrict__ S, int tid,
 
 // ABL = true only in the ablation instantiation (option gemm.debug != 0): the production kernel carries
 // none of the ablation branches.
-template <bool FULL, bool ABL, bool PIPE = false, bool CACC = true, int CKS = GEMM_COMMIT_KS>
+// FLAGS: 1 = traced instantiation; 2 = persistent caller: lane-derived values are recomputed per tile from an opaque copy of the
+// thread index (otherwise they are hoisted out of the tile loop and spilled across the k loop)
+template <bool FULL, bool ABL, bool PIPE = false, bool CACC = true, int CKS = GEMM_COMMIT_KS, int FLAGS = 0>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[2][GT * GPITCH],
-                                               int64_t row0, int64_t col0) {
+                                               int64_t row0, int64_t col0, int64_t trace_slot = 0, unsigned* s_next = nullptr) {
   const int dbg = ABL ? g.dbg : 0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // traced instantiation only: stamps of the tile's phases and the time parked before / in the k-tile barrier
+  unsigned long long tr_t0 = 0, tr_t1 = 0, tr_t3 = 0, tr_vm = 0, tr_bar = 0, tr_mx = 0;
+  constexpr bool TR = (FLAGS & 1) != 0;
+  if constexpr (TR) tr_t0 = __builtin_amdgcn_s_memtime();
+  int tid_ = threadIdx.x;
+  if constexpr ((FLAGS & 2) != 0) asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
 
@@ -204,6 +222,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
     gemm_store_tile(lds[0][1], tid, rb);
   }
   __syncthreads();
+  if constexpr (TR) tr_t1 = __builtin_amdgcn_s_memtime();
 
   if constexpr (PIPE) {
     // ---- 16-byte LDS layout (gemm_store_tile16): per k-tile two batches of 8 ds_read_b128 + 32 MFMAs.  The sign lives in
@@ -222,8 +241,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
     auto load_ab = [&](int64_t kt_, d2 (&ra_)[4], d2 (&rb_)[4]) {
       if constexpr (FULL) {
         const int64_t ko = kofs(kt_);
-        gemm_load_tile_u(Abase + ko, offA, ra_);
-        gemm_load_tile_u(Bbase + ko, offB, rb_);
+        gemm_load_tile_g(Abase + ko, offA, ra_);
+        gemm_load_tile_g(Bbase + ko, offB, rb_);
       } else {
         gemm_load_tile<FULL>(g.A, g.lda, row0, g.M, kofs(kt_), g.K, tid, ra_);
         gemm_load_tile<FULL>(g.B, g.ldb, col0, g.N, kofs(kt_), g.K, tid, rb_);
@@ -290,12 +309,27 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
           __builtin_amdgcn_sched_barrier(0);
           mfma16(a1, b1, 0);
           __builtin_amdgcn_sched_barrier(0);
+          unsigned long long ta_ = 0, tm_ = 0;
+          if constexpr (TR && HN) {
+            ta_ = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            tm_ = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
           if constexpr (HN) {
             gemm_store_tile16(lds[cur ^ 1][0], tid, ra);
             gemm_store_tile16(lds[cur ^ 1][1], tid, rb);
           }
           if constexpr (HN) {
             __syncthreads();
+            if constexpr (TR) {
+              const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              const unsigned long long dv = tm_ - ta_, db = tb_ - tm_;
+              tr_vm += dv; tr_bar += db;
+              const unsigned long long mv = tr_mx >> 32, mb = tr_mx & 0xffffffffull;
+              tr_mx = ((dv > mv ? dv : mv) << 32) | (db > mb ? db : mb);
+            }
             read_half(a0, b0, cur ^ 1, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -303,7 +337,21 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
           __builtin_amdgcn_sched_barrier(0);
         };
         for (int kt = 0; kt + 1 < nk32; ++kt) step(kt, std::true_type{});
+        // persistent caller: the index of the workgroup's NEXT tile is requested here -- the counter's round trip (device
+        // scope: microseconds) passes under the last 64 MFMAs and the stores.  Requested at the top of a tile it sat in
+        // front of the tile's own loads (memory operations of a wavefront return in order: every tile started with the
+        // round trip exposed, 11 k cycles between two tiles of a slot -- no better than a workgroup launch).
+        unsigned nxt_ = 0;
+        if constexpr ((FLAGS & 2) != 0 && FULL) {
+          if (tid == 0) nxt_ = atomicAdd(g.queue, 1u);
+        }
         step(nk32 - 1, std::false_type{});
+        if constexpr ((FLAGS & 2) != 0 && FULL) {
+          if (tid == 0) {
+            s_next[0] = nxt_;
+            s_next[1] = 1u;  // "fetched"
+          }
+        }
       }
     } else
     for (int64_t kt = 0; kt < nk; ++kt) {
@@ -390,6 +438,19 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 
   // ---- epilogue: C -= acc.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r.
   // All loads of a 64x16 column strip are issued before the first use (no serialised round trips).
+  if constexpr (TR) tr_t3 = __builtin_amdgcn_s_memtime();
+  auto trace_out = [&]() {
+    if constexpr (TR) {
+      if (g.trace != nullptr && (threadIdx.x & 63) == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        unsigned long long* o = g.trace + (trace_slot * 4 + (threadIdx.x >> 6)) * 8;
+        o[0] = tr_t0; o[1] = tr_t1; o[2] = tr_t3; o[3] = t4; o[4] = tr_vm; o[5] = tr_bar; o[6] = tr_mx;
+        o[7] = ((unsigned long long)xcc << 32) | hw;
+      }
+    }
+  };
   if (CIN) {
     // recompute the store addresses from laundered copies: the compiler otherwise keeps the prologue's 32 load addresses
     // alive across the main loop (spilled to scratch)
@@ -413,6 +474,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) (Ct2 + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff2 + j * 16] = SGN * acc[i][j][r];
+    trace_out();
     return;
   }
 #pragma unroll
@@ -452,8 +514,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
 }
 
 // block index -> tile (XCD-aware 8x8 super tiles: block b runs on XCD b % 8) and the tile's GEMM
-template <bool ABL, bool PIPE = false, bool CACC = true, int CKS = GEMM_COMMIT_KS>
-__device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][GT * GPITCH], int64_t b) {
+template <bool ABL, bool PIPE = false, bool CACC = true, int CKS = GEMM_COMMIT_KS, int FLAGS = 0>
+__device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][GT * GPITCH], int64_t b, unsigned* s_next = nullptr) {
+  const int64_t b_launch = b;
   if (b < g.tiles2) {  // second problem (workgroup-uniform branch)
     const int tn2 = (int)((g.N2 + GT - 1) / GT);
     const int64_t ti = b / tn2, tj = b - ti * tn2;
@@ -464,9 +527,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
     const int64_t row0 = ti * GT, col0 = tj * GT;
     const bool full = (row0 + GT <= h.M) && (col0 + GT <= h.N) && ((h.K & (GBK - 1)) == 0) && h.aligned;
     if (full)
-      gemm_tile_body<true, ABL, PIPE, CACC, CKS>(h, lds, row0, col0);
+      gemm_tile_body<true, ABL, PIPE, CACC, CKS, (FLAGS & 2)>(h, lds, row0, col0, 0, s_next);
     else
-      gemm_tile_body<false, ABL, PIPE, CACC, CKS>(h, lds, row0, col0);
+      gemm_tile_body<false, ABL, PIPE, CACC, CKS, (FLAGS & 2)>(h, lds, row0, col0);
     if (g.ready && ti < g.ready_rows && tj < g.ready_rows) {
       __threadfence();
       __syncthreads();
@@ -510,9 +573,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
   }
   const bool full = (row0 + GT <= g.M) && (col0 + GT <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
   if (full)
-    gemm_tile_body<true, ABL, PIPE, CACC, CKS>(g, lds, row0, col0);
+    gemm_tile_body<true, ABL, PIPE, CACC, CKS, FLAGS>(g, lds, row0, col0, b_launch, s_next);
   else
-    gemm_tile_body<false, ABL, PIPE, CACC, CKS>(g, lds, row0, col0);
+    gemm_tile_body<false, ABL, PIPE, CACC, CKS, (FLAGS & 2)>(g, lds, row0, col0);
   if (g.ready && g.tiles2 == 0 && ti < g.ready_rows && tj < g.ready_rows) {  // publish the tile (release: every thread's stores, then one count)
     __threadfence();
     __syncthreads();
@@ -559,6 +622,7 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   g.col0_first = (diag && diag->col0_first) ? 1 : 0;
   g.ready = nullptr; g.ready_target = 0; g.ready_rows = 0;
   g.A2 = g.B2 = nullptr; g.C2 = nullptr; g.M2 = g.N2 = g.K2 = 0; g.tiles2 = 0;
+  g.trace = nullptr; g.queue = nullptr; g.n_items = 0;
   if (cyc) { g.cyc_W = cyc->W; g.cyc_rank = cyc->rank; g.cyc_lb0 = cyc->lb0; g.cyc_nb = cyc->nb; g.cyc_col0 = cyc->col0; g.cyc_block_rows = cyc->block_rows; }
   g.dbg = ctx_opt_i(ctx, "gemm.debug", 0);
   g.nt_c = ctx_opt_i(ctx, "gemm.nt_c", 0);
@@ -587,6 +651,49 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
       g.tiles2 = (int)(ceil_div(g.M2, GT) * ceil_div(g.N2, GT));
     }
     const dim3 grid((unsigned)(blocks + 1 + g.tiles2));
+    // gemm.trace = k > 0: the k-th fused launch since the option was set runs the traced instantiation and leaves
+    // gemm_trace.bin (header: blocks, tiles2, tiles_m, s_begin, n_super, col0_first; then 4 x 8 words per workgroup)
+    const int trace_k = ctx_opt_i(ctx, "gemm.trace", 0);
+    if (trace_k > 0 && ++ctx->gemm_trace_seen == trace_k) {
+      const size_t words = (size_t)(blocks + g.tiles2) * 32;
+      unsigned long long* d_tr = nullptr;
+      GDML_TRY(ctx_alloc(ctx, (void**)&d_tr, (int64_t)(words * 8)));
+      HIP_CHECK(ctx, hipMemsetAsync(d_tr, 0, words * 8, st));
+      g.trace = d_tr;
+      const int64_t resident_t = 2 * (int64_t)ctx->num_cus;
+      if (ctx_opt_i(ctx, "gemm.persist", 0) != 0 && blocks + g.tiles2 >= 4 * resident_t && ctx->gemm_queue != nullptr) {
+        if (ctx->gemm_queue_next >= ctx->gemm_queue_sets) {
+          HIP_CHECK(ctx, hipMemsetAsync(ctx->gemm_queue, 0, (size_t)ctx->gemm_queue_sets * 512, st));
+          ctx->gemm_queue_next = 0;
+        }
+        g.queue = ctx->gemm_queue + (size_t)(ctx->gemm_queue_next++) * 128;
+        g.n_items = blocks + g.tiles2;
+        hipLaunchKernelGGL((gemm_nt_sub_persist_kernel<5, 3>), dim3((unsigned)resident_t), dim3(256), 0, st, g);
+      } else
+      hipLaunchKernelGGL(gemm_nt_sub_diag_trace_kernel, grid, dim3(256), 0, st, g);
+      std::vector<unsigned long long> h(words + 8);
+      HIP_CHECK(ctx, hipMemcpyAsync(h.data() + 8, d_tr, words * 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(ctx, hipStreamSynchronize(st));
+      h[0] = (unsigned long long)blocks; h[1] = (unsigned long long)g.tiles2; h[2] = (unsigned long long)g.tiles_m;
+      h[3] = (unsigned long long)g.s_begin; h[4] = (unsigned long long)g.n_super; h[5] = (unsigned long long)g.col0_first;
+      h[6] = (unsigned long long)K; h[7] = (unsigned long long)M;
+      if (FILE* f = fopen("gemm_trace.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+      GDML_TRY(ctx_free(ctx, d_tr));
+      ktime_end(ctx, slot, "gemm_nt_sub_diag_traced", 0.0);
+      ctx->launch_counter++;
+      return GDML_OK;
+    }
+    // gemm.persist (default 0: measured 1.5 % slower, profiles/r06_gemm_variants.txt): resident workgroups pulling tiles from per-XCD counters, for launches of at least four rounds
+    const int64_t resident = 2 * (int64_t)ctx->num_cus;
+    if (ctx_opt_i(ctx, "gemm.persist", 0) != 0 && blocks + g.tiles2 >= 4 * resident && ctx->gemm_queue != nullptr) {
+      if (ctx->gemm_queue_next >= ctx->gemm_queue_sets) {  // (chol_factor_device zeroes the ring; a caller that does not gets a fresh one here)
+        HIP_CHECK(ctx, hipMemsetAsync(ctx->gemm_queue, 0, (size_t)ctx->gemm_queue_sets * 512, st));
+        ctx->gemm_queue_next = 0;
+      }
+      g.queue = ctx->gemm_queue + (size_t)(ctx->gemm_queue_next++) * 128;
+      g.n_items = blocks + g.tiles2;
+      hipLaunchKernelGGL((gemm_nt_sub_persist_kernel<5>), dim3((unsigned)resident), dim3(256), 0, st, g);
+    } else
     // gemm.lds16 = 2: the loop with its last k-tile inside (A/B reference of the peeled production loop)
     if (ctx_opt_i(ctx, "gemm.lds16", 3) == 2) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 4>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 5>), grid, dim3(256), 0, st, g);
@@ -918,6 +1025,87 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
     return;
   }
   gemm_block<false, PIPE, CACC, CKS>(g, lds, (int64_t)blockIdx.x - 1);
+}
+
+// Persistent form of the fused launch (round 6, option gemm.persist): 2 workgroups per CU stay resident and pull tiles
+// from per-XCD counters in the order the hardware dispatcher would have started them (item i of XCD x = block 8 i + x:
+// the same super-tile -> L2 mapping), so a slot never waits for a workgroup launch between two tiles (measured with the
+// traced kernel: 8-22 k cycles from a tile's last store to the first instruction of the next workgroup on that CU, during
+// which the CU's other workgroup runs alone at ~0.7 of the pipe -- profiles/r06_gemm_trace.txt).  The index of the NEXT
+// tile is requested before a tile's last k-tile (gemm_tile_body); workgroup 0 factors the diagonal block first and then joins.
+template <int CKS, int FLAGS>
+__global__ void __launch_bounds__(256, 2) gemm_nt_sub_persist_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
+  __shared__ unsigned s_item[2];
+  if (blockIdx.x == 0 && g.diagA != nullptr) {
+    if (g.ready) {
+      if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(g.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.ready_target) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 24)) { atomicExch(g.ready + 1, 1); break; }
+        }
+      }
+      __syncthreads();
+      __threadfence();
+    }
+    diag_block_role(g.diagA, g.ldc, g.diag_nbw, g.diag_off, g.diag_info, &lds[0][0][0]);
+    __syncthreads();
+  }
+  const unsigned xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // XCC_ID: the XCD this workgroup really runs on
+  unsigned* const q = g.queue + xcd * 16;
+  // items of this XCD: first the second problem's blocks v = 8 i + xcd < tiles2, then the tile list's blocks
+  const unsigned n2 = (unsigned)g.tiles2 > xcd ? ((unsigned)g.tiles2 - xcd + 7u) / 8u : 0u;
+  const unsigned n_mine = n2 + (unsigned)((g.n_items - g.tiles2) / 8);
+  if (threadIdx.x == 0) s_item[0] = atomicAdd(q, 1u);
+  __syncthreads();
+  unsigned item = __builtin_amdgcn_readfirstlane(s_item[0]);
+  while (item < n_mine) {
+    if (threadIdx.x == 0) s_item[1] = 0u;  // set by the tile body once it has requested the next item
+    // the arguments are re-read from the kernarg segment per tile (an opaque pointer): kept live across the tile body they
+    // cost ~300 SGPR spills
+    // (constant address space: scalar loads; through a generic pointer they would be vector loads and every tile
+    //  parameter a lane value)
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc parses kernel bodies too and has no address spaces)
+    typedef const __attribute__((address_space(4))) GemmArgs* kernarg_ptr;
+    kernarg_ptr gp = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();  // GemmArgs is the kernel's only argument
+    asm volatile("" : "+s"(gp));
+    GemmArgs gl = *gp;
+#else
+    GemmArgs gl = g;
+#endif
+    gl.queue = q;  // this XCD's counter
+    const int64_t v = item < n2 ? (int64_t)item * 8 + xcd : (int64_t)gl.tiles2 + (int64_t)(item - n2) * 8 + xcd;
+    gemm_block<false, true, true, CKS, FLAGS>(gl, lds, v, s_item);
+    __syncthreads();  // every wavefront is done with the LDS tiles; s_item is visible
+    if (s_item[1] == 0u) {  // a skipped or ragged tile: nothing was requested on the way (workgroup-uniform)
+      if (threadIdx.x == 0) s_item[0] = atomicAdd(q, 1u);
+      __syncthreads();
+    }
+    item = __builtin_amdgcn_readfirstlane(s_item[0]);
+    __syncthreads();  // (s_item is rewritten at the top)
+  }
+}
+
+// Traced instantiation of the production loop (option gemm.trace): the same launch, every full tile leaves its stamps.
+__global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_trace_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
+  if (blockIdx.x == 0) {
+    if (g.ready) {
+      if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(g.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.ready_target) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 24)) { atomicExch(g.ready + 1, 1); break; }
+        }
+      }
+      __syncthreads();
+      __threadfence();
+    }
+    diag_block_role(g.diagA, g.ldc, g.diag_nbw, g.diag_off, g.diag_info, &lds[0][0][0]);
+    return;
+  }
+  gemm_block<false, true, true, 5, 1>(g, lds, (int64_t)blockIdx.x - 1);
 }
 
 __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int64_t ld, int w,
@@ -1486,6 +1674,10 @@ int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int6
 int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out, int64_t n_rows) {
   if (n_rows < n) n_rows = n;
   HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  if (ctx->gemm_queue) {  // tile counters of the persistent trailing updates: one zeroed set per launch
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->gemm_queue, 0, (size_t)ctx->gemm_queue_sets * 512, ctx->stream));
+    ctx->gemm_queue_next = 0;
+  }
   int64_t NB = (int64_t)ctx_opt(ctx, "chol.nb", 512);  // outer panel width (multiple of 64)
   if (NB < 64 || NB % 64 || NB > 512) NB = 512;  // the diagonal-block role and the row-local solve hold at most 8 x 64 columns
   const bool lookahead = ctx_opt_i(ctx, "chol.lookahead", 1) != 0;

@@ -25,15 +25,20 @@ struct RcclApi {
   ncclResult_t_ (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
   ncclResult_t_ (*AllGather)(const void*, void*, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
   ncclResult_t_ (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+  ncclResult_t_ (*CommCount)(ncclComm_t_, int*) = nullptr;  // optional
 };
 static RcclApi g_rccl;
 static const int kNcclDouble = 8, kNcclSum = 0;
 
 static bool rccl_load(std::string* err) {
   if (g_rccl.handle) return true;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // A copy already mapped into the process wins (a caller that brought PyTorch's bundled RCCL keeps ONE RCCL); otherwise the
+  // ROCm installation's own library is asked for by path BEFORE the loader's search order -- on a box with PyTorch on
+  // LD_LIBRARY_PATH the bare name resolved to torch/lib/librccl.so, which made "no PyTorch in the ranks" depend on the
+  // environment (round-5 review).
+  const char* names[] = {"/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1", "librccl.so", "librccl.so.1"};
   void* h = nullptr;
-  for (const char* n : names)  // a copy already in the process wins
+  for (const char* n : names)
     if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL)) != nullptr) break;
   if (!h)
     for (const char* n : names)
@@ -47,6 +52,7 @@ static bool rccl_load(std::string* err) {
   a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
   a.CommAbort = (decltype(a.CommAbort))dlsym(h, "ncclCommAbort");  // optional: comm_abort falls back to destroy
   a.CommSplit = (decltype(a.CommSplit))dlsym(h, "ncclCommSplit");  // optional: without it comm2 = comm
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
@@ -104,6 +110,10 @@ extern "C" int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int wo
   ctx->comm_aborted = false;
   ctx->rank = rank;
   ctx->world = world;
+  {  // what RCCL itself says about the communicator (read back with gdml_get_option "comm.rccl_ranks": bench.py's rccl_ranks_seen)
+    int cnt = -1;
+    if (g_rccl.CommCount && g_rccl.CommCount(comm, &cnt) == 0) ctx->opts["comm.rccl_ranks"] = (double)cnt;
+  }
   ctx->virtual_rank = false;
   ctx->coll_calls = 0;
   ctx->coll_bytes = 0.0;

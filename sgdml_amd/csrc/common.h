@@ -97,6 +97,9 @@ struct gdml_ctx {
   unsigned* d_fused_counter = nullptr;
   unsigned long long fused_seq = 0;
   int64_t launch_counter = 0;
+  unsigned* gemm_queue = nullptr;    // ring of tile-counter sets (8 x 64 bytes each) of the persistent GEMM launches
+  int gemm_queue_sets = 256, gemm_queue_next = 0;
+  int gemm_trace_seen = 0;           // fused GEMM launches seen since option gemm.trace was set (chol.hip)
   bool profiling = false;
   std::map<std::string, KernelStat> kstats;
   std::vector<PendingTiming> pending;
@@ -197,6 +200,8 @@ int ctx_scratch(gdml_ctx* ctx, int64_t bytes, double** out);
 void phase_begin(gdml_ctx* ctx);
 // kernel timing (no-ops unless ctx->profiling)
 int phase_resolve(gdml_ctx* ctx);  // reads a pending phase timer (waits for its end event)
+void precon_release_f32(gdml_ctx* ctx);  // cg.hip
+void precon_release_aux(gdml_ctx* ctx);
 int ktime_begin(gdml_ctx* ctx);  // returns slot or -1
 void ktime_end(gdml_ctx* ctx, int slot, const char* name, double work);
 int ktime_collect(gdml_ctx* ctx);

@@ -30,10 +30,10 @@ extern "C" int gdml_abi_version(void) { return 4; }
 static const char* kKnownOptions[] = {
     "asm.wave", "asm.j_chunk", "asm.lower", "asm.strip", "asm.i_chunk",
     "asm.pts", "asm.pts_nv", "asm.pts_nt", "asm.pts_xcd", "asm.pts_i_chunk", "asm.pts_debug", "asm.perm_debug", "asm.perm_w", "asm.perm_lds_kb", "asm.perm_level", "asm.perm_nimg", "asm.perm_pg", "asm.perm_na", "asm.perm_fast_store", "asm.perm_i_chunk", "asm.perm_compact", "asm.perm_lds_rows", "asm.perm2", "asm.perm2_min_n", "asm.perm2_min_p", "asm.perm2_split", "asm.perm2_post", "asm.perm2_ed", "asm.perm2_es", "asm.perm2_direct", "asm.perm2_chunk", "asm.perm2_i_chunk", "asm.perm2_debug",
-    "gemm.debug", "gemm.nt_c", "gemm.lds16", "chol.nb", "chol.small_update", "pcg.gemv_plain", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
+    "gemm.debug", "gemm.trace", "gemm.persist", "gemm.nt_c", "gemm.lds16", "chol.nb", "chol.small_update", "pcg.gemv_plain", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
     "chol.fused_min_rows", "chol.outer", "chol.outer_min_rows", "chol.merge_gemm1", "chol.tail_lookahead", "trsm.debug",
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide", "predict.fused", "predict.fused_rows", "predict.fused_spin",
-    "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb", "dist.lookahead", "pcg.depth", "pcg.precon_form", "pcg.f32_rows_per", "pcg.f32_rw", "pcg.f32_min_pivot", "pcg.f32_last_min_pivot", "pcg.f32_gram_rows"};
+    "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb", "dist.lookahead", "dist.force_panels", "pcg.depth", "pcg.precon_form", "pcg.f32_rows_per", "pcg.f32_rw", "pcg.f32_min_pivot", "pcg.f32_last_min_pivot", "pcg.f32_gram_rows"};
 
 double ctx_opt(const gdml_ctx* ctx, const char* key, double dflt) {
   auto it = ctx->opts.find(key);
@@ -131,10 +131,14 @@ static void arena_release_owner(gdml_ctx* ctx) {  // caller holds g_arena_mu
   for (size_t i = a->blocks.size(); i-- > 0;)
     if (a->blocks[i].owner == ctx) a->blocks.erase(a->blocks.begin() + (long)i);
 }
-static int64_t arena_idle_bytes(const DeviceArena* a) {  // caller holds g_arena_mu
-  int64_t used = 0;
-  for (const ArenaBlock& b : a->blocks) used += b.bytes;
-  return a->bytes - used;
+static int64_t arena_largest_gap(const DeviceArena* a) {  // caller holds g_arena_mu; blocks are sorted by offset
+  int64_t best = 0, off = 0;
+  for (const ArenaBlock& b : a->blocks) {
+    if (b.off - off > best) best = b.off - off;
+    off = b.off + b.bytes;
+  }
+  if (a->bytes - off > best) best = a->bytes - off;
+  return best;
 }
 
 extern "C" int gdml_device_count(int* n_out) {
@@ -192,7 +196,9 @@ extern "C" int gdml_ctx_create(int device, gdml_ctx** ctx_out) {
       (e = hipEventCreateWithFlags(&ctx->ev_la[3], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&ctx->ev_la[4], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&ctx->ev_la[5], hipEventDisableTiming)) != hipSuccess ||
-      (e = hipMalloc((void**)&ctx->d_info, 64)) != hipSuccess) {
+      (e = hipMalloc((void**)&ctx->d_info, 64)) != hipSuccess ||
+      (e = hipMalloc((void**)&ctx->gemm_queue, (size_t)ctx->gemm_queue_sets * 512)) != hipSuccess ||
+      (e = hipMemset(ctx->gemm_queue, 0, (size_t)ctx->gemm_queue_sets * 512)) != hipSuccess) {
     gdml_fail(nullptr, GDML_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
     delete ctx;
     return GDML_ERR_HIP;
@@ -221,6 +227,7 @@ extern "C" int gdml_ctx_destroy(gdml_ctx* ctx) {
     arena_release_owner(ctx);  // the block itself stays with the process
   }
   if (ctx->d_info) hipFree(ctx->d_info);
+  if (ctx->gemm_queue) hipFree(ctx->gemm_queue);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   for (hipEvent_t ev : ctx->ev_la)
@@ -252,12 +259,14 @@ extern "C" int gdml_mem_info(gdml_ctx* ctx, int64_t* held, int64_t* free_b, int6
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   HIP_CHECK(ctx, hipMemGetInfo(&f, &t));
   if (held) *held = ctx->held;
-  // what a large buffer of this context could get: driver-free memory plus the idle part of the process arena (the
-  // context's own resident matrix is re-used in place by the next assembly: callers add resident_K_bytes themselves)
+  // what large buffers of this context could get: driver-free memory plus the LARGEST contiguous gap of the process arena
+  // (a carve needs one gap: the sum of the idle pieces -- the round-5 figure -- promised memory that a fragmented arena
+  // cannot hand out; the context's own resident matrix is re-used in place by the next assembly: callers add
+  // resident_K_bytes themselves)
   {
     std::lock_guard<std::mutex> lk(g_arena_mu);
     const DeviceArena* a = arena_of(ctx);
-    if (a && a->base) f += (size_t)arena_idle_bytes(a);
+    if (a && a->base) f += (size_t)arena_largest_gap(a);
   }
   if (free_b) *free_b = (int64_t)f;
   if (total_b) *total_b = (int64_t)t;

@@ -119,6 +119,19 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int64_t N3 = 3 * (int64_t)ts.N, n = ts.M * N3;
   if (n_in != n) return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_dist_chol_solve: n mismatch");
+  if ((ctx->world <= 1) && ctx_opt_i(ctx, "dist.force_panels", 0) == 0) {
+    // One rank: the block-row-cyclic layout IS the plain layout and no collective moves data, so the single-GPU schedule
+    // applies as it stands -- K = 1024 trailing updates with the diagonal block factored inside them (chol.hip) instead of
+    // this file's K = 512 panels (1.39-1.53 s against 1.27 s at n = 63 000, profiles/r03_dist_chol_lookahead_1rank.txt).
+    // Option dist.force_panels = 1 keeps the panel schedule (tests and probes of the distributed code on one rank).
+    GDML_TRY(gdml_assemble_A(ctx, sig, lam, 0, 1));
+    GDML_TRY(gdml_chol_set_rhs(ctx, y, n));
+    int inf = 0;
+    const int rc1 = gdml_chol_factor(ctx, lam, &inf);
+    if (info_out) *info_out = inf;
+    if (rc1 != GDML_OK) return rc1;
+    return gdml_chol_solve(ctx, nullptr, n, 0, alphas_out);
+  }
   Cyc c;
   c.W = ctx->world > 0 ? ctx->world : 1;
   c.rank = ctx->rank;
@@ -175,13 +188,15 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
     //                       -> owner(k+1) factors diagonal block k+1 -> broadcast of it   (broadcasts: second communicator)
     //   sn (collective)     pack + all-gather + unpack of the whole panel k            (under the bulk update of panel k-1)
     //   sb (bulk)           update of the columns right of block k+1 by panel k         (under the critical path of k+1)
-    // Default (dist.lookahead = 0): the same steps in the same order on ONE stream and one communicator -- the schedule
-    // that needs nothing from RCCL beyond in-order execution.  The three-stream schedule issues collectives of two
-    // communicators from two streams (always from this one host thread, in the same order on every rank); it has run with
-    // one rank and with host-staged collectives only, so it stays opt-in until it has run on several physical GPUs.
+    // dist.lookahead = 0: the same steps in the same order on ONE stream and one communicator -- the schedule that needs
+    // nothing from RCCL beyond in-order execution.  The three-stream schedule issues collectives of two communicators from
+    // two streams (always from this one host thread, in the same order on every rank); it has run with one rank and with
+    // host-staged collectives (2-3 processes sharing the GPU), not yet on several physical GPUs.
     phase_begin(ctx);
     HIP_CHECK(ctx, hipStreamSynchronize(st));  // assembly, right-hand side, info slot: visible to the other streams
-    const bool la = ctx_opt_i(ctx, "dist.lookahead", 0) != 0;
+    // default (round 6): look-ahead from two ranks on -- the per-panel model in DESIGN.md section 5: without it the 4 n^2 / W ... 4 n^2
+    // bytes of panel all-gather per rank are serialised with the update on one stream and exposed in full
+    const bool la = ctx_opt_i(ctx, "dist.lookahead", c.W > 1 ? 1 : 0) != 0;
     hipStream_t sa = la ? ctx->stream2 : st, sb = st, sn = st;  // stream2 is the high-priority one
     hipStream_t sn_own = nullptr;
     hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_p[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};

@@ -21,6 +21,8 @@
 #include <stddef.h>
 
 #include "common.h"
+#include <chrono>
+#include <thread>
 
 int upload_perms(gdml_ctx* ctx, const int64_t* tril_perms, int P, int N, std::vector<int32_t>& h_tp,
                  std::vector<int32_t>& h_perm, std::vector<int32_t>& h_pinv);
@@ -1343,12 +1345,20 @@ static int predict_fused(gdml_ctx* ctx, const double* R, int64_t B, const double
   volatile unsigned long long* flag = (volatile unsigned long long*)ctx->h_map;
   bool seen = false;
   if (ctx_opt_i(ctx, "predict.fused_spin", 1)) {
-    for (int64_t spin = 0; spin < ((int64_t)1 << 26); ++spin) {  // bounded: a few hundred ms of polling at most
+    // bounded by WALL CLOCK (2 ms: the kernel takes ~20 us; a 2^26-iteration bound was seconds of busy waiting on recent
+    // x86), checked every 256 polls; beyond it the stream synchronisation below takes over
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+    for (unsigned spin = 0;; ++spin) {
       if (*flag == A.seq) {
         seen = true;
         break;
       }
+      if ((spin & 255u) == 255u && std::chrono::steady_clock::now() > t_end) break;
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
     }
   }
   if (!seen) {

@@ -342,5 +342,13 @@ class Iterative(object):
         to_dof = (3 * n_atoms) ** 2 * 8
         lin = -(-n_train // max(1, int(world))) * to_dof  # n_loc m 8 = ceil(M / W) k (3N)^2 8
         sq = 2 * to_dof  # 2 m^2 8
-        k = (np.sqrt(lin**2 + 4.0 * sq * budget_bytes) - lin) / (2 * sq)
+
+        def solve(lin_, sq_):
+            return (np.sqrt(lin_**2 + 4.0 * sq_ * budget_bytes) - lin_) / (2 * sq_)
+
+        k = solve(lin, sq)
+        if lin * k >= 2**30:
+            # the fp32 + Gram-correction form is chosen from 1 GiB of factor per rank (csrc/cg.hip::choose_precon_form): it
+            # holds the fp64 factor AND its fp32 copy (1.5 x) plus T0 and four m x m work matrices while it is built
+            k = solve(1.5 * lin, sq + 5 * to_dof)
         return min(int(k), n_train)

@@ -397,6 +397,8 @@ def test_dropin_train_iterative(golden):
         'sig': int(g['sig']), 'lam': float(g['lam']), 'use_E': True, 'use_E_cstr': bool(g['use_E_cstr']),
         'use_sym': g['perms'].shape[0] > 1, 'perms': g['perms'],
     }
+    if 'lattice' in g:
+        task['lattice'] = g['lattice']
     np.random.seed(0)
     trainer = GDMLTrain()
     trainer._force_solver = 'cg'

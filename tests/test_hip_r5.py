@@ -75,13 +75,14 @@ def test_preconditioner_forms_agree(golden, ctx):
         scale = np.abs(ref[k]).max()
         assert np.abs(out[0][0][k] - ref[k]).max() <= 1e-6 * scale
         assert np.abs(out[1][0][k] - out[0][0][k]).max() <= 1e-6 * scale, np.abs(out[1][0][k] - out[0][0][k]).max() / scale
-        # where the fp32 form was accepted: 1e-5 when every inducing direction is strong (sigma_i >> lam: squared singular
-        # values of the factor ~1).  Directions with sigma_i ~ lam (the periodic fixture: smallest pivot 0.77) weigh
-        # lam / (sigma_i + lam) ~ 0.2 in the operator, and there the stored factor's Gram matrix differs from the exact
-        # I - lam L^-1 L^-T the fp32 form uses by the rounding error of K_nm^T K_nm relative to lam (1e-13 / 1e-10)
+        # where the fp32 form was accepted: 1e-5 of the operator.  One exception: lam = 1e-10 with a weak inducing direction
+        # (n4_p6_pbc: smallest squared singular value 0.77) -- such a direction weighs lam / (sigma_i + lam) ~ 0.2 in the
+        # operator, and there it is the REFERENCE's stored factor whose Gram matrix is off the exact I - lam L^-1 L^-T by the
+        # rounding error of K_nm^T K_nm relative to lam (1e-13 / 1e-10).  Round 6: on n10_p2_pbc (lam = 1e-4, weakest direction
+        # 0.06) this assertion found that round 5's T0 used L0 L0^T where the operator needs L0^T L0 (3 % off; csrc/cg.hip).
         piv = ctx.get_option('pcg.f32_last_min_pivot')
         if out[3][2] & 4:
-            tol3 = 1e-5 if piv >= 0.99 else 1e-2
+            tol3 = 1e-5 if (piv >= 0.99 or lam >= 1e-6) else 1e-2
             assert np.abs(out[3][0][k] - out[0][0][k]).max() <= tol3 * scale, (np.abs(out[3][0][k] - out[0][0][k]).max() / scale, piv)
     lev_ref = np.einsum('ij,ij->j', g['L_inv_K_mn'], g['L_inv_K_mn'])
     np.testing.assert_allclose(out[0][1], lev_ref, rtol=0, atol=1e-6)
@@ -301,8 +302,8 @@ def test_mem_reserve_arena_lifecycle():
     """gdml_mem_reserve: reserve -> the large matrices of two contexts are carved from the block in turn (first fit; no
     growth of driver-side use) -> a third that fits no gap goes to hipMalloc -> handing a matrix back frees its gap -> the
     block survives gdml_ctx_destroy and serves the next context -> reserve(0) refuses while a buffer is carved and releases
-    afterwards; gdml_mem_info counts exactly the idle part of the arena as free; K is the same matrix through the arena as
-    through hipMalloc."""
+    afterwards; gdml_mem_info counts the LARGEST contiguous gap of the arena as free (round 6: a carve needs one gap, so the
+    sum of the idle pieces over-promised on a fragmented arena); K is the same matrix through the arena as through hipMalloc."""
     import ctypes as C
 
     from sgdml_amd import _lib
@@ -374,7 +375,9 @@ def test_mem_reserve_arena_lifecycle():
         # a goes away: its gap is idle again (the block stays with the process) and serves the next large request
         a.close()
         _, free5, _ = b.mem_info()
-        assert free5 >= free4 + KB - GB // 4
+        # layout now: [gap of a's matrix | b's matrix | tail]: the largest gap is a's former block, not gap + tail
+        tail = 12 * GB - 2 * KB
+        assert abs((free5 - free4) - (KB - tail)) <= GB // 4, (free4, free5)
         d = new_ctx()
         d.train_upload(xd, gd, tp)
         d.assemble_K(20.0, False)

@@ -117,3 +117,38 @@ def test_default_preconditioner_follows_the_reference_trace():
         assert np.linalg.norm(r) <= 1.05e-4 * ny
     finally:
         c.close()
+
+
+def test_bench_lines_for_one_and_two_ranks_carry_the_same_metric(tmp_path):
+    """`python bench.py` and `python bench.py --gpus 2 --comm host` (two ranks sharing the GPU, host-staged collectives, the
+    module's own launcher) at a reduced size: ONE JSON line each, identical `metric` and `config.workload`, `scale_point`
+    under the same keys, the two-rank value produced by the distributed Cholesky with a residual at the contract; the
+    `--workload cg` lines of both rank counts agree with each other as well."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, OMP_NUM_THREADS='2')
+    common = ['--steps', '1', '--warmup', '1', '--no-cpu', '--n-train', '96', '--cg-n-train', '160', '--cg-inducing', '8',
+              '--cg-iters', '5', '--no-to-tol']
+
+    def line(extra):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + common + extra, env=env, capture_output=True,
+                           text=True, timeout=900, cwd=str(tmp_path))
+        assert p.returncode == 0, p.stderr[-3000:]
+        rows = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+        assert len(rows) == 1, p.stdout[-2000:]
+        return json.loads(rows[0])
+
+    one = line(['--no-configs', '--no-profile'])
+    two = line(['--gpus', '2', '--comm', 'host'])
+    assert one['metric'] == two['metric'] and one['config']['workload'] == two['config']['workload']
+    assert (one['n_gpus'], two['n_gpus']) == (1, 2) and one['unit'] == two['unit'] == 's'
+    assert set(one['scale_point']) == set(two['scale_point']) and two['scale_point']['seconds'] == two['value'] > 0
+    assert two['solve_rel_residual'] < 1e-10 and one['solve_rel_residual'] < 1e-10
+    assert two['config']['collectives'] == 'host' and two['config']['rccl_ranks_seen'] is None
+    assert two['cg']['s_per_step'] > 0 and two['scale_point_cg']['seconds'] == two['cg']['s_per_step']
+    assert 'first_call_in_process' in one and one['first_call_in_process']['first_step_s'] > 0
+    cg1 = line(['--workload', 'cg'])
+    cg2 = line(['--workload', 'cg', '--gpus', '2', '--comm', 'host'])
+    assert cg1['metric'] == cg2['metric'] and cg1['config']['workload'] == cg2['config']['workload']
+    assert cg1['value'] > 0 and cg2['value'] > 0 and (cg1['n_gpus'], cg2['n_gpus']) == (1, 2)

@@ -422,9 +422,15 @@ def test_distributed_cholesky_single_rank(ctx, N, M, nb, perms, lookahead):
     a_ref, Kop = _reference_solve(ctx, ds['R'], y, N, 20.0, 1e-10, perms)
     ctx.set_option('dist.nb', nb)
     ctx.set_option('dist.lookahead', lookahead)
+    ctx.set_option('dist.force_panels', 1)  # (round 6: a one-rank call otherwise degenerates to the single-GPU factorisation)
     a = ctx.dist_chol_solve(20.0, 1e-10, y)
     r = Kop(-a) + y  # y - A x with A x = -(K x - lam x)
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(y)
+    if lookahead == 0:  # the default one-rank path: the single-GPU schedule behind the same entry point
+        ctx.set_option('dist.force_panels', 0)
+        a1 = ctx.dist_chol_solve(20.0, 1e-10, y)
+        assert np.linalg.norm(Kop(-a1) + y) <= 1e-9 * np.linalg.norm(y)
+        assert np.abs(a1 - a_ref).max() <= 1e-4 * np.abs(a_ref).max()
     # alphas of two correct factorisations differ by about cond(A) * eps * |alphas|: the two paths assemble K with different
     # kernels (entries equal to ~1e-16 relative), lam = 1e-10 against |K| ~ 1e0..1e1 gives cond(A) up to ~1e10-1e11, i.e. a
     # relative difference up to ~1e-5 (observed 2e-5 on the 26-atom case): the residual above is the parity statement, this

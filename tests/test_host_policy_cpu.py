@@ -327,3 +327,24 @@ def test_bench_labels_follow_the_library_dispatch_of_the_perm2_kernel():
         for p in (1, 2, 6, 12, 16, 27, 64):
             assert bench.assembly_kernel_name(n, p).startswith('assemble_perm2_kernel') == lib_rule(n, p), (n, p)
     assert bench.assembly_kernel_name(21, 1).startswith('assemble_strip') and bench.assembly_kernel_name(100, 1) == 'assemble_perm_kernel'
+
+
+def test_bench_lines_of_every_gpu_count_name_the_same_workload():
+    """bench.py --gpus N: `metric` and `config.workload` are ONE string per workload for every N (bench.line_skeleton), so that the
+    driver's N = 1, 2, 4, 8 values form a curve (round-5 review: the N = 1 line printed configs[1] seconds, the N > 1 line a
+    configs[2] step); the default workload is the same (analytic) at every N; only `parallelism` names the partitioning."""
+    import inspect
+
+    import bench
+
+    for wl, kw in (('analytic', {}), ('cg', {'cg_iters': 50, 'cg_inducing': 200})):
+        lines = [bench.line_skeleton(wl, 21, 1000 if wl == 'analytic' else 5000, w, **kw) for w in (1, 2, 4, 8)]
+        assert len({ln['metric'] for ln in lines}) == 1 and len({ln['workload'] for ln in lines}) == 1
+        assert lines[0]['parallelism'] == 'single GPU' and len({ln['parallelism'] for ln in lines}) == 4
+    assert 'configs[1]' in bench.line_skeleton('analytic', 21, 1000, 8)['workload']
+    src = inspect.getsource(bench.main)
+    assert "workload = 'analytic' if args.workload == 'auto' else args.workload" in src  # one default for every N
+    # both producers of a line take their strings from the skeleton and publish the curve point under the same key
+    for fn in (bench.run_analytic, bench.run_multi):
+        body = inspect.getsource(fn)
+        assert 'line_skeleton(' in body and "out['scale_point']" in body

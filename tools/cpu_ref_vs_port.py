@@ -2,7 +2,7 @@
 """The REFERENCE's CPU path timed beside the oracle (the NumPy port bench.py's cpu_baseline leg times on the GPU box) on
 identical inputs, in the two thread layouts of BASELINE.md section 3.2.  Build container only (needs /root/reference):
 
-    python tools/cpu_ref_vs_port.py [M]          -> profiles/r05_cpu_reference_vs_port_m<M>.json
+    python tools/cpu_ref_vs_port.py [M]          -> profiles/r06_cpu_reference_vs_port_m<M>.json
 
   layout "blas":  one Python process, BLAS/LAPACK threads = all cores   (best for the Cholesky)
   layout "procs": reference worker pool = all cores, BLAS threads = 1    (best for the reference's assembly: it forks
@@ -56,8 +56,13 @@ def child(layout, M):
 
     an = Analytic(gt, desc)
     t0 = time.perf_counter()
-    alphas_ref = an.solve(task, R_desc, R_d_desc, lin, y)
+    # a COPY of y: the reference's LU branch calls scipy.linalg.solve(..., overwrite_b=True) (analytic.py:112-114), which
+    # leaves the solution in the caller's label vector -- the round-5 record computed the reference's residual against that
+    # overwritten vector and reported 0.99999 for a solve that was in fact fine
+    y_ref = y.copy()
+    alphas_ref = an.solve(task, R_desc, R_d_desc, lin, y_ref)
     t_ref_total = time.perf_counter() - t0  # assembles again inside (analytic.py:57-63)
+    ref_took_lu = not np.array_equal(y_ref, y)
     # ---- port
     xo, go = orc.desc_from_R(R.reshape(M, -1))
     tp = orc.tril_perms_from_atom_perms(perms)
@@ -74,6 +79,7 @@ def child(layout, M):
            'blas_threads': os.environ.get('OPENBLAS_NUM_THREADS', 'all'),
            'reference': {'assemble_s': t_ref_asm, 'solve_s': max(0.0, t_ref_total - t_ref_asm), 'analytic_solve_total_s': t_ref_total},
            'port': {'assemble_s': t_port_asm, 'solve_s': t_port_solve, 'lu_fallback': bool(used_lu)},
+           'reference_lu_fallback': bool(ref_took_lu),
            'resid_reference': float(np.linalg.norm(A @ (-alphas_ref) - y) / np.linalg.norm(y)),
            'resid_port': float(np.linalg.norm(A @ (-alphas_port) - y) / np.linalg.norm(y))}
     print('RESULT ' + json.dumps(res), flush=True)
@@ -104,7 +110,7 @@ def main():
     rec = {'what': 'reference (sgdml, /root/reference) vs oracle/gdml_oracle.py on identical inputs, build container',
            'n_atoms': 21, 'M': M, 'layouts': out, 'best_of_layouts': best,
            'host': {'nproc': os.cpu_count(), 'numpy': numpy.__version__, 'scipy': scipy.__version__}}
-    path = os.path.join(ROOT, "profiles", "r05_cpu_reference_vs_port_m%d.json" % M)
+    path = os.path.join(ROOT, "profiles", "r06_cpu_reference_vs_port_m%d.json" % M)
     with open(path, 'w') as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec['best_of_layouts']))

@@ -17,6 +17,7 @@ tp = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
 xd, gd = c.desc_from_R(R.reshape(M, -1), N)
 c.train_upload(xd, gd, tp)
 c.set_option('dist.nb', nb)
+c.set_option('dist.force_panels', 1)  # round 6: the panel schedule itself (a one-rank call otherwise takes the single-GPU path)
 for rep in range(2):
     c.sync(); t0 = time.perf_counter()
     a = c.dist_chol_solve(20.0, 1e-10, y)
