@@ -1089,6 +1089,8 @@ def run_analytic(args):
         # scaled with the molecule (the descriptor has N (N - 1) / 2 entries; the reference's CLI searches 10:10:100):
         # 20 for 21 atoms, 60 for 42, 100 for 100 -- at sigma = 20 the 42-atom system needs 4306 iterations instead of 331
         # (profiles/r04_cfg3_m2000_first_probe.txt, r04_large_molecule_cg_probe.txt).
+        from sgdml_amd.solvers.iterative import Iterative
+
         TRAJ = {'n_modes': 8, 'amp': 0.15, 'noise': 0.01}
         for label, kw in (
             ('configs[2]: aspirin-sized N=21, N_train={} iterative solver to solver_tol 1e-4 on a synthetic trajectory '
@@ -1098,9 +1100,18 @@ def run_analytic(args):
              'iterative.py:120-140) instead of the fp32 factor + Gram correction the library picks at this size',
              dict(n_atoms=N, n_train=args.cg_n_train, solver='cg', max_memory=32, traj=TRAJ, sig=args.sig,
                   options={'pcg.precon_form': 0})),
+            ('configs[2] at the k the REFERENCE\'s own memory rule gives for the same max_memory (iterative.py:827-844 counts four '
+             'n x m host arrays: k = 53 at 32 GB; this backend\'s HBM model above holds one and allows ~2.7 x as many) -- also the '
+             'measured optimum of the k sweep (profiles/r06_k_sweep.txt): the larger k of the entry above costs more to build than '
+             'its fewer iterations save',
+             dict(n_atoms=N, n_train=args.cg_n_train, solver='cg', max_memory=32, traj=TRAJ, sig=args.sig,
+                  n_inducing=Iterative.max_n_inducing_pts(args.cg_n_train, N, 32 * 1024**3))),
             ('configs[3]: N=42 with a 27-element permutation group, N_train=2000 (n = 252 000: 508 GB as a matrix), iterative '
              'solver to solver_tol 1e-4, budget 64 GB', dict(n_atoms=42, n_train=2000, perms_kind='c3x3', solver='cg', max_memory=64,
                                                             traj=TRAJ, sig=60)),
+            ('configs[3] at the k of the reference\'s memory rule for 64 GB (k = 64; measured optimum of the sweep ~70)',
+             dict(n_atoms=42, n_train=2000, perms_kind='c3x3', solver='cg', max_memory=64, traj=TRAJ, sig=60,
+                  n_inducing=Iterative.max_n_inducing_pts(2000, 42, 64 * 1024**3))),
             ('configs[4]: 100-atom molecule, N_train=3000 (n = 900 000: 6.5 TB as a matrix), iterative solver to solver_tol 1e-4, '
              'budget 64 GB', dict(n_atoms=100, n_train=3000, solver='cg', max_memory=64, traj=TRAJ, sig=100)),
             ('configs[3] shape at the largest N_train one GPU factors directly: N=42, P=27, N_train=1000 (n = 126 000, 127 GB), analytic',

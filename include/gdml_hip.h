@@ -166,6 +166,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   pcg.f32_rows_per (1024), pcg.f32_rw (4)  shape of the fp32 form's two GEMVs: rows per partial sum of X32^T v, rows per
  *                         wavefront of X32 t (A/B)
  *   pcg.f32_gram_rows (2048)  fp32 form: rows per chunk of the compensated Gram sum of the rounded factor
+ *   pcg.f32_inplace (1)   fp32 form: the rounded factor overlays the fp64 factor in the matrix buffer (no second n x m buffer; the
+ *                         leverage scores are cached first); 0 = a separate fp32 copy beside the fp64 factor (round 5)
  *   pcg.f32_min_pivot (1e-7)  fp32 form: smallest squared Cholesky pivot of the rounded factor's Gram matrix below which the
  *                         reference's fp64 form is kept (gdml_get_option("pcg.f32_last_min_pivot") reads the last value seen)
  * Unknown keys return GDML_ERR_INVALID. */

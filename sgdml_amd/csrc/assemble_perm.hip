@@ -782,9 +782,15 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
     return gdml_fail(ctx, GDML_ERR_INVALID, "assemble_perm: the lower form needs the dense full column range");
   if (cyc_W > 0 && 3 * N > cyc_nb)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_perm: row-cyclic layout needs 3N <= %d", cyc_nb);
-  // 25 ... 42 atoms, dense columns, plain layout: the MFMA / fixed-atom-split kernel of assemble_perm2.hip
-  if (!d_jlist && !d_colmap && !use_E && cyc_W == 0 && assemble_perm2_applicable(ctx)) {
-    const int rc = assemble_perm2_launch(ctx, sig, j0, n_j, col0, K, ld, i_beg, i_end, lower ? 1 : 0, lam);
+  // 25 ... 42 atoms, plain layout: the MFMA / fixed-atom-split kernel of assemble_perm2.hip -- dense column ranges, and
+  // (round 6) index lists that request WHOLE column points in list order (every column of each listed point, output column
+  // 3N v + c: what the iterative solver's K_nm is, iterative.py:229-247 -- configs[3] spent 0.69 s per build on the general
+  // kernel for it)
+  bool whole_points = d_jlist != nullptr && d_colmap != nullptr && h_colmap != nullptr && col0 == 0 && !lower;
+  if (whole_points)
+    for (int64_t e = 0; e < n_j * 3 * N && whole_points; ++e) whole_points = h_colmap[e] == (int32_t)e;
+  if (((!d_jlist && !d_colmap) || whole_points) && !use_E && cyc_W == 0 && assemble_perm2_applicable(ctx)) {
+    const int rc = assemble_perm2_launch(ctx, sig, j0, n_j, col0, K, ld, i_beg, i_end, lower ? 1 : 0, lam, whole_points ? d_jlist : nullptr);
     if (rc != GDML_ERR_UNSUPPORTED) return rc;
   }
   PermArgs A;

@@ -67,6 +67,7 @@ struct Perm2Args {
   int N, P, nF;
   double sig;
   int64_t j0, n_j, col0, i_beg, i_end;
+  const int32_t* jlist;  // column POINTS of an index list that requests whole points (K_nm of the iterative solver), or null: j0 + v
   int i_chunk;
   int lower;
   double lam;
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t jv = blockIdx.x;
-  const int64_t jpt = A.j0 + jv;
+  const int64_t jpt = A.jlist ? (int64_t)A.jlist[jv] : A.j0 + jv;
   const bool lower = A.lower != 0;
   const int64_t i_lo = (lower ? jv : A.i_beg) + (int64_t)blockIdx.y * A.i_chunk;
   const int64_t i_top = lower ? A.M : A.i_end;
@@ -1079,7 +1080,7 @@ static int perm2_plan(gdml_ctx* ctx) {
 
 // Column points [j0, j0 + n_j) written at col0 + 3N v, row points [i_beg, i_end); lower: A = -K + lam I, blocks j <= i.
 int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg,
-                          int64_t i_end, int lower, double lam) {
+                          int64_t i_end, int lower, double lam, const int32_t* d_jlist) {
   TrainSet& ts = ctx->ts;
   if (n_j <= 0 || i_end <= i_beg) return GDML_OK;
   GDML_TRY(build_dense_tables(ctx));
@@ -1092,6 +1093,7 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
   A.n_tasks = ts.p2_ntasks;
   A.M = ts.M; A.N = N; A.P = P; A.nF = ts.p2_nF; A.nFb = ts.p2_nFb; A.sig = sig;
   A.j0 = j0; A.n_j = n_j; A.col0 = col0; A.i_beg = i_beg; A.i_end = i_end;
+  A.jlist = d_jlist;
   A.lower = lower; A.lam = lam; A.K = K; A.ld = ld;
   A.dbg = ctx_opt_i(ctx, "asm.perm2_debug", 0);
   // small LDS items into the two free regions: the unused rows of B0 (16 doubles per moved atom) and the tail behind the byte

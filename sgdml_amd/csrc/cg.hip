@@ -356,6 +356,26 @@ __global__ void __launch_bounds__(256) t0_combine_kernel(double* __restrict__ T0
   const int64_t r = blockIdx.x;
   for (int64_t c = threadIdx.x; c < m; c += 256) T0[r * ld + c] = ((T0[r * ld + c] - H[r * ld + c]) - H[c * ld + r]) + S[r * ld + c];
 }
+// D (rows x ld doubles) <- double(float(X rows)), pad columns 0: what widen_f32_kernel gives for a rounded copy, without the copy
+__global__ void __launch_bounds__(256) widen_round_kernel(const double* __restrict__ X, int64_t ld, int64_t m, double* __restrict__ D) {
+  const int64_t r = blockIdx.x;
+  for (int64_t c = threadIdx.x; c < ld; c += 256) D[r * ld + c] = c < m ? (double)(float)X[r * ld + c] : 0.0;
+}
+// In-place rounding of the factor (option pcg.f32_inplace, round 6): row r of X (ld doubles) becomes ld floats at the START of
+// the same row -- X32 with a row pitch of 2 ld floats, no second buffer.  Chunks of 256 columns front to back: the floats of
+// chunk k overlay doubles [128 k, 128 k + 128), all of which were read in this or an earlier chunk; floats [m, ld) <- 0.
+__global__ void __launch_bounds__(256) round_f32_inplace_kernel(double* __restrict__ X, int64_t ld, int64_t m) {
+  const int64_t r = blockIdx.x;
+  const double* row = X + r * ld;
+  float* row32 = reinterpret_cast<float*>(X + r * ld);
+  for (int64_t c0 = 0; c0 < ld; c0 += 256) {
+    const int64_t c = c0 + threadIdx.x;
+    const float v = (c < m) ? (float)row[c < ld ? c : ld - 1] : 0.0f;
+    __syncthreads();
+    if (c < ld) row32[c] = v;
+    __syncthreads();
+  }
+}
 // D (rows x ld doubles) <- double(X32 rows): the Gram matrix of the rounded factor is accumulated chunk by chunk
 __global__ void __launch_bounds__(256) widen_f32_kernel(const float* __restrict__ X32, int64_t ld, double* __restrict__ D) {
   const int64_t r = blockIdx.x;
@@ -727,7 +747,8 @@ static int choose_precon_form(const gdml_ctx* ctx, const ShardGeo& sg, int64_t m
 // fp32 copy and Gram correction of form 3, the matrix-free form's Z: released when the form is rejected and when the
 // matrix buffer they belong to changes size (assemble.hip) -- not on every assembly: PCG restarts re-factor at one size
 void precon_release_f32(gdml_ctx* ctx) {
-  if (ctx->precon_X32) ctx_free(ctx, ctx->precon_X32);
+  if (ctx->precon_X32 && !ctx->precon_X32_inplace) ctx_free(ctx, ctx->precon_X32);
+  ctx->precon_X32_inplace = false;
   if (ctx->precon_T0) ctx_free(ctx, ctx->precon_T0);
   ctx->precon_X32 = nullptr; ctx->precon_X32_bytes = 0;
   ctx->precon_T0 = nullptr; ctx->precon_T0_bytes = 0;
@@ -754,13 +775,14 @@ static int ensure_buf(gdml_ctx* ctx, void** p, int64_t* have, int64_t want) {
 // threshold: inducing columns the data does not support, a numerically rank-deficient K_mm).  The caller then keeps the
 // reference's fp64 form.
 static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S, int64_t n_loc, int64_t m, int64_t ld,
-                          int* usable) {
+                          int* usable, bool inplace) {
   *usable = 0;
   ctx->opts["pcg.f32_last_min_pivot"] = 0.0;
   hipStream_t st = ctx->stream;
   void* tmp = nullptr;
   {  // no room for the fp32 copy next to the fp64 factor: keep the reference's form (X is untouched at this point)
-    int rc_a = ensure_buf(ctx, (void**)&ctx->precon_X32, &ctx->precon_X32_bytes, (n_loc > 0 ? n_loc : 1) * ld * 4);
+    int rc_a = inplace ? GDML_OK  // (the rounded factor will overlay the fp64 one: gdml_nystroem_factor converts it at the end)
+                       : ensure_buf(ctx, (void**)&ctx->precon_X32, &ctx->precon_X32_bytes, (n_loc > 0 ? n_loc : 1) * ld * 4);
     if (rc_a == GDML_OK) rc_a = ensure_buf(ctx, (void**)&ctx->precon_T0, &ctx->precon_T0_bytes, m * ld * 8);
     if (rc_a == GDML_OK) rc_a = ctx_alloc(ctx, &tmp, 4 * m * ld * 8);
     // sharded: every rank must apply the same form (row blocks of ONE operator) -- free HBM differs between the ranks, so
@@ -806,7 +828,7 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
     // rounded factor and its Gram matrix (summed over the row shards).  The fp32 values are widened chunk by chunk into a
     // work buffer (X stays untouched), every chunk's Gram matrix is one short MFMA chain per entry, and the chunks are
     // summed with compensation (kahan_acc_lower_kernel): the diagonal of G is what the spectrum correction hangs on
-    if (n_loc > 0)
+    if (n_loc > 0 && !inplace)
       hipLaunchKernelGGL(round_f32_kernel, dim3((unsigned)n_loc), dim3(256), 0, st, X, ld, n_loc, m, ctx->precon_X32);
     {
       int64_t chunk = (int64_t)ctx_opt(ctx, "pcg.f32_gram_rows", 2048);
@@ -817,7 +839,10 @@ static int build_f32_form(gdml_ctx* ctx, double lam, double* X, const double* S,
       HIP_CHECK(ctx, hipMemsetAsync(G, 0, 2 * m * ld * 8, st));  // G and Gc (upper tiles are never written again)
       for (int64_t r0 = 0; r0 < n_loc; r0 += chunk) {
         const int64_t rows = (n_loc - r0 < chunk) ? n_loc - r0 : chunk;
-        hipLaunchKernelGGL(widen_f32_kernel, dim3((unsigned)rows), dim3(256), 0, st, ctx->precon_X32 + r0 * ld, ld, D);
+        if (inplace)
+          hipLaunchKernelGGL(widen_round_kernel, dim3((unsigned)rows), dim3(256), 0, st, X + r0 * ld, ld, m, D);
+        else
+          hipLaunchKernelGGL(widen_f32_kernel, dim3((unsigned)rows), dim3(256), 0, st, ctx->precon_X32 + r0 * ld, ld, D);
         hipLaunchKernelGGL(syrk_tn_kernel, tri, dim3(256), 0, st, D, ld, rows, m, Gp, ld, tiles, 0);
         hipLaunchKernelGGL(kahan_acc_lower_kernel, dim3((unsigned)m), dim3(256), 0, st, G, Gc, Gp, ld, m, r0 == 0 ? 1 : 0);
       }
@@ -900,6 +925,11 @@ extern "C" int gdml_nystroem_lev_scores(gdml_ctx* ctx, double* lev_scores_out) {
                                           "gdml_nystroem_factor overwrites it)");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const ShardGeo sg = shard_geo(ctx);
+  if (ctx->precon_X32_inplace) {  // the fp64 factor was rounded in place: the scores were taken before that
+    if ((int64_t)ctx->precon_lev_cache.size() != sg.n) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_nystroem_lev_scores: no cached scores");
+    memcpy(lev_scores_out, ctx->precon_lev_cache.data(), (size_t)sg.n * 8);
+    return GDML_OK;
+  }
   int rc = lev_scores_to_host(ctx, sg, lev_scores_out);
   if (rc == GDML_ERR_HIP) comm_abort(ctx);
   return rc;
@@ -918,6 +948,14 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
   double* X = ctx->K;               // this rank's rows of K_nm
   double* S = ctx->K + n_loc * ld;  // m x m work block (replicated)
   int form = choose_precon_form(ctx, sg, m, ld);
+  // fp32 form: the rounded factor overlays the fp64 one (no 1.5 x footprint; leverage scores are cached first) unless the
+  // caller wants the fp64 factor kept (pcg.f32_inplace = 0)
+  const bool f32_inplace = ctx_opt_i(ctx, "pcg.f32_inplace", 1) != 0;
+  if (ctx->precon_X32_inplace) {  // the overlay of the previous factor went with the assembly that rebuilt this matrix
+    ctx->precon_X32 = nullptr;
+    ctx->precon_X32_inplace = false;
+  }
+  ctx->precon_lev_cache.clear();
   // matrix-free form: Z = L_mm^-T L^-T, built by applying to the m x m identity every triangular solve X receives
   double* Z = nullptr;
   if (form == 1) {
@@ -969,7 +1007,7 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
       if (Z) GDML_TRY(tall_trsm(ctx, S, Z, m, m, ld));
       if (form == 3) {
         int usable = 0;
-        GDML_TRY(build_f32_form(ctx, lam, X, S, n_loc, m, ld, &usable));
+        GDML_TRY(build_f32_form(ctx, lam, X, S, n_loc, m, ld, &usable, f32_inplace));
         if (!usable) form = 0;
       }
     } else {
@@ -1055,6 +1093,23 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
         for (int64_t r = 0; r < n_loc; ++r)
           for (int64_t c = 0; c < m; ++c) LinvKmn_host_out[c * n_loc + r] = h[(size_t)r * m + c];
     }
+    ctx->precon_lev_cache.clear();
+    ctx->precon_X32_ld = ld;
+    if (rc == GDML_OK && form == 3 && f32_inplace) {
+      // everything that needs the fp64 factor has happened; the leverage scores (restart policy, iterative.py:107-109) are
+      // taken now and served from the cache, then X is rounded where it stands
+      ctx->precon_lev_cache.resize((size_t)sg.n);
+      rc = lev_scores_to_host(ctx, sg, ctx->precon_lev_cache.data());
+      if (rc == GDML_ERR_HIP) comm_abort(ctx);
+      if (rc == GDML_OK) {
+        if (n_loc > 0) hipLaunchKernelGGL(round_f32_inplace_kernel, dim3((unsigned)n_loc), dim3(256), 0, ctx->stream, X, ld, m);
+        ctx->precon_X32 = reinterpret_cast<float*>(X);
+        ctx->precon_X32_bytes = 0;
+        ctx->precon_X32_inplace = true;
+        ctx->precon_X32_ld = 2 * ld;
+        if (hipGetLastError() != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "in-place rounding of the factor failed to launch");
+      }
+    }
   }
   int rc2 = ctx_free(ctx, tmp);
   return rc != GDML_OK ? rc : rc2;
@@ -1130,10 +1185,10 @@ static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, dou
     if (n_loc > 0) {
       if (nt)
         hipLaunchKernelGGL(gemv_t_part_f32_kernel<true>, dim3(ceil_div(m, 1024), nparts), dim3(256), 0, ctx->stream,
-                           ctx->precon_X32, ld, n_loc, m, d_v + sg.row0, rows_per, part);
+                           ctx->precon_X32, ctx->precon_X32_ld, n_loc, m, d_v + sg.row0, rows_per, part);
       else
         hipLaunchKernelGGL(gemv_t_part_f32_kernel<false>, dim3(ceil_div(m, 1024), nparts), dim3(256), 0, ctx->stream,
-                           ctx->precon_X32, ld, n_loc, m, d_v + sg.row0, rows_per, part);
+                           ctx->precon_X32, ctx->precon_X32_ld, n_loc, m, d_v + sg.row0, rows_per, part);
       hipLaunchKernelGGL(reduce_parts_kahan_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m, nparts, t);
     } else {
       HIP_CHECK(ctx, hipMemsetAsync(t, 0, m * 8, ctx->stream));
@@ -1149,7 +1204,7 @@ static int precon_apply_device(gdml_ctx* ctx, double lam, const double* d_v, dou
       const double il = 1.0 / lam;
 #define GDML_GEMV_N_F32(NT_, RW_)                                                                                          \
   hipLaunchKernelGGL((gemv_n_precon_f32_kernel<NT_, RW_>), dim3(ceil_div(n_loc, 4 * RW_)), dim3(256), 0, ctx->stream, X32, \
-                     ld, n_loc, m, u, vv, il, oo)
+                     ctx->precon_X32_ld, n_loc, m, u, vv, il, oo)
       if (rw >= 4) { if (nt) GDML_GEMV_N_F32(true, 4); else GDML_GEMV_N_F32(false, 4); }
       else if (rw >= 2) { if (nt) GDML_GEMV_N_F32(true, 2); else GDML_GEMV_N_F32(false, 2); }
       else { if (nt) GDML_GEMV_N_F32(true, 1); else GDML_GEMV_N_F32(false, 1); }

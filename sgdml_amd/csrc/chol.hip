@@ -1077,13 +1077,15 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_persist_kernel(GemmArgs g)
     gl.queue = q;  // this XCD's counter
     const int64_t v = item < n2 ? (int64_t)item * 8 + xcd : (int64_t)gl.tiles2 + (int64_t)(item - n2) * 8 + xcd;
     gemm_block<false, true, true, CKS, FLAGS>(gl, lds, v, s_item);
-    __syncthreads();  // every wavefront is done with the LDS tiles; s_item is visible
+    // every wavefront is done with the LDS tiles; s_item is visible.  LDS-only barriers: __syncthreads() carries a vmcnt(0),
+    // i.e. it would wait for the tile's 64 stores per lane to drain (5-12 k cycles) before the next tile's loads are issued
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (s_item[1] == 0u) {  // a skipped or ragged tile: nothing was requested on the way (workgroup-uniform)
       if (threadIdx.x == 0) s_item[0] = atomicAdd(q, 1u);
       __syncthreads();
     }
     item = __builtin_amdgcn_readfirstlane(s_item[0]);
-    __syncthreads();  // (s_item is rewritten at the top)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (s_item is rewritten at the top)
   }
 }
 

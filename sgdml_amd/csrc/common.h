@@ -136,6 +136,9 @@ struct gdml_ctx {
   // (X32 T0 X32^T - I)/lam the exact Woodbury inverse on range(X32) (cg.hip)
   float* precon_X32 = nullptr;
   int64_t precon_X32_bytes = 0;
+  bool precon_X32_inplace = false;        // X32 overlays the fp64 factor in the matrix buffer (row pitch 2 K_ld floats): not ours to free
+  int64_t precon_X32_ld = 0;              // row pitch of X32 in floats
+  std::vector<double> precon_lev_cache;   // leverage scores taken before the in-place rounding
   double* precon_T0 = nullptr;
   int64_t precon_T0_bytes = 0;
 
@@ -274,7 +277,7 @@ int assemble_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int
                            int cyc_nb);
 bool assemble_perm2_applicable(const gdml_ctx* ctx);
 int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg,
-                          int64_t i_end, int lower, double lam);
+                          int64_t i_end, int lower, double lam, const int32_t* d_jlist = nullptr);
 int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist, const int32_t* d_colmap, int64_t j0,
                          int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg, int64_t i_end, int lower, double lam,
                          int cyc_W, int cyc_rank, int cyc_nb, const int32_t* h_colmap = nullptr);

@@ -23,7 +23,12 @@ class GDMLPredict(object):
         use_torch=False,
         log_level=None,
         _borrow_ctx=None,
+        devices=None,
     ):
+        """devices (no counterpart in the reference's signature; its torch path wraps the model in nn.DataParallel over every
+        visible GPU, predict.py:375-378): list of GPU indices to replicate the model on -- query batches are then split over
+        them (replicas + query sharding).  None: every visible GPU when `use_torch` is set (what the reference
+        does), else GPU 0 only."""
         self.log = logging.getLogger(__name__)
         if log_level is not None:
             self.log.setLevel(log_level)
@@ -62,20 +67,60 @@ class GDMLPredict(object):
         # _borrow_ctx (internal): evaluate on a context somebody else owns -- the trainer's, for the short-lived predictors of
         # GDMLTrain._recov_int_const and sweep.sigma_sweep.  The model tables of a context belong to whoever uploaded last.
         self._owns_ctx = _borrow_ctx is None
-        self._ctx = _lib.Context() if _borrow_ctx is None else _borrow_ctx
-        self._ctx.predict_upload_model(
-            R_desc_train,
-            model['R_d_desc_alpha'],
-            self._tril_perms,
-            self.sig,
-            model['alphas_E'] if 'alphas_E' in model else None,
-        )
+        if devices is None:
+            devices = list(range(_lib.device_count())) if (use_torch and _borrow_ctx is None) else [0]
+        devices = [int(d) for d in devices] or [0]
+        self._ctx = _lib.Context(devices[0]) if _borrow_ctx is None else _borrow_ctx
+        # replicas on the other devices (one context per entry: the same index twice gives two contexts on one GPU, which is
+        # how the sharded path is tested on a one-GPU box); the training-set mode and set_alphas stay on the first one
+        self._replicas = [] if _borrow_ctx is not None else [_lib.Context(d) for d in devices[1:]]
+        for ctx in [self._ctx] + self._replicas:
+            ctx.predict_upload_model(
+                R_desc_train,
+                model['R_d_desc_alpha'],
+                self._tril_perms,
+                self.sig,
+                model['alphas_E'] if 'alphas_E' in model else None,
+            )
+        self._replicas_stale = False
+        self._min_shard = 64  # geometries per device below which a batch is not worth splitting
         self._train_resident = False
 
     def __del__(self):
+        for ctx in getattr(self, '_replicas', []):
+            ctx.close()
         ctx = getattr(self, '_ctx', None)
         if ctx is not None and getattr(self, '_owns_ctx', True):
             ctx.close()
+
+    def _sharded(self, n_items, fn):
+        """fn(ctx, lo, hi) for contiguous query shards, one per device, concurrently (ctypes releases the GIL inside the
+        library calls); results in shard order.  One shard when the batch is small or the replicas do not hold the current
+        coefficients (set_alphas re-targets only the first context)."""
+        ctxs = [self._ctx] + ([] if self._replicas_stale else self._replicas)
+        n_sh = min(len(ctxs), max(1, n_items // self._min_shard))
+        if n_sh <= 1:
+            return [fn(self._ctx, 0, n_items)]
+        import threading
+
+        cuts = [n_items * k // n_sh for k in range(n_sh + 1)]
+        out, err = [None] * n_sh, []
+
+        def run(k):
+            try:
+                out[k] = fn(ctxs[k], cuts[k], cuts[k + 1])
+            except BaseException as e:  # re-raised in the caller's thread
+                err.append(e)
+
+        ths = [threading.Thread(target=run, args=(k,)) for k in range(1, n_sh)]
+        for t in ths:
+            t.start()
+        run(0)
+        for t in ths:
+            t.join()
+        if err:
+            raise err[0]
+        return out
 
     # ---- training-mode hooks (predict.py:510-601)
 
@@ -102,6 +147,7 @@ class GDMLPredict(object):
         """Re-target the model with new coefficients (predict.py:551-601); J alpha runs on the GPU."""
         self._ensure_train_resident()
         self._ctx.set_alphas(alphas_F, alphas_E)
+        self._replicas_stale = True  # the replicas still hold the constructor's coefficients
 
     # ---- CPU-tuning API of the reference: no-ops here, like its torch path (predict.py:826-830)
 
@@ -136,7 +182,12 @@ class GDMLPredict(object):
         if R.ndim == 1:
             R = R[None, :]
         B = R.shape[0]
-        s = self._ctx.predict_errors(R.reshape(B, -1), F, E, std=self.std, c=self.c, lat_and_inv=self.lat_and_inv)
+        R = R.reshape(B, -1)
+        F = np.asarray(F, dtype=np.float64).reshape(B, -1)
+        E = None if E is None else np.asarray(E, dtype=np.float64).reshape(B)
+        parts = self._sharded(B, lambda ctx, lo, hi: ctx.predict_errors(
+            R[lo:hi], F[lo:hi], None if E is None else E[lo:hi], std=self.std, c=self.c, lat_and_inv=self.lat_and_inv))
+        s = np.sum(np.asarray(parts, dtype=np.float64), axis=0)  # the eight sums are additive over query shards
         n_f, n_a = B * 3 * self.n_atoms, B * self.n_atoms
         out = {
             'force': (s[2] / n_f, np.sqrt(s[3] / n_f)),
@@ -155,7 +206,10 @@ class GDMLPredict(object):
             R = np.asarray(R, dtype=np.float64)
             if R.ndim == 1:
                 R = R[None, :]
-            E, F = self._ctx.predict(R.reshape(R.shape[0], -1), self.lat_and_inv, return_E=return_E)
+            R = R.reshape(R.shape[0], -1)
+            parts = self._sharded(R.shape[0], lambda ctx, lo, hi: ctx.predict(R[lo:hi], self.lat_and_inv, return_E=return_E))
+            F = parts[0][1] if len(parts) == 1 else np.concatenate([p_[1] for p_ in parts])
+            E = None if not return_E else (parts[0][0] if len(parts) == 1 else np.concatenate([p_[0] for p_ in parts]))
         else:
             if self.R_desc is None or self.R_d_desc is None:
                 self.log.critical(

@@ -348,7 +348,7 @@ class Iterative(object):
 
         k = solve(lin, sq)
         if lin * k >= 2**30:
-            # the fp32 + Gram-correction form is chosen from 1 GiB of factor per rank (csrc/cg.hip::choose_precon_form): it
-            # holds the fp64 factor AND its fp32 copy (1.5 x) plus T0 and four m x m work matrices while it is built
-            k = solve(1.5 * lin, sq + 5 * to_dof)
+            # the fp32 + Gram-correction form is chosen from 1 GiB of factor per rank (csrc/cg.hip::choose_precon_form): the
+            # rounded factor overlays the fp64 one (pcg.f32_inplace), but T0 and four m x m work matrices exist while it is built
+            k = solve(lin, sq + 5 * to_dof)
         return min(int(k), n_train)

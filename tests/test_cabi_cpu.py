@@ -325,8 +325,8 @@ def test_find_perms_matches_reference_on_the_cli_sweep_sample():
 def test_inducing_point_memory_model_is_per_shard():
     """Iterative.max_n_inducing_pts_device: the largest k whose footprint (this rank's rows of K_nm + the m x m block + its
     backup) fits the budget; the row term shrinks with the number of ranks, the replicated m x m terms do not.  From 1 GiB
-    of factor per rank the library keeps the fp32 copy beside the fp64 factor and needs T0 + four m x m work matrices to build
-    it (csrc/cg.hip::build_f32_form): the model counts them (round 6)."""
+    of factor per rank the library builds the fp32 form (rounded in place over the fp64 factor) and needs T0 + four m x m work
+    matrices for it (csrc/cg.hip::build_f32_form): the model counts them (round 6)."""
     from sgdml_amd.solvers.iterative import Iterative
 
     M, N = 5000, 21
@@ -336,7 +336,7 @@ def test_inducing_point_memory_model_is_per_shard():
     for w, k in zip((1, 2, 4, 8), ks):
         n_loc = -(-M // w) * 3 * N
         foot64 = lambda kk: (n_loc + 2 * 3 * N * kk) * (3 * N * kk) * 8  # (n_loc + m) m + m^2 doubles
-        foot32 = lambda kk: (1.5 * n_loc + 7 * 3 * N * kk) * (3 * N * kk) * 8
+        foot32 = lambda kk: (n_loc + 7 * 3 * N * kk) * (3 * N * kk) * 8
         assert n_loc * 3 * N * k * 8 >= 2**30  # every case here is in the fp32-form regime
         assert foot32(k) <= budget < foot32(k + 1) and foot64(k) < foot32(k)
     # below 1 GiB of factor: the fp64 form's footprint

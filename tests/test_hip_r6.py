@@ -152,3 +152,145 @@ def test_bench_lines_for_one_and_two_ranks_carry_the_same_metric(tmp_path):
     cg2 = line(['--workload', 'cg', '--gpus', '2', '--comm', 'host'])
     assert cg1['metric'] == cg2['metric'] and cg1['config']['workload'] == cg2['config']['workload']
     assert cg1['value'] > 0 and cg2['value'] > 0 and (cg1['n_gpus'], cg2['n_gpus']) == (1, 2)
+
+
+def test_persistent_trailing_update_is_bitwise_the_plain_one(ctx):
+    """Option gemm.persist = 1 (resident workgroups pulling tiles from per-XCD counters, csrc/chol.hip) against the default
+    launch-per-tile schedule at a size whose trailing updates are long enough to take it (n = 9450: 2 775 lower tiles in the
+    first fused launch, the threshold is four rounds of 512): every tile is the same arithmetic in the same order, so the
+    factor's solution is BIT-identical, with the right-hand side carried through and with the merged schedule's tile counter
+    (the diagonal-block workgroup waits for tiles that persistent workgroups compute)."""
+    N, M = 21, 150
+    ds = orc.synth_dataset(N, M, seed=4, jitter=0.3)
+    xd, gd = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    y = ds['F'].ravel() / np.std(ds['F'])
+    ctx.train_upload(xd, gd, tp)
+    sols = {}
+    for persist in (0, 1):
+        ctx.set_option('gemm.persist', persist)
+        ctx.assemble_K(20.0, False, alloc_extra_rows=1, for_cholesky=1e-10)
+        ctx.chol_set_rhs(y)
+        assert ctx.chol_factor(1e-10) == 0
+        sols[persist] = ctx.chol_solve(None)
+    assert np.array_equal(sols[0], sols[1])
+    ctx.predict_upload_model(xd, np.zeros_like(xd), tp, 20.0, None)
+    r = ctx.kernel_matvec(1e-10, False, -sols[1]) + y
+    assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(y)
+
+
+def test_whole_point_index_lists_run_on_the_perm2_kernel(ctx):
+    """K_nm of the iterative solver (an index list that requests every column of the listed points, iterative.py:229-247) for a
+    42-atom molecule with a 27-element group: round 6 routes it to assemble_perm2_kernel (column point = jlist[v]) instead of
+    the general kernel.  Against the oracle (1e-12 max|K|), against the general kernel (asm.perm2 = 0), with extra rows
+    allocated (the Nystroem layout), for a row-point sub-range, and a list with ONE column missing stays on the general
+    kernel and is still right."""
+    import bench
+
+    N, M = 42, 7
+    perms = bench.perm_group(N, 'c3x3')
+    ds = orc.synth_dataset(N, M, seed=6, jitter=0.25)
+    xd, gd = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(perms)
+    lin = orc.tril_perms_lin_from_tril_perms(tp)
+    sig = 60.0
+    Ko = orc.assemble_K(xd, gd, lin, sig)
+    scale = np.abs(Ko).max()
+    ctx.train_upload(xd, gd, tp)
+    pts = np.array([1, 4, 6])
+    idx = (pts[:, None] * 3 * N + np.arange(3 * N)[None, :]).ravel()
+    n_launch = {}
+    for opt in (1, 0):
+        ctx.set_option('asm.perm2', opt)
+        ctx.profile(True)
+        Kc = ctx.assemble_K(sig, False, idx=idx, alloc_extra_rows=len(idx), to_host=True)
+        ctx.profile(False)
+        assert Kc.shape[1] == len(idx)
+        assert np.abs(Kc[:3 * N * M] - Ko[:, idx]).max() <= 1e-12 * scale, opt
+        n_launch[opt] = Kc[:3 * N * M].copy()
+    assert np.abs(n_launch[1] - n_launch[0]).max() <= 1e-13 * scale
+    ctx.set_option('asm.perm2', 1)
+    # one column short of whole points: the general kernel (compact column lists), same numbers
+    idx2 = np.delete(idx, 5)
+    Kc2 = ctx.assemble_K(sig, False, idx=idx2, to_host=True)
+    assert np.abs(Kc2 - Ko[:, idx2]).max() <= 1e-12 * scale
+
+
+def test_discovered_permutations_feed_training_like_the_reference_group():
+    """create_task without `perms` discovers the group (sgdml_amd/utils/perm.py, index-exact against the
+    reference's find_perms output in tests/golden/perm_c3.npz) and the model trained from it is the model trained from the
+    reference's group: same kernel matrix, same coefficients' predictions."""
+    from sgdml_amd.predict import GDMLPredict
+    from sgdml_amd.train import GDMLTrain
+
+    g = dict(np.load(os.path.join(GOLDEN, 'perm_c3.npz')))
+    R, z = g['R'], g['z']
+    n = R.shape[0]
+    E, F = _pair_labels(R)
+    ds = {'type': 'd', 'name': np.array('c3'), 'theory': np.array('pair'), 'z': z, 'R': R, 'F': F, 'E': E}
+    models = []
+    for perms in (None, g['perms']):
+        tr = GDMLTrain()
+        try:
+            np.random.seed(1)
+            task = tr.create_task(ds, n, ds, 0, sig=12, lam=1e-8, perms=perms)  # every point: the fixture's group was found on all of them
+            assert {tuple(p) for p in task['perms']} == {tuple(p) for p in g['perms']}
+            models.append(tr.train(task))
+        finally:
+            tr.__del__()
+    assert np.array_equal(models[0]['idxs_train'], models[1]['idxs_train'])
+    Rq = (R[:8] + 0.05 * np.random.RandomState(2).normal(size=R[:8].shape)).reshape(8, -1)
+    out = []
+    for m in models:
+        p = GDMLPredict(m)
+        out.append(p.predict(Rq))
+        del p
+    # the discovered group may list the same permutations in another order: the perm-summed kernel does not care
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-9 * np.abs(out[1][1]).max()
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-9 * max(1.0, np.abs(out[1][0]).max())
+
+
+def _pair_labels(R):
+    n_frames, n_atoms = R.shape[:2]
+    i, j = np.tril_indices(n_atoms, -1)
+    diff = R[:, i, :] - R[:, j, :]
+    dist = np.sqrt((diff**2).sum(-1))
+    E = (1.0 / dist).sum(-1)
+    gp = diff / (dist**3)[..., None]
+    F = np.zeros_like(R)
+    for m in range(n_frames):
+        np.add.at(F[m], i, gp[m])
+        np.subtract.at(F[m], j, gp[m])
+    return E, F
+
+
+def test_replicated_predictor_shards_query_batches():
+    """GDMLPredict(devices=[...]) (replicas + query sharding; the reference wraps its torch model in
+    nn.DataParallel, predict.py:375-378): the model is uploaded to one context per entry and a batch is split over them in
+    threads.  On a one-GPU box two contexts on GPU 0 stand in for two devices: same energies / forces / error sums as the
+    single-context predictor, small batches and the training-set mode stay on the first context."""
+    from sgdml_amd.predict import GDMLPredict
+
+    g = load('n5_p4')
+    m = dict(_model(g), type='m', z=np.ones(g['R_train'].shape[1], dtype=int), perms=g['perms'])
+    Rq = np.tile(g['R_test'].reshape(len(g['R_test']), -1), (40, 1))  # 280 geometries
+    rs = np.random.RandomState(0)
+    Rq = Rq + 0.01 * rs.normal(size=Rq.shape)
+    one = GDMLPredict(m)
+    two = GDMLPredict(m, devices=[0, 0])
+    assert len(two._replicas) == 1
+    E1, F1 = one.predict(Rq)
+    E2, F2 = two.predict(Rq)
+    # (a shard of 140 may take another kernel than the batch of 280: equal to rounding, not bitwise)
+    assert np.abs(F1 - F2).max() <= 1e-12 * np.abs(F1).max() and np.abs(E1 - E2).max() <= 1e-12 * np.abs(E1).max()
+    (F3,) = two.predict(Rq[:5], return_E=False)
+    assert np.abs(F3 - F1[:5]).max() <= 1e-12 * np.abs(F1).max()
+    Fl, El = F1 + 0.01 * rs.normal(size=F1.shape), E1 + 0.01
+    e1, e2 = one.test_errors(Rq, Fl, El), two.test_errors(Rq, Fl, El)
+    for k in e1:
+        assert np.allclose(e1[k], e2[k], rtol=1e-9, atol=0), k
+    two.set_R_desc(g['R_desc'])
+    two.set_R_d_desc(g['R_d_desc'])
+    Et, Ft = two.predict()
+    assert np.abs(Ft - g['F_train_pred']).max() <= 1e-10 * np.abs(g['F_train_pred']).max() + cancel_floor(g)
+    del one, two
