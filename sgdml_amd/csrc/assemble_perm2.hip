@@ -85,7 +85,9 @@ struct Perm2Args {
             // 128 no staging of the rows, 256 no image prefetch
 };
 
-template <bool TRACE, bool DIRECT>
+// LIST: column points come from A.jlist (a separate instantiation: the dense kernel's register allocation is untouched --
+// tests/test_isa_schedule.py pins its scratch budget)
+template <bool TRACE, bool DIRECT, bool LIST = false>
 __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = A.N, N3 = 3 * N, NN = N * N, P = A.P, nF = A.nF;
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(P2_T) assemble_perm2_kernel(Perm2Args A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t jv = blockIdx.x;
-  const int64_t jpt = A.jlist ? (int64_t)A.jlist[jv] : A.j0 + jv;
+  const int64_t jpt = LIST ? (int64_t)A.jlist[jv] : A.j0 + jv;
   const bool lower = A.lower != 0;
   const int64_t i_lo = (lower ? jv : A.i_beg) + (int64_t)blockIdx.y * A.i_chunk;
   const int64_t i_top = lower ? A.M : A.i_end;
@@ -1141,7 +1143,10 @@ int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, in
     A.trace = d_trace;
   }
   const int slot = ktime_begin(ctx);
-  if (d_trace && direct) hipLaunchKernelGGL((assemble_perm2_kernel<true, true>), grid, dim3(P2_T), lds, ctx->stream, A);
+  if (A.jlist != nullptr) {  // whole-point index list: its own instantiation (staged rows)
+    (void)hipFuncSetAttribute((const void*)assemble_perm2_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((assemble_perm2_kernel<false, false, true>), grid, dim3(P2_T), lds, ctx->stream, A);
+  } else if (d_trace && direct) hipLaunchKernelGGL((assemble_perm2_kernel<true, true>), grid, dim3(P2_T), lds, ctx->stream, A);
   else if (d_trace) hipLaunchKernelGGL((assemble_perm2_kernel<true, false>), grid, dim3(P2_T), lds, ctx->stream, A);
   else if (direct) hipLaunchKernelGGL((assemble_perm2_kernel<false, true>), grid, dim3(P2_T), lds, ctx->stream, A);
   else hipLaunchKernelGGL((assemble_perm2_kernel<false, false>), grid, dim3(P2_T), lds, ctx->stream, A);

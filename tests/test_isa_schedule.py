@@ -159,7 +159,7 @@ def test_perm2_kernel_keeps_scratch_out_of_its_store_passes_and_inner_loops():
     (profiles/r05_assemble_perm2.txt: 125 -> 17 scratch instructions was 18.9 -> 17.5 ms; three-entry trips for every row type spill and
     were 16.4 -> 19.2 ms).  Checked on the compiled production kernel: few scratch instructions overall, at most three behind the first
     row store (today: two accumulator tuples reloaded for a later pass, the table pointer of the image request), LDS-only barriers between the row passes, and no chain of three or more single-read LDS round trips."""
-    ins = _kernel(_assembly('assemble_perm2'), '_Z21assemble_perm2_kernelILb0ELb0EEv9Perm2Args')  # the staged-rows variant (asm.perm2_direct = 0)
+    ins = _kernel(_assembly('assemble_perm2'), '_Z21assemble_perm2_kernelILb0ELb0ELb0EEv9Perm2Args')  # the staged-rows variant (asm.perm2_direct = 0)
     scratch = [k for k, l in enumerate(ins) if l.startswith('scratch_')]
     assert len(scratch) <= 45, len(scratch)
     stores = [k for k, l in enumerate(ins) if l.startswith('global_store')]
