@@ -105,7 +105,7 @@ def test_trailing_update_loop_keeps_its_schedule():
     text = _assembly('chol')
     sym = '_Z23gemm_nt_sub_diag_kernelILb1ELb1ELi5EEv8GemmArgs'
     start = text.index('\n' + sym + ':')
-    kern = text[start:text.index('s_endpgm', start)]
+    kern = text[start:text.index('.Lfunc_end', start)]  # (the kernel has several exits since it carries the panel-solve strips)
     # inner loops = from an "Inner Loop Header" label to the backward branch to that label
     loops = []
     for m in re.finditer(r'^(\.LBB\d+_\d+):[^\n]*Inner Loop Header[^\n]*\n', kern, flags=re.M):
