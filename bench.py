@@ -532,6 +532,7 @@ def main():
     ap.add_argument('--cg-inducing', type=int, default=200)
     ap.add_argument('--cg-iters', type=int, default=50, help='PCG iterations per step of the configs[2] workload')
     ap.add_argument('--no-to-tol', action='store_true', help='N>1: skip the sharded run to solver_tol')
+    ap.add_argument('--dist-chol-timeout', type=float, default=900.0, help='N>1: seconds the distributed-Cholesky measurement may take')
     ap.add_argument('--to-tol-timeout', type=float, default=600.0, help='N>1: seconds the sharded run to solver_tol may take')
     ap.add_argument('--dist-chol', action='store_true', help='N>1: also time the configs[1] system through the distributed Cholesky')
     ap.add_argument('--workload', default='auto', choices=('auto', 'analytic', 'cg'),
@@ -570,8 +571,8 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
-        if isinstance(out, dict) and isinstance(out.get('time_to_tol'), dict) and \
-                str(out['time_to_tol'].get('error', '')).startswith('no result within'):
+        stuck = [out.get(k) for k in ('time_to_tol', 'dist_cholesky')] if isinstance(out, dict) else []
+        if any(isinstance(x, dict) and str(x.get('error', '')).startswith('no result within') for x in stuck):
             os._exit(0)  # a worker thread is stuck inside a collective: do not wait for it at interpreter exit
 
 
@@ -666,59 +667,77 @@ def run_multi(args, rank, world, workload):
     # assemble this rank's row blocks of A = -K + lam I + factor + both substitutions.  Default schedule (dist.lookahead
     # unset: one panel of look-ahead from two ranks on), then the other schedule for comparison (3 repetitions).
     dchol = None
+    chol_hung = False
     if with_chol:
-        try:
-            Mc = args.n_train
-            Rc, Ec, Fc = synth_geometries(N, Mc, seed=0)
-            yc = Fc.ravel() / np.std(Fc)
-            xdc, gdc = ctx.desc_from_R(Rc.reshape(Mc, -1), N)
-            tpc = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
-            ctx.train_upload(xdc, gdc, tpc)
-            for _ in range(max(1, args.warmup) if workload == 'analytic' else 1):
-                ctx.dist_chol_solve(args.sig, args.lam, yc)
-            ctx.profile(True)
-            barrier()
-            t0 = time.perf_counter()
-            ph = []
-            n_steps = args.steps if workload == 'analytic' else 2
-            for _ in range(n_steps):
-                a_c = ctx.dist_chol_solve(args.sig, args.lam, yc)
-                ph.append({k_: ctx.phase_ms(k_)[0] for k_ in ('assemble', 'factor', 'solve')})
-            barrier()
-            wall = (time.perf_counter() - t0) / max(1, n_steps)
-            g_ms, g_n, g_fl = ctx.kernel_stat('gemm_nt_sub')
-            ctx.profile(False)
-            (wall, g_ms_max) = max_over_ranks([wall, g_ms])
-            phases = {k_: max_over_ranks([float(np.mean([p_[k_] for p_ in ph]))])[0] for k_ in ph[0]}
-            ctx.predict_upload_model(xdc, np.zeros_like(xdc), tpc, args.sig, None)
-            Kv = ctx.kernel_matvec(args.lam, False, -a_c)
-            resid = float(np.linalg.norm(-Kv - yc) / np.linalg.norm(yc))
-            ctx.train_upload(xdc, gdc, tpc)
-            ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-            dchol = {'s_per_solve': wall, 'build_solve_s': (phases['assemble'] + phases['factor'] + phases['solve']) / 1e3,
-                     'phases_ms': phases, 'solve_rel_residual': resid, 'matrix_n': Mc * 3 * N,
-                     'matrix_bytes_per_rank': ctx.mem_info()[0],
-                     'schedule': 'dist.lookahead default (1 from two ranks on)',
-                     'roofline': {'kernel': 'gemm_nt_sub_kernel (fp64 MFMA trailing updates of this rank\'s row blocks, K = 512, '
-                                            'block-cyclic lower tile predicate)', 'bound': 'mfma', 'achieved': ach,
-                                  'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': ach / FP64_MFMA_PEAK_TF, 'traffic': None,
-                                  'launches': g_n, 'avg_launch_ms': g_ms / max(1, g_n), 'rank': 0,
-                                  'kernel_ms_per_solve_max_over_ranks': g_ms_max / max(1, n_steps)},
-                     'other_schedule': {}}
-            la_default = 1 if world > 1 else 0
-            ctx.set_option('dist.lookahead', 1 - la_default)
-            ts = []
-            for rep in range(3):
+        # in a worker thread under a time limit (--dist-chol-timeout): the RCCL branch of the distributed Cholesky has never run
+        # on more than one physical GPU; should a collective hang there, a line must still be printed (value null + the error)
+        # instead of the driver's timeout killing the run
+        import threading
+
+        cbox = {}
+
+        def _chol():
+            try:
+                Mc = args.n_train
+                Rc, Ec, Fc = synth_geometries(N, Mc, seed=0)
+                yc = Fc.ravel() / np.std(Fc)
+                xdc, gdc = ctx.desc_from_R(Rc.reshape(Mc, -1), N)
+                tpc = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
+                ctx.train_upload(xdc, gdc, tpc)
+                for _ in range(max(1, args.warmup) if workload == 'analytic' else 1):
+                    ctx.dist_chol_solve(args.sig, args.lam, yc)
+                ctx.profile(True)
                 barrier()
                 t0 = time.perf_counter()
-                ctx.dist_chol_solve(args.sig, args.lam, yc)
+                ph = []
+                n_steps = args.steps if workload == 'analytic' else 2
+                for _ in range(n_steps):
+                    a_c = ctx.dist_chol_solve(args.sig, args.lam, yc)
+                    ph.append({k_: ctx.phase_ms(k_)[0] for k_ in ('assemble', 'factor', 'solve')})
                 barrier()
-                ts.append(time.perf_counter() - t0)
-            (t_best,) = max_over_ranks([min(ts[1:])])
-            dchol['other_schedule'] = {'dist.lookahead': 1 - la_default, 's_per_solve': t_best}
-            ctx.set_option('dist.lookahead', la_default)
-        except Exception as e:  # a line must still be printed
-            dchol = {'error': repr(e)}
+                wall = (time.perf_counter() - t0) / max(1, n_steps)
+                g_ms, g_n, g_fl = ctx.kernel_stat('gemm_nt_sub')
+                ctx.profile(False)
+                (wall, g_ms_max) = max_over_ranks([wall, g_ms])
+                phases = {k_: max_over_ranks([float(np.mean([p_[k_] for p_ in ph]))])[0] for k_ in ph[0]}
+                ctx.predict_upload_model(xdc, np.zeros_like(xdc), tpc, args.sig, None)
+                Kv = ctx.kernel_matvec(args.lam, False, -a_c)
+                resid = float(np.linalg.norm(-Kv - yc) / np.linalg.norm(yc))
+                ctx.train_upload(xdc, gdc, tpc)
+                ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+                dchol_ = {'s_per_solve': wall, 'build_solve_s': (phases['assemble'] + phases['factor'] + phases['solve']) / 1e3,
+                         'phases_ms': phases, 'solve_rel_residual': resid, 'matrix_n': Mc * 3 * N,
+                         'matrix_bytes_per_rank': ctx.mem_info()[0],
+                         'schedule': 'dist.lookahead default (1 from two ranks on)',
+                         'roofline': {'kernel': 'gemm_nt_sub_kernel (fp64 MFMA trailing updates of this rank\'s row blocks, K = 512, '
+                                                'block-cyclic lower tile predicate)', 'bound': 'mfma', 'achieved': ach,
+                                      'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': ach / FP64_MFMA_PEAK_TF, 'traffic': None,
+                                      'launches': g_n, 'avg_launch_ms': g_ms / max(1, g_n), 'rank': 0,
+                                      'kernel_ms_per_solve_max_over_ranks': g_ms_max / max(1, n_steps)},
+                         'other_schedule': {}}
+                la_default = 1 if world > 1 else 0
+                ctx.set_option('dist.lookahead', 1 - la_default)
+                ts = []
+                for rep in range(3):
+                    barrier()
+                    t0 = time.perf_counter()
+                    ctx.dist_chol_solve(args.sig, args.lam, yc)
+                    barrier()
+                    ts.append(time.perf_counter() - t0)
+                (t_best,) = max_over_ranks([min(ts[1:])])
+                dchol_['other_schedule'] = {'dist.lookahead': 1 - la_default, 's_per_solve': t_best}
+                ctx.set_option('dist.lookahead', la_default)
+                cbox['r'] = dchol_
+            except Exception as e:  # a line must still be printed
+                cbox['r'] = {'error': repr(e)}
+
+        th_c = threading.Thread(target=_chol, daemon=True)
+        th_c.start()
+        th_c.join(timeout=args.dist_chol_timeout)
+        chol_hung = th_c.is_alive()
+        dchol = {'error': 'no result within {} s'.format(args.dist_chol_timeout)} if chol_hung else cbox.get('r')
+        if chol_hung:  # the context is stuck inside a collective: nothing more can run on it
+            with_cg = False
 
     # ---- configs[2]: K_nm rows + preconditioner + a fixed number of PCG iterations
     res = wl = None
@@ -735,12 +754,13 @@ def run_multi(args, rank, world, workload):
                 raise
             res = None
             wl = {'error': repr(e)}
-    ctx.close()
+    if not chol_hung:
+        ctx.close()
 
     # the same workload as the 1-GPU configs[2] entry run to solver_tol through GDMLTrain.train, sharded over the ranks
     # (leverage-sampled inducing points, the reference's restart policy): what a SCALE record means as a SOLVE
     to_tol = None
-    hung = False
+    hung = chol_hung
     if with_cg and not args.no_to_tol:
         # in a worker thread under a time limit: this leg builds a second communicator and runs several hundred sharded
         # iterations; should a collective ever hang on some node, the line above must still be printed (the main
