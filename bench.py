@@ -406,6 +406,8 @@ def assembly_kernel_name(n_atoms, n_perms):
     (tests/test_host_policy_cpu.py checks that the two agree)."""
     if n_perms == 1 and n_atoms <= 21:
         return 'assemble_strip_kernel' if n_atoms >= 11 else 'assemble_wave_kernel'
+    if n_perms == 1 and 22 <= n_atoms <= 256:
+        return 'assemble_big1_kernel (P = 1: rank-one term + one 3 x 3 outer product per atom pair; one workgroup per block pair)'
     if n_perms > 1 and 8 <= n_atoms <= 24:
         return 'assemble_pts_kernel'
     if n_atoms <= 42 and ((n_perms >= 16 and n_atoms >= 36) or (n_perms >= 6 and n_atoms >= 40)):

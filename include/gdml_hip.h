@@ -111,6 +111,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *                         full-line stores, row points per workgroup
  *   asm.perm_compact (1)  index-list columns: strips of the REQUESTED column atoms instead of all atoms of every point touched
  *   asm.perm_lds_rows (1) permutation entries from the LDS copy for 64 < N <= 128 (always beyond 128 atoms); 0 = two lane-held rows (A/B)
+ *   asm.big1 (1)          no permutation group and 22 <= N <= 256, dense column range: the direct P = 1 kernel (assemble_big1.hip,
+ *                         round 6) instead of the general permutation kernel; 0 = the general kernel (A/B)
  *   asm.perm2 (1)         molecules with a permutation group of at least asm.perm2_min_p (6) elements, asm.perm2_min_n (36) <= N <= 42
  *                         (groups below 16 elements: from 4 atoms more), dense column ranges -- where it beats the general kernel
  *                         (1.8x at N = 42, P = 27): outer products on

@@ -782,6 +782,9 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
     return gdml_fail(ctx, GDML_ERR_INVALID, "assemble_perm: the lower form needs the dense full column range");
   if (cyc_W > 0 && 3 * N > cyc_nb)
     return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "assemble_perm: row-cyclic layout needs 3N <= %d", cyc_nb);
+  // no permutation group, more than 21 atoms, dense column range, plain layout: the direct P = 1 kernel of assemble_big1.hip
+  if (!d_jlist && !d_colmap && !use_E && cyc_W == 0 && assemble_big1_applicable(ctx))
+    return assemble_big1_launch(ctx, sig, j0, n_j, col0, K, ld, i_beg, i_end, lower ? 1 : 0, lam);
   // 25 ... 42 atoms, plain layout: the MFMA / fixed-atom-split kernel of assemble_perm2.hip -- dense column ranges, and
   // (round 6) index lists that request WHOLE column points in list order (every column of each listed point, output column
   // 3N v + c: what the iterative solver's K_nm is, iterative.py:229-247 -- configs[3] spent 0.69 s per build on the general

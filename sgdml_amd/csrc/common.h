@@ -276,6 +276,9 @@ int assemble_strip_launch(gdml_ctx* ctx, double sig, double* K, int64_t ld, int 
 int assemble_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int64_t ld, int cyc_W, int cyc_rank,
                            int cyc_nb);
 bool assemble_perm2_applicable(const gdml_ctx* ctx);
+bool assemble_big1_applicable(const gdml_ctx* ctx);  // assemble_big1.hip: P = 1, 22 <= N <= 256, dense column ranges
+int assemble_big1_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg,
+                         int64_t i_end, int lower, double lam);
 int assemble_perm2_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, int64_t col0, double* K, int64_t ld, int64_t i_beg,
                           int64_t i_end, int lower, double lam, const int32_t* d_jlist = nullptr);
 int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_jlist, const int32_t* d_colmap, int64_t j0,

@@ -294,3 +294,43 @@ def test_replicated_predictor_shards_query_batches():
     Et, Ft = two.predict()
     assert np.abs(Ft - g['F_train_pred']).max() <= 1e-10 * np.abs(g['F_train_pred']).max() + cancel_floor(g)
     del one, two
+
+
+@pytest.mark.parametrize('N,M', [(22, 9), (30, 6), (64, 5), (100, 3), (130, 2)])
+def test_direct_kernel_for_large_molecules_without_a_group(ctx, N, M):
+    """assemble_big1_kernel (csrc/assemble_big1.hip, round 6: P = 1, 22 <= N <= 256, dense column ranges -- one workgroup per row
+    point and up to four adjacent column points) against the oracle at 1e-12 max|K|: all columns, a point range that does not
+    start at a group boundary (ragged groups of column points), extra rows allocated, the lower form A = -K + lam I that the
+    analytic solver consumes (blocks on / below the block diagonal: the diagonal group of a row is ragged too); and equal to the
+    general kernel (asm.big1 = 0), which keeps index lists and energy constraints."""
+    ds = orc.synth_dataset(N, M, seed=N, jitter=0.3)
+    xd, gd = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    lin = orc.tril_perms_lin_from_tril_perms(tp)
+    sig, lam = 40.0, 1e-7
+    Ko = orc.assemble_K(xd, gd, lin, sig)
+    scale = np.abs(Ko).max()
+    ctx.train_upload(xd, gd, tp)
+    got = {}
+    for opt in (1, 0):
+        ctx.set_option('asm.big1', opt)
+        K = ctx.assemble_K(sig, False, to_host=True)
+        assert np.abs(K - Ko).max() <= 1e-12 * scale, opt
+        lo, hi = 1, min(M, 8)
+        Ks = ctx.assemble_K(sig, False, points=(lo, hi), alloc_extra_rows=3, to_host=True)
+        assert np.abs(Ks[:3 * N * M] - Ko[:, 3 * N * lo:3 * N * hi]).max() <= 1e-12 * scale, opt
+        ctx.assemble_K(sig, False, alloc_extra_rows=1, for_cholesky=lam)
+        A = ctx.K_to_host()[:3 * N * M]
+        low = np.kron(np.tril(np.ones((M, M))), np.ones((3 * N, 3 * N))).astype(bool)
+        assert np.abs((A - (-Ko + lam * np.eye(3 * N * M)))[low]).max() <= 1e-12 * scale, opt
+        got[opt] = (K, A[low])
+    assert np.abs(got[1][0] - got[0][0]).max() <= 1e-13 * scale
+    # the analytic solve through the lower form
+    ctx.set_option('asm.big1', 1)
+    y = ds['F'].ravel() / np.std(ds['F'])
+    ctx.assemble_K(sig, False, alloc_extra_rows=1, for_cholesky=lam)
+    ctx.chol_set_rhs(y)
+    assert ctx.chol_factor(lam) == 0
+    a = ctx.chol_solve(None)
+    Am = -Ko + lam * np.eye(3 * N * M)
+    assert np.linalg.norm(Am @ (-a) - y) <= 1e-10 * np.linalg.norm(y)

@@ -326,7 +326,12 @@ def test_bench_labels_follow_the_library_dispatch_of_the_perm2_kernel():
     for n in range(25, 50):
         for p in (1, 2, 6, 12, 16, 27, 64):
             assert bench.assembly_kernel_name(n, p).startswith('assemble_perm2_kernel') == lib_rule(n, p), (n, p)
-    assert bench.assembly_kernel_name(21, 1).startswith('assemble_strip') and bench.assembly_kernel_name(100, 1) == 'assemble_perm_kernel'
+    # P = 1 beyond 21 atoms: the direct kernel of assemble_big1.hip (its rule is read from the source as well)
+    big = open(os.path.join(root, 'sgdml_amd', 'csrc', 'assemble_big1.hip')).read()
+    assert 'ts.P == 1 && ts.N >= 22 && ts.N <= 256' in big
+    assert bench.assembly_kernel_name(21, 1).startswith('assemble_strip') and bench.assembly_kernel_name(100, 1).startswith('assemble_big1_kernel')
+    assert bench.assembly_kernel_name(22, 1).startswith('assemble_big1') and bench.assembly_kernel_name(300, 1) == 'assemble_perm_kernel'
+    assert bench.assembly_kernel_name(100, 2) == 'assemble_perm_kernel'
 
 
 def test_bench_lines_of_every_gpu_count_name_the_same_workload():
