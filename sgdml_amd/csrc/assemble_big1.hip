@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(256) assemble_big1_kernel(Big1Args A) {
   // coalesced 512-byte pieces of ONE column point per workgroup 29.7 ms, with its Jacobian gathers removed 27.5 ms -- i.e. the store
   // pattern itself (tools/store_bw.hip's 'seg' patterns: 2.4-2.9 TB/s for one segment per row against 4.5 for eight); FOUR adjacent
   // column points 22.8 ms; the four column points dealt to the four wavefronts instead (each 3N x 8 bytes of the same rows) 28.0 ms;
-  // one matrix row at a time (gathers and LDS reads repeated per row) 32.8 ms.
+  // one matrix row at a time (gathers and LDS reads repeated per row) 32.8 ms; the column points one after the other inside a row atom
+  // (per-point quantities wave uniform, but a partly filled last chunk per point and 512-byte pieces that start anywhere) 26.0 ms.
   const int64_t row0 = A.lower ? i * N3 : (i - A.i_beg) * N3;
   const int64_t colb = A.lower ? j_first * N3 : A.col0 + (j_first - A.j0) * N3;
   double* __restrict__ Kb = A.K + row0 * A.ld + colb;
@@ -237,7 +238,9 @@ int assemble_big1_launch(gdml_ctx* ctx, double sig, int64_t j0, int64_t n_j, int
   while (2 * Q * ts.N <= 256 && Q < 32) Q *= 2;
   A.Q = Q;
   A.dbg = ctx_opt_i(ctx, "asm.big1", 1);
-  const size_t lds = (size_t)BIG1_J * ts.N * 16 * 8;
+  const size_t lds = (size_t)BIG1_J * ts.N * 16 * 8;  // 51 KB at 100 atoms, 131 KB at 256
+  if (lds > (size_t)48 * 1024)
+    (void)hipFuncSetAttribute((const void*)assemble_big1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int slot = ktime_begin(ctx);
   hipLaunchKernelGGL(assemble_big1_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, A);
   ktime_end(ctx, slot, "assemble", 8.0 * (lower ? 0.5 * (double)n_i * (double)(n_i + 1) : (double)n_i * (double)n_j) * 9.0 * ts.N * ts.N);
