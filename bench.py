@@ -686,6 +686,31 @@ def run_multi(args, rank, world, workload):
                 xdc, gdc = ctx.desc_from_R(Rc.reshape(Mc, -1), N)
                 tpc = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
                 ctx.train_upload(xdc, gdc, tpc)
+                la_default = 1 if world > 1 else 0
+
+                def residual(a_):
+                    ctx.predict_upload_model(xdc, np.zeros_like(xdc), tpc, args.sig, None)
+                    Kv = ctx.kernel_matvec(args.lam, False, -a_)
+                    ctx.train_upload(xdc, gdc, tpc)
+                    return float(np.linalg.norm(-Kv - yc) / np.linalg.norm(yc))
+
+                # (1) the in-order schedule first (one stream, one communicator: what needs least from RCCL) -- if the look-ahead
+                # schedule below should not come back on some node, this is the number the line falls back to
+                ctx.set_option('dist.lookahead', 0)
+                ts = []
+                for rep in range(3):
+                    barrier()
+                    t0 = time.perf_counter()
+                    a_c = ctx.dist_chol_solve(args.sig, args.lam, yc)
+                    barrier()
+                    ts.append(time.perf_counter() - t0)
+                (t_in,) = max_over_ranks([min(ts[1:])])
+                ph_in = {k_: max_over_ranks([ctx.phase_ms(k_)[0]])[0] for k_ in ('assemble', 'factor', 'solve')}
+                cbox['inorder'] = {'dist.lookahead': 0, 's_per_solve': t_in, 'phases_ms': ph_in,
+                                   'build_solve_s': (ph_in['assemble'] + ph_in['factor'] + ph_in['solve']) / 1e3,
+                                   'solve_rel_residual': residual(a_c)}
+                # (2) the default schedule (one panel of look-ahead from two ranks on): W untimed, K timed solves
+                ctx.set_option('dist.lookahead', la_default)
                 for _ in range(max(1, args.warmup) if workload == 'analytic' else 1):
                     ctx.dist_chol_solve(args.sig, args.lam, yc)
                 ctx.profile(True)
@@ -702,33 +727,18 @@ def run_multi(args, rank, world, workload):
                 ctx.profile(False)
                 (wall, g_ms_max) = max_over_ranks([wall, g_ms])
                 phases = {k_: max_over_ranks([float(np.mean([p_[k_] for p_ in ph]))])[0] for k_ in ph[0]}
-                ctx.predict_upload_model(xdc, np.zeros_like(xdc), tpc, args.sig, None)
-                Kv = ctx.kernel_matvec(args.lam, False, -a_c)
-                resid = float(np.linalg.norm(-Kv - yc) / np.linalg.norm(yc))
-                ctx.train_upload(xdc, gdc, tpc)
+                resid = residual(a_c)
                 ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
                 dchol_ = {'s_per_solve': wall, 'build_solve_s': (phases['assemble'] + phases['factor'] + phases['solve']) / 1e3,
-                         'phases_ms': phases, 'solve_rel_residual': resid, 'matrix_n': Mc * 3 * N,
-                         'matrix_bytes_per_rank': ctx.mem_info()[0],
-                         'schedule': 'dist.lookahead default (1 from two ranks on)',
-                         'roofline': {'kernel': 'gemm_nt_sub_kernel (fp64 MFMA trailing updates of this rank\'s row blocks, K = 512, '
-                                                'block-cyclic lower tile predicate)', 'bound': 'mfma', 'achieved': ach,
-                                      'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': ach / FP64_MFMA_PEAK_TF, 'traffic': None,
-                                      'launches': g_n, 'avg_launch_ms': g_ms / max(1, g_n), 'rank': 0,
-                                      'kernel_ms_per_solve_max_over_ranks': g_ms_max / max(1, n_steps)},
-                         'other_schedule': {}}
-                la_default = 1 if world > 1 else 0
-                ctx.set_option('dist.lookahead', 1 - la_default)
-                ts = []
-                for rep in range(3):
-                    barrier()
-                    t0 = time.perf_counter()
-                    ctx.dist_chol_solve(args.sig, args.lam, yc)
-                    barrier()
-                    ts.append(time.perf_counter() - t0)
-                (t_best,) = max_over_ranks([min(ts[1:])])
-                dchol_['other_schedule'] = {'dist.lookahead': 1 - la_default, 's_per_solve': t_best}
-                ctx.set_option('dist.lookahead', la_default)
+                          'phases_ms': phases, 'solve_rel_residual': resid, 'matrix_n': Mc * 3 * N,
+                          'matrix_bytes_per_rank': ctx.mem_info()[0],
+                          'schedule': 'dist.lookahead = %d (library default for %d rank%s)' % (la_default, world, '' if world == 1 else 's'),
+                          'roofline': {'kernel': 'gemm_nt_sub_kernel (fp64 MFMA trailing updates of this rank\'s row blocks, K = 512, '
+                                                 'block-cyclic lower tile predicate)', 'bound': 'mfma', 'achieved': ach,
+                                       'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': ach / FP64_MFMA_PEAK_TF, 'traffic': None,
+                                       'launches': g_n, 'avg_launch_ms': g_ms / max(1, g_n), 'rank': 0,
+                                       'kernel_ms_per_solve_max_over_ranks': g_ms_max / max(1, n_steps)},
+                          'other_schedule': cbox['inorder']}
                 cbox['r'] = dchol_
             except Exception as e:  # a line must still be printed
                 cbox['r'] = {'error': repr(e)}
@@ -737,7 +747,16 @@ def run_multi(args, rank, world, workload):
         th_c.start()
         th_c.join(timeout=args.dist_chol_timeout)
         chol_hung = th_c.is_alive()
-        dchol = {'error': 'no result within {} s'.format(args.dist_chol_timeout)} if chol_hung else cbox.get('r')
+        if chol_hung and 'inorder' in cbox:  # the look-ahead schedule did not come back: the in-order measurement stands in
+            io = cbox['inorder']
+            dchol = {'s_per_solve': io['s_per_solve'], 'build_solve_s': io['build_solve_s'], 'phases_ms': io['phases_ms'],
+                     'solve_rel_residual': io['solve_rel_residual'], 'matrix_n': args.n_train * 3 * N,
+                     'schedule': 'dist.lookahead = 0: the default (look-ahead) schedule did not return within {} s'.format(args.dist_chol_timeout),
+                     'roofline': {'kernel': 'gemm_nt_sub_kernel', 'bound': 'mfma', 'achieved': None, 'peak': FP64_MFMA_PEAK_TF,
+                                  'unit': 'TFLOP/s', 'frac': None, 'traffic': None},
+                     'error': 'no result within {} s (look-ahead schedule)'.format(args.dist_chol_timeout)}
+        else:
+            dchol = {'error': 'no result within {} s'.format(args.dist_chol_timeout)} if chol_hung else cbox.get('r')
         if chol_hung:  # the context is stuck inside a collective: nothing more can run on it
             with_cg = False
 
