@@ -38,6 +38,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GT 128
 #define GBK 16
 #define GPITCH 17
+#define G6N 64  // tile columns of the 128 x 64 kernel (gemm.n64)
 #ifndef GEMM_COMMIT_KS
 #define GEMM_COMMIT_KS 12  // k-step after which the prefetched tile is written to LDS (0,4,8,12): 12 = as late as possible,
                            // the global loads of the next tile get the whole tile to arrive (4 -> 12: -1.1 % factorisation time)
@@ -92,6 +93,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g);
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_trace_kernel(GemmArgs g);
 template <int CKS, int FLAGS = 2>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sub_persist_kernel(GemmArgs g);
+__global__ void __launch_bounds__(256, 3) gemm_nt_sub_n64_kernel(GemmArgs g);
 
 template <bool FULL>
 __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ G, int64_t ld,
@@ -609,6 +611,8 @@ struct DiagJob {
   int64_t M2 = 0, N2 = 0, K2 = 0;
 };
 
+static bool gemm_use_n64(gdml_ctx* ctx) { return ctx_opt_i(ctx, "gemm.n64", 0) != 0; }
+
 static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
                                    const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
                                    int64_t N, int64_t K, int lower, double f0, double f1, bool timed,
@@ -628,9 +632,12 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   g.nt_c = ctx_opt_i(ctx, "gemm.nt_c", 0);
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
               (lda % 2 == 0) && (ldb % 2 == 0);
+  // gemm.n64: 128 x 64 tiles, three workgroups per CU (gemm_nt_sub_n64_kernel); super tiles stay 1024 x 1024
+  const bool n64 = gemm_use_n64(ctx) && !cyc && g.dbg == 0;
+  const int TN = n64 ? G6N : GT, super_cols = n64 ? 16 : 8;
   g.tiles_m = (int)((M + GT - 1) / GT);
-  g.tiles_n = (int)((N + GT - 1) / GT);
-  int64_t sm = (g.tiles_m + 7) / 8, sn = (g.tiles_n + 7) / 8;
+  g.tiles_n = (int)((N + TN - 1) / TN);
+  int64_t sm = (g.tiles_m + 7) / 8, sn = (g.tiles_n + super_cols - 1) / super_cols;
   g.super_n = (int)sn;
   const int64_t n_super_all = lower ? sm * (sm + 1) / 2 : sm * sn;
   g.s_begin = (int64_t)(f0 * (double)n_super_all);
@@ -641,16 +648,18 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
     g.n_super = g.s_begin;  // empty tile range: the launch still carries the diagonal-block workgroup
   }
   int64_t groups = (g.n_super - g.s_begin + 7) / 8;  // each group of 8 super tiles = 8 XCDs x 64 blocks
-  int64_t blocks = groups * 512;
+  int64_t blocks = groups * (n64 ? 1024 : 512);
   const int slot = (timed && st == (ctx->kt_stream ? ctx->kt_stream : ctx->stream)) ? ktime_begin(ctx) : -1;
   if (has_diag) {
     g.diagA = diag->A; g.diag_nbw = diag->nbw; g.diag_off = diag->off; g.diag_info = ctx->d_info;
     if (diag->ready) { g.ready = diag->ready; g.ready_target = diag->ready_target; g.ready_rows = diag->nbw * 64 / GT; }
     if (diag->A2 && diag->M2 > 0) {
       g.A2 = diag->A2; g.B2 = diag->B2; g.C2 = diag->C2; g.M2 = diag->M2; g.N2 = diag->N2; g.K2 = diag->K2;
-      g.tiles2 = (int)(ceil_div(g.M2, GT) * ceil_div(g.N2, GT));
+      g.tiles2 = (int)(ceil_div(g.M2, GT) * ceil_div(g.N2, TN));
     }
     const dim3 grid((unsigned)(blocks + 1 + g.tiles2));
+    if (n64) hipLaunchKernelGGL(gemm_nt_sub_n64_kernel, grid, dim3(256), 0, st, g);
+    else {
     // gemm.trace = k > 0: the k-th fused launch since the option was set runs the traced instantiation and leaves
     // gemm_trace.bin (header: blocks, tiles2, tiles_m, s_begin, n_super, col0_first; then 4 x 8 words per workgroup)
     const int trace_k = ctx_opt_i(ctx, "gemm.trace", 0);
@@ -697,7 +706,10 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
     // gemm.lds16 = 2: the loop with its last k-tile inside (A/B reference of the peeled production loop)
     if (ctx_opt_i(ctx, "gemm.lds16", 3) == 2) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 4>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 5>), grid, dim3(256), 0, st, g);
-  } else if (g.dbg)
+    }
+  } else if (n64)
+    hipLaunchKernelGGL(gemm_nt_sub_n64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+  else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL(gemm_nt_sub_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
@@ -829,12 +841,12 @@ __device__ __forceinline__ double quad_bcast(double v, int q) {
 // of an LDS permute round trip), the L values of column c + 1 are fetched from LDS while column c is applied, and the
 // column steps are expanded at compile time (a 64-trip loop of this size is only partially unrolled even under
 // #pragma unroll, which turns t[c >> 3] into a dynamically indexed register array).
-template <int LP>
+template <int LP, bool TRL = false>
 __device__ __forceinline__ void subst64_row8(double (&t)[8], const double* __restrict__ Lt, const double* __restrict__ rinv,
                                              int sq) {
   double ln[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ln[i] = Lt[sq + 8 * i];
+  for (int i = 0; i < 8; ++i) ln[i] = TRL ? Lt[(sq + 8 * i) * LP] : Lt[sq + 8 * i];
   double rn = rinv[0];
   auto column = [&](auto cc) __attribute__((always_inline)) {
     constexpr int c = decltype(cc)::value;
@@ -847,7 +859,7 @@ __device__ __forceinline__ void subst64_row8(double (&t)[8], const double* __res
       rn = rinv[c + 1];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (i >= ((c + 1) >> 3)) ln[i] = Lt[(c + 1) * LP + sq + 8 * i];
+        if (i >= ((c + 1) >> 3)) ln[i] = TRL ? Lt[(sq + 8 * i) * LP + (c + 1)] : Lt[(c + 1) * LP + sq + 8 * i];
     }
     const double xq = quad_bcast(t[ic] * rc, qc & 3);                      // lane (qc & 3) of the own quad
     const double xo = (qc < 4) ? dpp_mov<0x114>(xq) : dpp_mov<0x104>(xq);  // the other quad's: row_shr:4 / row_shl:4
@@ -910,11 +922,14 @@ __device__ __forceinline__ int potrf64_wg(double* T, double* colbuf /* 2 x 64 */
   return fail;
 }
 
+// SMALL: no transposed copy of L_jj (the substitution reads the factored block in T column-wise: pitch 65 is conflict free both
+// ways) -- 35 KB of LDS instead of 68, for the 128 x 64-tile kernel that runs three workgroups per CU on 48 KB each
+template <bool SMALL = false>
 __device__ __forceinline__ void diag_block_role(double* __restrict__ D, int64_t ld, int nbw, int64_t global_off,
                                              int* __restrict__ info, double* lds) {
   double* T = lds;                   // 64 x 65 (potrf); afterwards reused as S: 32 x 66 row block of the substitution
   double* Lt = lds + 64 * 65;        // L_jj^T, pitch 65
-  double* rinv = Lt + 64 * 65;       // 64
+  double* rinv = SMALL ? lds + 64 * 65 : Lt + 64 * 65;  // 64
   double* col = rinv + 64;           // 2 x 64
   double* S = T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -934,7 +949,7 @@ __device__ __forceinline__ void diag_block_role(double* __restrict__ D, int64_t 
     for (int e = tid; e < 64 * 64; e += 256) {
       const int r = e >> 6, c = e & 63;
       const double v = (c <= r) ? T[r * 65 + c] : 0.0;
-      Lt[c * 65 + r] = v;
+      if constexpr (!SMALL) Lt[c * 65 + r] = v;
       if (c <= r) Ad[(int64_t)r * ld + c] = v;
       if (c == r) rinv[r] = 1.0 / v;
     }
@@ -947,7 +962,8 @@ __device__ __forceinline__ void diag_block_role(double* __restrict__ D, int64_t 
       double t[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) t[i] = xr[sq + 8 * i];
-      subst64_row8<65>(t, Lt, rinv, sq);
+      if constexpr (SMALL) subst64_row8<65, true>(t, T, rinv, sq);
+      else subst64_row8<65>(t, Lt, rinv, sq);
 #pragma unroll
       for (int i = 0; i < 8; ++i) xr[sq + 8 * i] = t[i];
     }
@@ -1025,6 +1041,249 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_diag_kernel(GemmArgs g) {
     return;
   }
   gemm_block<false, PIPE, CACC, CKS>(g, lds, (int64_t)blockIdx.x - 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// 128 x 64 tiles, THREE workgroups per CU (round 6, option gemm.n64).  The traced 128 x 128 kernel loses its time in the state
+// "one of the CU's two workgroups is between tiles, the other runs alone at 0.76 of the pipe" (14 % of the time,
+// profiles/r06_gemm_trace.txt); with three narrower workgroups (64 accumulator registers per lane instead of 128: 168 VGPRs,
+// 48 KB of LDS each) two of them are still in their k loops while the third turns over.  Price: 1.5 x the operand traffic
+// per flop from L2 and a barrier every 32 MFMAs instead of 64.  Same loop as the production kernel's (16-byte LDS layout,
+// operand pairs of the next half k-tile read ahead, last k-tile peeled, schedule pinned by sched_barriers); wave (wm, wn)
+// owns 64 rows x 32 columns = 4 x 2 MFMA tiles.
+// ------------------------------------------------------------------------------------------
+#define G6_STAGE ((GT + G6N) * GBK)  // doubles per LDS stage: A tile (128 x 16), then B tile (64 x 16)
+
+template <bool FULL>
+__device__ __forceinline__ void gemm_tile_body_n64(const GemmArgs& g, double* __restrict__ lds, int64_t row0, int64_t col0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c16 = lane & 15, gq = lane >> 4;
+  const int wu = __builtin_amdgcn_readfirstlane(wave);
+  double* const Ct = g.C + (row0 + (wu >> 1) * 64) * g.ldc + col0 + (wu & 1) * 32;
+  const unsigned coff = (unsigned)gq * (unsigned)g.ldc + (unsigned)c16;
+  d4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (FULL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = -(Ct + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff + j * 16];
+      } else {
+        acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+      }
+    }
+  const int nk32 = (int)((g.K + GBK - 1) / GBK);
+  unsigned offA[4], offB[2];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int cidx = tid + 256 * s4;
+    offA[s4] = (unsigned)(((int64_t)(cidx >> 3) * g.lda + (cidx & 7) * 2) * 8);
+    if (s4 < 2) offB[s4] = (unsigned)(((int64_t)(cidx >> 3) * g.ldb + (cidx & 7) * 2) * 8);
+  }
+  const double* const Abase = g.A + row0 * g.lda;
+  const double* const Bbase = g.B + col0 * g.ldb;
+  d2 ra[4], rb[2];
+  auto load_ab = [&](int kt_) {
+    const int64_t ko = (int64_t)kt_ * GBK;
+    if constexpr (FULL) {
+      typedef const __attribute__((address_space(1))) char* gcptr;
+      typedef const __attribute__((address_space(1))) d2* gd2ptr;
+      const uint64_t pa = reinterpret_cast<uint64_t>(Abase + ko), pb = reinterpret_cast<uint64_t>(Bbase + ko);
+      const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)pa), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
+      const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)pb), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32));
+      gcptr ba = (gcptr)(((uint64_t)ahi << 32) | alo);
+      gcptr bb = (gcptr)(((uint64_t)bhi << 32) | blo);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) ra[s4] = *(gd2ptr)(ba + offA[s4]);
+#pragma unroll
+      for (int s4 = 0; s4 < 2; ++s4) rb[s4] = *(gd2ptr)(bb + offB[s4]);
+    } else {
+      // branch-free guarded loads: clamp the address, then zero what is out of range
+      auto guarded = [&](const double* __restrict__ G, int64_t ld, int64_t r0, int64_t nrows, int cidx) -> d2 {
+        const int64_t gr = r0 + (cidx >> 3), gk = ko + (cidx & 7) * 2;
+        const int64_t cr = gr < nrows ? gr : nrows - 1;
+        const int64_t ck0 = gk < g.K ? gk : g.K - 1, ck1 = gk + 1 < g.K ? gk + 1 : g.K - 1;
+        const double v0 = G[cr * ld + ck0], v1 = G[cr * ld + ck1];
+        d2 v;
+        v.x = (gr < nrows && gk < g.K) ? v0 : 0.0;
+        v.y = (gr < nrows && gk + 1 < g.K) ? v1 : 0.0;
+        return v;
+      };
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) ra[s4] = guarded(g.A, g.lda, row0, g.M, tid + 256 * s4);
+#pragma unroll
+      for (int s4 = 0; s4 < 2; ++s4) rb[s4] = guarded(g.B, g.ldb, col0, g.N, tid + 256 * s4);
+    }
+  };
+  // element (row, kq = k / 2) of a tile = the pair (k, k + 1) at d2 index kq * rows + (row ^ kq)  (gemm_store_tile16's layout)
+  auto commit = [&](int buf) {
+    d2* SA = reinterpret_cast<d2*>(lds + buf * G6_STAGE);
+    d2* SB = SA + GT * GBK / 2;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int cidx = tid + 256 * s4;
+      const int row = cidx >> 3, kq = cidx & 7;
+      SA[kq * GT + (row ^ kq)] = ra[s4];
+      if (s4 < 2) SB[kq * G6N + (row ^ kq)] = rb[s4];
+    }
+  };
+  auto read_half = [&](d2 (&a_)[4], d2 (&b_)[2], int buf, int h) {
+    const int kq = 2 * gq + h;
+    const int cx = c16 ^ kq;
+    const d2* Ap = reinterpret_cast<const d2*>(lds + buf * G6_STAGE) + kq * GT + wm * 64 + cx;
+    const d2* Bp = reinterpret_cast<const d2*>(lds + buf * G6_STAGE) + GT * GBK / 2 + kq * G6N + wn * 32 + cx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_[i] = Ap[16 * i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_[j] = Bp[16 * j];
+  };
+  auto mfma8 = [&](const d2 (&a_)[4], const d2 (&b_)[2], int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(t ? a_[i].y : a_[i].x, t ? b_[j].y : b_[j].x, acc[i][j], 0, 0, 0);
+  };
+  load_ab(0);
+  commit(0);
+  __syncthreads();
+  d2 a0[4], b0[2], a1[4], b1[2];
+  read_half(a0, b0, 0, 0);
+  auto step = [&](int kt, auto has_next_t) {
+    constexpr bool HN = decltype(has_next_t)::value;
+    const int cur = kt & 1;
+    if constexpr (HN) load_ab(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(a0, b0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_half(a1, b1, cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(a0, b0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(a1, b1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HN) {
+      commit(cur ^ 1);
+      __syncthreads();
+      read_half(a0, b0, cur ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma8(a1, b1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int kt = 0; kt + 1 < nk32; ++kt) step(kt, std::true_type{});
+  step(nk32 - 1, std::false_type{});
+
+  // ---- epilogue: the accumulator holds -C + A B^T (full tiles) or A B^T (edge tiles)
+  if constexpr (FULL) {
+    double* Ct2g = Ct;
+    unsigned coff2 = coff;
+    asm volatile("" : "+v"(Ct2g), "+v"(coff2));
+    __attribute__((address_space(1))) double* Ct2 = (__attribute__((address_space(1))) double*)Ct2g;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) (Ct2 + (int64_t)(i * 16 + 4 * r) * g.ldc)[coff2 + j * 16] = -acc[i][j][r];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t gc = col0 + wn * 32 + j * 16 + c16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gr = row0 + wm * 64 + i * 16 + gq + 4 * r;
+          if (gc < g.N && gr < g.M) g.C[gr * g.ldc + gc] -= acc[i][j][r];
+        }
+    }
+  }
+}
+
+// block index -> tile: super tiles of 8 x 16 tiles (1024 x 1024 elements, 128 workgroups; block b runs on XCD b % 8)
+__device__ __forceinline__ void gemm_block_n64(const GemmArgs& g, double* __restrict__ lds, int64_t b) {
+  if (b < g.tiles2) {  // second problem
+    const int tn2 = (int)((g.N2 + G6N - 1) / G6N);
+    const int64_t ti = b / tn2, tj = b - ti * tn2;
+    if (ti * GT < g.N2 && tj * G6N > ti * GT + GT - 1) return;  // above the diagonal of its leading N2 x N2 block
+    GemmArgs h = g;
+    h.A = g.A2; h.B = g.B2; h.C = g.C2; h.M = g.M2; h.N = g.N2; h.K = g.K2;
+    h.aligned = ((reinterpret_cast<uintptr_t>(g.A2) | reinterpret_cast<uintptr_t>(g.B2)) & 15) == 0 && g.aligned;
+    const int64_t row0 = ti * GT, col0 = tj * G6N;
+    const bool full = (row0 + GT <= h.M) && (col0 + G6N <= h.N) && ((h.K & (GBK - 1)) == 0) && h.aligned;
+    if (full) gemm_tile_body_n64<true>(h, lds, row0, col0);
+    else gemm_tile_body_n64<false>(h, lds, row0, col0);
+    if (g.ready && ti < g.ready_rows && col0 < (int64_t)g.ready_rows * GT) {
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) atomicAdd(g.ready, 1);
+    }
+    return;
+  }
+  b -= g.tiles2;
+  const int64_t xcd = b & 7, loc = b >> 3;
+  const int64_t s = g.s_begin + (loc >> 7) * 8 + xcd;
+  const int within = (int)(loc & 127);
+  if (s >= g.n_super) return;
+  int64_t SI, SJ;
+  if (g.lower) {
+    int64_t sr = s, shift = 0;
+    const int64_t sm = (g.tiles_m + 7) / 8;
+    if (g.col0_first) {
+      if (s < sm) { SI = s; SJ = 0; sr = -1; }
+      else { sr = s - sm; shift = 1; }
+    }
+    if (sr >= 0) {
+      SI = (int64_t)((sqrt(8.0 * (double)sr + 1.0) - 1.0) * 0.5);
+      while (SI * (SI + 1) / 2 > sr) --SI;
+      while ((SI + 1) * (SI + 2) / 2 <= sr) ++SI;
+      SJ = sr - SI * (SI + 1) / 2;
+      SI += shift; SJ += shift;
+    }
+  } else {
+    SI = s / g.super_n;
+    SJ = s - SI * g.super_n;
+  }
+  const int64_t ti = SI * 8 + (within >> 4), tj = SJ * 16 + (within & 15);
+  if (ti >= g.tiles_m || tj >= g.tiles_n) return;
+  const int64_t row0 = ti * GT, col0 = tj * G6N;
+  if (g.lower && col0 > row0 + GT - 1) return;
+  const bool full = (row0 + GT <= g.M) && (col0 + G6N <= g.N) && ((g.K & (GBK - 1)) == 0) && g.aligned;
+  if (full) gemm_tile_body_n64<true>(g, lds, row0, col0);
+  else gemm_tile_body_n64<false>(g, lds, row0, col0);
+  if (g.ready && g.tiles2 == 0 && ti < g.ready_rows && col0 < (int64_t)g.ready_rows * GT) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(g.ready, 1);
+  }
+}
+
+__global__ void __launch_bounds__(256, 3) gemm_nt_sub_n64_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[2 * G6_STAGE];  // 48 KB
+  static_assert(2 * G6_STAGE >= 64 * 65 + 64 + 128, "LDS of the diagonal role (SMALL form)");
+  int64_t b = blockIdx.x;
+  if (g.diagA != nullptr) {
+    if (b == 0) {
+      if (g.ready) {
+        if (threadIdx.x == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(g.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.ready_target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 24)) { atomicExch(g.ready + 1, 1); break; }
+          }
+        }
+        __syncthreads();
+        __threadfence();
+      }
+      diag_block_role<true>(g.diagA, g.ldc, g.diag_nbw, g.diag_off, g.diag_info, lds);
+      return;
+    }
+    b -= 1;
+  }
+  gemm_block_n64(g, lds, b);
 }
 
 // Persistent form of the fused launch (round 6, option gemm.persist): 2 workgroups per CU stay resident and pull tiles
@@ -1734,7 +1993,9 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
         dj.A = A + t0 * ld + t0; dj.nbw = (int)(NB / 64); dj.off = t0;
         dj.col0_first = true;
         dj.ready = ctx->d_info + 6;
-        ready_count += (int)((NB / GT) * (NB / GT + 1) / 2);
+        // (tiles of a diagonal block: lower 128 x 128 tiles, or with gemm.n64 the 128 x 64 tiles that touch its lower triangle)
+        const int block_tiles = gemm_use_n64(ctx) ? (int)((NB / GT) * (NB / GT + 1)) : (int)((NB / GT) * (NB / GT + 1) / 2);
+        ready_count += block_tiles;
         dj.ready_target = ready_count;
         GDML_TRY(launch_gemm_nt_sub_part(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, n - t0, nb, 1, 0.0, fs, true,
                                          &dj));
@@ -1744,7 +2005,7 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
         // waits for the tiles of block b and factors it
         dj.A = A + ta * ld + ta; dj.off = ta;
         dj.A2 = Xa; dj.B2 = Xa; dj.C2 = A + ta * ld + ta; dj.M2 = n_rows - ta; dj.N2 = NB; dj.K2 = NB;
-        ready_count += (int)((NB / GT) * (NB / GT + 1) / 2);
+        ready_count += block_tiles;
         dj.ready_target = ready_count;
         GDML_TRY(launch_gemm_nt_sub_part(ctx, st, P, ld, P, ld, A + t0 * ld + t0, ld, n_rows - t0, n - t0, nb, 1, fs, 1.0, true,
                                          &dj));

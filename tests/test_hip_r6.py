@@ -179,6 +179,35 @@ def test_persistent_trailing_update_is_bitwise_the_plain_one(ctx):
     assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(y)
 
 
+def test_narrow_tile_trailing_update_solves_the_same_system(ctx):
+    """Option gemm.n64 = 1 (128 x 64 tiles, three workgroups per CU, its own diagonal-block role without the transposed copy
+    of L_jj -- csrc/chol.hip; measured 6.8 % slower, profiles/r06_gemm_n64_ab.txt, so it stays an A/B option): same system,
+    same solution up to the rounding of a different summation order, residual inside the contract.  n = 9450 with the carried
+    right-hand-side row: merged schedule with the tile counter (20 narrow tiles per diagonal block), edge tiles in both
+    dimensions, the K = 64 updates inside the panel factorisation and the plain launches of the schedule's tail."""
+    N, M = 21, 150
+    ds = orc.synth_dataset(N, M, seed=4, jitter=0.3)
+    xd, gd = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    y = ds['F'].ravel() / np.std(ds['F'])
+    ctx.train_upload(xd, gd, tp)
+    sols = {}
+    try:
+        for n64 in (0, 1):
+            ctx.set_option('gemm.n64', n64)
+            ctx.assemble_K(20.0, False, alloc_extra_rows=1, for_cholesky=1e-10)
+            ctx.chol_set_rhs(y)
+            assert ctx.chol_factor(1e-10) == 0
+            sols[n64] = ctx.chol_solve(None)
+    finally:
+        ctx.set_option('gemm.n64', 0)
+    ctx.predict_upload_model(xd, np.zeros_like(xd), tp, 20.0, None)
+    for n64 in (0, 1):
+        r = ctx.kernel_matvec(1e-10, False, -sols[n64]) + y
+        assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(y)
+    assert np.linalg.norm(sols[1] - sols[0]) <= 1e-6 * np.linalg.norm(sols[0])  # cond(K) ~ 1e9 times the fp64 rounding of the two orders
+
+
 def test_whole_point_index_lists_run_on_the_perm2_kernel(ctx):
     """K_nm of the iterative solver (an index list that requests every column of the listed points, iterative.py:229-247) for a
     42-atom molecule with a 27-element group: round 6 routes it to assemble_perm2_kernel (column point = jlist[v]) instead of
