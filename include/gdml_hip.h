@@ -185,6 +185,18 @@ int gdml_get_option(gdml_ctx* ctx, const char* key, double* value_out, int* is_s
 int gdml_desc_from_R(gdml_ctx* ctx, const double* R, int64_t M, int N, const double* lat,
                      const double* lat_inv, double* R_desc_out, double* R_d_desc_out);
 
+/* ---- pairwise atom matching of the symmetry search  (replaces the pool of sgdml/utils/perm.py:200-221 and its worker _bipartite_match_wkr, :53-92;
+ * SURVEY.md 8(f)4).  One wavefront per pair i < j of the M geometries: cost[a][b] = -sum_k absv_i[a][k] absv_j[b][k], atoms of
+ * different species pushed above every same-species entry, the linear assignment by the shortest-augmenting-path algorithm
+ * scipy.optimize.linear_sum_assignment implements, kept when it brings geometry i's distance matrix closer to j's
+ * (perm.py:76-89: after < before and not numpy.isclose).
+ *   absv (M,N,N): |eigenvectors| of the distance matrices, columns by decreasing eigenvalue;  adj (M,N,N): distance matrices;
+ *   species (N) int32;  cost_out (M,M): entry (i,j), i < j = the pair's remaining distance (the rest 0);
+ *   found_ij (capacity,2), found_perm (capacity,N) int32: the kept assignments, in no particular order; *n_found their number --
+ *   if it exceeds `capacity` only the first `capacity` were stored (call again with more room; M (M-1)/2 always suffices). */
+int gdml_perm_match(gdml_ctx* ctx, const double* absv, const double* adj, const int32_t* species, int64_t M, int N,
+                    double* cost_out, int32_t* found_ij, int32_t* found_perm, int64_t capacity, int64_t* n_found);
+
 /* ---- training set residency (replaces the H2D copies at sgdml/train.py:1447-1448) -------
  * tril_perms is the (P,D) descriptor-permutation table, i.e. the un-linearised form of
  * tril_perms_lin (train.py:897-904): tril_perms[p][k] = tril_perms_lin[k*P+p] - p*D.  Each

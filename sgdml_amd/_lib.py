@@ -32,6 +32,7 @@ SIGNATURES = {
     'gdml_profile': (C.c_int, [_vp, C.c_int]),
     'gdml_kernel_stat': (C.c_int, [_vp, C.c_char_p, _dp, _ip, _dp]),
     'gdml_desc_from_R': (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
+    'gdml_perm_match': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     'gdml_train_upload': (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_int]),
     'gdml_assemble_K': (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64,
                                   C.c_int64, _vp, C.c_int64]),
@@ -338,6 +339,26 @@ class Context(object):
         self._check(self._lib.gdml_desc_from_R(self._h, _ptr(R), M, n_atoms, _ptr(lat), _ptr(lat_inv),
                                                _ptr(xd), _ptr(gd)))
         return xd, gd
+
+    def perm_match(self, absv, adj, species):
+        """Pairwise atom matching of the symmetry search on the device (gdml_perm_match).  Returns (cost (M,M) with the
+        entries i < j set, ij (n,2), perms (n,N)): the kept assignments."""
+        absv, adj = f64(absv), f64(adj)
+        M, N = absv.shape[0], absv.shape[1]
+        if absv.shape != (M, N, N) or adj.shape != (M, N, N):
+            raise ValueError('absv and adj must be (M,N,N)')
+        sp = np.ascontiguousarray(species, dtype=np.int32)
+        cost = np.zeros((M, M))
+        cap = max(1, min(M * (M - 1) // 2, 4 * M))  # a tree's worth of kept pairs and then some; repeated with full room if short
+        while True:
+            ij = np.empty((cap, 2), dtype=np.int32)
+            pm = np.empty((cap, N), dtype=np.int32)
+            n = C.c_int64(0)
+            self._check(self._lib.gdml_perm_match(self._h, _ptr(absv), _ptr(adj), _ptr(sp), M, N, _ptr(cost), _ptr(ij),
+                                                  _ptr(pm), cap, C.byref(n)))
+            if n.value <= cap:
+                return cost, ij[:n.value], pm[:n.value]
+            cap = M * (M - 1) // 2
 
     def train_upload(self, R_desc, R_d_desc, tril_perms):
         R_desc, R_d_desc, tril_perms = f64(R_desc), f64(R_d_desc), i64(tril_perms)

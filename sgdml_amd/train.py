@@ -175,7 +175,7 @@ class GDMLTrain(object):
                     )
                     task['perms'] = train_dataset['perms']
                 else:
-                    # Symmetry discovery (train.py:560-584): own host implementation, utils/perm.py
+                    # Symmetry discovery (train.py:560-584): utils/perm.py, the pairwise matching on the GPU (perm_match.hip)
                     from .utils import perm as perm_mod
 
                     lat_and_inv = None
@@ -191,7 +191,7 @@ class GDMLTrain(object):
                         )
                     task['perms'] = perm_mod.find_perms(
                         R_sync, train_dataset['z'], lat_and_inv=lat_and_inv, callback=callback,
-                        max_processes=self._max_processes,
+                        max_processes=self._max_processes, ctx=self._context(),
                     )
             else:
                 n_perms, perms_len = perms.shape

@@ -237,23 +237,6 @@ def test_perm_group_helpers():
     assert [tuple(p) for p in kept] == [(0, 1, 2, 3), (1, 2, 0, 3)]
 
 
-def test_create_task_discovers_perms_without_reference():
-    from sgdml_amd.train import GDMLTrain
-
-    g = np.load(os.path.join(GOLD, 'perm_c3.npz'))
-    n = g['R'].shape[0]
-    rs = np.random.RandomState(0)
-    ds = {'type': 'd', 'name': np.array('c3'), 'theory': np.array('none'), 'z': g['z'], 'R': g['R'],
-          'F': rs.normal(size=g['R'].shape), 'E': rs.normal(size=n)}
-    tr = GDMLTrain()
-    try:
-        np.random.seed(1)
-        task = tr.create_task(ds, n, ds, 0, sig=10)
-        assert {tuple(p) for p in task['perms']} == {tuple(p) for p in g['perms']}
-    finally:
-        tr.__del__()
-
-
 def test_draw_strat_sample_reproduces_reference_indices():
     """draw_strat_sample restates train.py:1537-1646 because the RNG call sequence must be identical for a
     drop-in: under the same seed it returns the reference's indices (fixtures from make_golden_r2.py)."""

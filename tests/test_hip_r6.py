@@ -363,3 +363,102 @@ def test_direct_kernel_for_large_molecules_without_a_group(ctx, N, M):
     a = ctx.chol_solve(None)
     Am = -Ko + lam * np.eye(3 * N * M)
     assert np.linalg.norm(Am @ (-a) - y) <= 1e-10 * np.linalg.norm(y)
+
+
+def _matching_cases():
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'perm_c3.npz'))
+    lat = g['lat']
+    yield 'c3', g['R'], g['z'], None
+    yield 'c3_small', g['R2'], g['z2'], None
+    yield 'c3_small_lattice', g['R2'], g['z2'], (lat, np.linalg.inv(lat))
+    rs = np.random.RandomState(0)
+    for N, M in ((30, 60), (70, 24), (130, 8)):  # 130 atoms: more than two lanes' worth of columns per row scan
+        R = (rs.normal(size=(N, 3)) * 2.0)[None] + 0.05 * rs.normal(size=(M, N, 3))
+        z = rs.choice([1, 6, 8], size=N)
+        same = np.where(z == z[0])[0][:2]
+        R[::2][:, same] = R[::2][:, same[::-1]]  # every other geometry with two like atoms exchanged: non-identity matches
+        yield 'random_n%d' % N, R, z, None
+
+
+def test_device_matching_is_the_host_matching(ctx):
+    """SURVEY 8(f)4 on the device (csrc/perm_match.hip, gdml_perm_match): one wavefront per pair of geometries builds the cost
+    matrix, solves the assignment problem (shortest augmenting paths, the algorithm behind scipy's linear_sum_assignment) and
+    applies the reference's acceptance rule (perm.py:76-89).  Against the NumPy / SciPy form in sgdml_amd/utils/perm.py, which
+    the CPU suite pins to the reference's output: the SAME pairs kept, the SAME assignments, pair costs to 1e-13 relative; and
+    find_perms with the device matching returns the reference's groups (tests/golden/perm_c3.npz) element for element."""
+    from sgdml_amd.utils import perm
+
+    kept_nontrivial = 0
+    for name, R, z, lat in _matching_cases():
+        fh, ch = perm.bipartite_match(R, z, lat)
+        fd, cd = perm.bipartite_match(R, z, lat, ctx=ctx)
+        assert set(fh) == set(fd), name
+        for k in fh:
+            assert np.array_equal(fh[k], fd[k]), (name, k)
+        ch, cd = ch.toarray(), cd.toarray()
+        fin = np.isfinite(ch)
+        assert np.array_equal(fin, np.isfinite(cd))
+        assert np.abs(ch[fin] - cd[fin]).max() <= 1e-13 * np.abs(ch[fin]).max(), name
+        kept_nontrivial += len(fh)
+    assert kept_nontrivial > 500
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'perm_c3.npz'))
+    lat = g['lat']
+    assert np.array_equal(perm.find_perms(g['R'], g['z'], ctx=ctx), g['perms'])
+    assert np.array_equal(perm.find_perms(g['R2'], g['z2'], ctx=ctx), g['perms2'])
+    assert np.array_equal(perm.find_perms(g['R2'], g['z2'], lat_and_inv=(lat, np.linalg.inv(lat)), ctx=ctx), g['perms3'])
+
+
+def test_device_matching_edge_sizes(ctx):
+    """One geometry (no pairs), two geometries, one atom, and a result buffer that is too small (the wrapper repeats the call
+    with room for every pair)."""
+    from sgdml_amd.utils import perm
+
+    rs = np.random.RandomState(3)
+    R = rs.normal(size=(1, 5, 3))
+    f, c = perm.bipartite_match(R, np.ones(5, int), ctx=ctx)
+    assert f == {} and c.shape == (1, 1)
+    R = rs.normal(size=(2, 1, 3))
+    f, c = perm.bipartite_match(R, np.ones(1, int), ctx=ctx)
+    assert f == {}
+    # 12 geometries of a 4-atom molecule, every second one with atoms 0 and 1 exchanged: 36 of 66 pairs are kept; room for 4
+    base = rs.normal(size=(4, 3)) * 2
+    R = base[None] + 0.01 * rs.normal(size=(12, 4, 3))
+    R[::2][:, [0, 1]] = R[::2][:, [1, 0]]
+    adj = perm._dist_matrices(R)
+    w, v = np.linalg.eigh(adj)
+    absv = np.abs(v[:, :, ::-1])
+    cost = np.zeros((12, 12))
+    ij, pm = np.empty((4, 2), np.int32), np.empty((4, 4), np.int32)
+    import ctypes as C
+    from sgdml_amd._lib import _ptr
+    n = C.c_int64(0)
+    sp = np.zeros(4, np.int32)
+    rc = ctx._lib.gdml_perm_match(ctx._h, _ptr(np.ascontiguousarray(absv)), _ptr(np.ascontiguousarray(adj)), _ptr(sp), 12, 4,
+                                  _ptr(cost), _ptr(ij), _ptr(pm), 4, C.byref(n))
+    assert rc == 0 and n.value == 36
+    fh, _ = perm.bipartite_match(R, np.ones(4, int))
+    assert len(fh) == 36
+    for (i, j), p in zip(ij, pm):
+        assert np.array_equal(fh[int(i), int(j)], p)
+    fd, _ = perm.bipartite_match(R, np.ones(4, int), ctx=ctx)  # the wrapper's capacity (4 M = 48) suffices here
+    assert set(fd) == set(fh)
+
+
+def test_create_task_discovers_the_group_on_the_device():
+    """create_task without `perms` (train.py:560-584): the matching runs through gdml_perm_match on the trainer's context and the
+    task carries the reference's group (tests/golden/perm_c3.npz)."""
+    from sgdml_amd.train import GDMLTrain
+
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'perm_c3.npz'))
+    n = g['R'].shape[0]
+    rs = np.random.RandomState(0)
+    ds = {'type': 'd', 'name': np.array('c3'), 'theory': np.array('none'), 'z': g['z'], 'R': g['R'],
+          'F': rs.normal(size=g['R'].shape), 'E': rs.normal(size=n)}
+    tr = GDMLTrain()
+    try:
+        np.random.seed(1)
+        task = tr.create_task(ds, n, ds, 0, sig=10)
+        assert {tuple(p) for p in task['perms']} == {tuple(p) for p in g['perms']}
+        assert tr._context().phase_ms('perm_match')[1] >= 1  # the device kernel ran
+    finally:
+        tr.__del__()
