@@ -14,7 +14,7 @@ synthetic batch, all inputs resident in HBM before the timed region starts:
     assemble -K + lam I (fp64, lower blocks, stays in HBM)  ->  in-place fp64 MFMA Cholesky  ->  triangular solves (alphas)
     [N = 1 only: -> batched force/energy prediction of B query geometries]
   `value` = build+solve seconds.  N = 1: single-GPU factorisation; the line also carries `configs` (the configs[0]-shaped
-  sigma sweep, configs[2] / [3] / [4] to solver_tol on this one GPU), `predict`, `first_call_in_process`, `cpu_baseline`.
+  sigma sweep, configs[2] / [3] / [4] to solver_tol on this one GPU), `predict`, `first_call_in_process`, `symmetry_search`, `cpu_baseline`.
   N > 1: the same system block-row-cyclic over the ranks through gdml_dist_chol_solve (RCCL broadcasts + all-gathers),
   "scaling": "strong"; the configs[2] step and its run to solver_tol ride along (`cg`, `time_to_tol`).
 cg (BASELINE.json configs[2]: aspirin N_train=5000, iterative solver sharded over the GPUs with RCCL): one "step" = this
@@ -1102,6 +1102,24 @@ def run_analytic(args):
         out['predict']['by_batch'], out['roofline_predict'] = predict_sweep(ctx, lib, Rq, N, M, 1)
     except Exception as e:
         out['predict']['by_batch'] = {'error': repr(e)}
+    try:  # what precedes the solve in the user's flow: GDMLTrain.create_task's symmetry search over (at most) 1000 geometries
+        from sgdml_amd.utils import perm as perm_mod
+
+        Ms = min(M, 1000)
+        zs = np.array([6] * (N // 3) + [1] * (N - N // 3))
+        walls = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            grp = perm_mod.find_perms(R[:Ms].reshape(Ms, N, 3), zs, ctx=ctx)
+            walls.append(time.perf_counter() - t0)
+        out['symmetry_search'] = {
+            'geometries': Ms, 'pairs': Ms * (Ms - 1) // 2, 'wall_s': walls[-1], 'first_call_s': walls[0],
+            'matching_kernel_ms': ctx.phase_ms('perm_match')[0], 'group_order': int(grp.shape[0]),
+            'note': 'sgdml_amd.utils.perm.find_perms with the pairwise matching on the device (gdml_perm_match: one assignment '
+                    'problem per wavefront); the same search costs 18.1 s in NumPy/SciPy on the host and 22.6 / 5.0 s in the '
+                    'reference with 1 / 8 processes (profiles/r06_perm_match.txt) -- not part of `value`'}
+    except Exception as e:
+        out['symmetry_search'] = {'error': repr(e)}
     ctx.close()
     if not args.no_configs:
         cfgs = []
