@@ -416,7 +416,7 @@ def assembly_kernel_name(n_atoms, n_perms):
 
 
 def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', sig=20, lam=1e-10, max_memory=None, seed=3,
-                 traj=None, n_inducing=None, dist_backend=None, options=None):
+                 traj=None, n_inducing=None, dist_backend=None, options=None, policy=None):
     """One BASELINE configuration shape run to a SOLUTION through the drop-in GDMLTrain.train (sgdml/train.py:836-1088):
     analytic = assemble + Cholesky + solves; cg = the reference's iterative policy (leverage-score inducing points,
     Nystroem preconditioner, PCG to solver_tol = 1e-4, restarts) -- wall-clock to the converged model, phases,
@@ -449,6 +449,8 @@ def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', si
     try:
         tr._force_solver = solver
         tr._force_n_inducing_pts = n_inducing
+        if policy is not None:
+            tr.inducing_pts_policy = policy
         ctx = tr._context()
         for k_, v_ in (options or {}).items():
             ctx.set_option(k_, v_)
@@ -494,6 +496,7 @@ def solve_config(label, n_atoms, n_train, perms_kind=None, solver='analytic', si
             out.update({'time_to_tol_s': wall, 'solver_tol': float(model['solver_tol']), 'solver_iters': int(model['solver_iters']),
                         'converged': bool(model['solver_resid'] <= model['solver_tol'] * model['norm_y_train']),
                         'inducing_pts_per_stage': draws, 'restarts': max(0, len(draws) - 1),
+                        'inducing_pts_policy': 'forced' if n_inducing else tr.inducing_pts_policy,
                         'precon_form': getattr(tr, '_last_precon_form', None),
                         'f32_gram_min_pivot': ctx.get_option('pcg.f32_last_min_pivot'),
                         'ms_per_pcg_iteration': ph.get('pcg', 0.0) / max(1, int(model['solver_iters']))})
@@ -1153,26 +1156,31 @@ def run_analytic(args):
         TRAJ = {'n_modes': 8, 'amp': 0.15, 'noise': 0.01}
         for label, kw in (
             ('configs[2]: aspirin-sized N=21, N_train={} iterative solver to solver_tol 1e-4 on a synthetic trajectory '
-             '(bench.synth_trajectory), device-memory budget 32 GB -> k inducing points by the memory model'.format(args.cg_n_train),
+             '(bench.synth_trajectory), device-memory budget 32 GB; k inducing points by the COST rule (the default, '
+             'Iterative.cost_n_inducing_pts: minimiser of predicted build + iteration time, never more than memory '
+             'allows)'.format(args.cg_n_train),
              dict(n_atoms=N, n_train=args.cg_n_train, solver='cg', max_memory=32, traj=TRAJ, sig=args.sig)),
             ('configs[2] again with the REFERENCE\'s form of the preconditioner (pcg.precon_form = 0: the stored fp64 factor, '
              'iterative.py:120-140) instead of the fp32 factor + Gram correction the library picks at this size',
              dict(n_atoms=N, n_train=args.cg_n_train, solver='cg', max_memory=32, traj=TRAJ, sig=args.sig,
                   options={'pcg.precon_form': 0})),
+            ('configs[2] with inducing_pts_policy = "memory": as many inducing points as the 32 GB hold, the REFERENCE\'s rule '
+             '(iterative.py:498-503) applied to this backend\'s HBM model -- rounds 3-5\' default',
+             dict(n_atoms=N, n_train=args.cg_n_train, solver='cg', max_memory=32, traj=TRAJ, sig=args.sig, policy='memory')),
             ('configs[2] at the k the REFERENCE\'s own memory rule gives for the same max_memory (iterative.py:827-844 counts four '
-             'n x m host arrays: k = 53 at 32 GB; this backend\'s HBM model above holds one and allows ~2.7 x as many) -- also the '
-             'measured optimum of the k sweep (profiles/r06_k_sweep.txt): the larger k of the entry above costs more to build than '
-             'its fewer iterations save',
+             'n x m host arrays: k = 53 at 32 GB; this backend\'s HBM model holds one and allows ~2.7 x as many)',
              dict(n_atoms=N, n_train=args.cg_n_train, solver='cg', max_memory=32, traj=TRAJ, sig=args.sig,
                   n_inducing=Iterative.max_n_inducing_pts(args.cg_n_train, N, 32 * 1024**3))),
             ('configs[3]: N=42 with a 27-element permutation group, N_train=2000 (n = 252 000: 508 GB as a matrix), iterative '
-             'solver to solver_tol 1e-4, budget 64 GB', dict(n_atoms=42, n_train=2000, perms_kind='c3x3', solver='cg', max_memory=64,
-                                                            traj=TRAJ, sig=60)),
+             'solver to solver_tol 1e-4, budget 64 GB, k by the cost rule (default)',
+             dict(n_atoms=42, n_train=2000, perms_kind='c3x3', solver='cg', max_memory=64, traj=TRAJ, sig=60)),
+            ('configs[3] with inducing_pts_policy = "memory" (rounds 3-5\' default)',
+             dict(n_atoms=42, n_train=2000, perms_kind='c3x3', solver='cg', max_memory=64, traj=TRAJ, sig=60, policy='memory')),
             ('configs[3] at the k of the reference\'s memory rule for 64 GB (k = 64; measured optimum of the sweep ~70)',
              dict(n_atoms=42, n_train=2000, perms_kind='c3x3', solver='cg', max_memory=64, traj=TRAJ, sig=60,
                   n_inducing=Iterative.max_n_inducing_pts(2000, 42, 64 * 1024**3))),
             ('configs[4]: 100-atom molecule, N_train=3000 (n = 900 000: 6.5 TB as a matrix), iterative solver to solver_tol 1e-4, '
-             'budget 64 GB', dict(n_atoms=100, n_train=3000, solver='cg', max_memory=64, traj=TRAJ, sig=100)),
+             'budget 64 GB (memory-limited: both rules give the same k)', dict(n_atoms=100, n_train=3000, solver='cg', max_memory=64, traj=TRAJ, sig=100)),
             ('configs[3] shape at the largest N_train one GPU factors directly: N=42, P=27, N_train=1000 (n = 126 000, 127 GB), analytic',
              dict(n_atoms=42, n_train=1000, perms_kind='c3x3', solver='analytic', sig=args.sig)),
             ('configs[4] shape at the largest N_train one GPU factors directly: 100 atoms, N_train=500 (n = 150 000, 180 GB), analytic',

@@ -161,6 +161,13 @@ class Iterative(object):
         world = ctx.comm_info()[1] if sharded else 1  # the rows of K_nm are split over the ranks, its m x m blocks are not
         n_inducing_pts = min(n_train, Iterative.max_n_inducing_pts_device(n_train, n_atoms, 0.8 * budget, world))
         n_inducing_pts = max(1, n_inducing_pts)
+        n_inducing_pts_mem = n_inducing_pts  # what memory allows: the reference's rule (iterative.py:498-503), and the cap of restarts
+        # (a forced count -- the testing hook the reference-trace tests use -- switches the policy off: reference behaviour)
+        cost_policy = (getattr(self.gdml_train, 'inducing_pts_policy', 'cost') == 'cost'
+                       and not getattr(self.gdml_train, '_force_n_inducing_pts', None))
+        if cost_policy:
+            n_perms = int(np.asarray(task['perms']).shape[0]) if 'perms' in task else 1
+            n_inducing_pts = Iterative.cost_n_inducing_pts(n_train, n_atoms, n_perms, n_inducing_pts, world)
         if getattr(self.gdml_train, '_force_n_inducing_pts', None):
             n_inducing_pts = min(n_train, int(self.gdml_train._force_n_inducing_pts))
         # sharded mode: rank 0's memory model decides for everybody (the reuse branch below, the restart growth and the
@@ -291,7 +298,10 @@ class Iterative(object):
                 # other exit (the reference returns +x here, iterative.py:762: sign-flipped forces -- not reproduced)
                 alphas = -state['alpha_t']
                 break
-            n_inducing_pts = min(int(np.ceil(1.2 * n_inducing_pts)), n_train)
+            # (the reference grows without looking at memory, iterative.py:776; here never beyond what the model allows)
+            # (growing faster under the cost policy -- 1.6 -- was measured on a hard 42-atom system: it overshoots, 26.8 s against
+            #  17.9 s with the reference's 1.2, profiles/r06_train_flow.txt)
+            n_inducing_pts = min(int(np.ceil(1.2 * n_inducing_pts)), n_train, max(n_inducing_pts, n_inducing_pts_mem))
             if lev_scores is None:  # the scores of the preconditioner that just stagnated (iterative.py:783-789)
                 lev_scores = self._lev_scores_now()
             inducing_pts_idxs = self.inducing_pts_from_lev_scores(lev_scores, n_inducing_pts * dim_i)
@@ -334,6 +344,30 @@ class Iterative(object):
         est_bytes = LINEAR_FACT * n_train * n_inducing_pts * (3 * n_atoms) ** 2 * 8
         est_bytes += SQUARE_FACT * n_inducing_pts * n_inducing_pts * (3 * n_atoms) ** 2 * 8
         return est_bytes
+
+    @staticmethod
+    def cost_n_inducing_pts(n_train, n_atoms, n_perms, k_mem, world=1):
+        """Number of inducing points by COST instead of by memory (GDMLTrain.inducing_pts_policy = 'cost', the default; 'memory'
+        = the reference's rule: as many as memory holds, iterative.py:498-503).  With 288 GB of HBM the memory rule builds
+        preconditioners that cost far more than they save: a 42-atom, 2000-point task took 74 s (3 x 20 s of factor builds,
+        12 s of iterations) where k = 64 takes 13 s; configs[2] 4.0 s at k = 162 against 2.5-2.7 s at k = 40-80
+        (profiles/r06_k_sweep.txt, r06_train_flow.txt).  Model, seconds:
+            T(k) = B k^2 + t_mv C / k,   B = 4.7 n (3N)^2 / 60 TFLOP/s   (two tall triangular solves + Gram passes of the build),
+            t_mv = 4e-13 M^2 D P^0.85    (the matrix-free mat-vec: 2.5 / 23 / 18 ms at configs[2] / [3] / [4]),
+            C = 35 000                   (iterations x k of the three configurations' sweeps: 20 000 - 50 000),
+        minimised at k = (t_mv C / 2B)^(1/3), where the build costs half of what the iterations do.  A build predicted under
+        one second is left at the memory rule (small systems: the reference's behaviour, exact preconditioners); a stagnating
+        run still grows k by the reference's restart policy, up to the memory rule.  Deterministic in its arguments (every rank
+        of a sharded run computes the same number)."""
+        dim_i = 3 * n_atoms
+        n = n_train * dim_i
+        w = max(1, int(world))
+        b = 4.7 * n * dim_i**2 / 6e13 / w
+        if b * k_mem**2 <= 1.0:
+            return k_mem
+        t_mv = 4e-13 * float(n_train) ** 2 * (n_atoms * (n_atoms - 1) // 2) * max(1, int(n_perms)) ** 0.85 / w
+        k = int(round((t_mv * 35000.0 / (2.0 * b)) ** (1.0 / 3.0)))
+        return max(1, min(k_mem, max(8, k)))
 
     @staticmethod
     def max_n_inducing_pts_device(n_train, n_atoms, budget_bytes, world=1):

@@ -36,6 +36,10 @@ class GDMLTrain(object):
         self._ctx = None
         self._force_solver = None  # testing hook: 'analytic' or 'cg' overrides the memory-based choice
         self._force_n_inducing_pts = None  # testing hook: inducing points of the iterative solver (else memory model)
+        # Public switch: how the iterative solver sizes its preconditioner.  'cost' (default): the number of inducing points that
+        # minimises predicted build + iteration time, never more than memory allows (solvers/iterative.py::cost_n_inducing_pts);
+        # 'memory': the reference's rule -- as many as fit (iterative.py:498-503).
+        self.inducing_pts_policy = 'cost'
         # Public switch: spend the np.random draws the reference's CPU path spends on its worker benchmark before the CG
         # loop (solvers/iterative.py::_spend_reference_benchmark_draw), so that a run under the same np.random.seed draws the
         # inducing columns of a freshly installed reference's NumPy path.  Off by default: the caller's global stream is

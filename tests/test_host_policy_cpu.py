@@ -353,3 +353,22 @@ def test_bench_lines_of_every_gpu_count_name_the_same_workload():
     for fn in (bench.run_analytic, bench.run_multi):
         body = inspect.getsource(fn)
         assert 'line_skeleton(' in body and "out['scale_point']" in body
+
+
+def test_cost_rule_for_the_number_of_inducing_points():
+    """Iterative.cost_n_inducing_pts (round 6; GDMLTrain.inducing_pts_policy = 'cost'): never more than the memory rule allows,
+    the memory rule itself for systems whose build is predicted under a second (the reference's behaviour, iterative.py:498-503),
+    the minimiser of B k^2 + t_mv C / k otherwise; deterministic, monotone in the mat-vec cost, per-rank cost under sharding."""
+    from sgdml_amd.solvers.iterative import Iterative as I
+
+    assert I.cost_n_inducing_pts(300, 21, 1, 300) == 300        # small: exact preconditioner, as the reference would build
+    assert I.cost_n_inducing_pts(10, 5, 4, 10) == 10
+    k2 = I.cost_n_inducing_pts(5000, 21, 1, 144)                # configs[2]: measured optimum 40-80 (profiles/r06_k_sweep.txt)
+    assert 50 <= k2 <= 90
+    k3 = I.cost_n_inducing_pts(2000, 42, 27, 143)               # configs[3]: measured optimum 70-85, flat to ~110
+    assert 70 <= k3 <= 120
+    assert I.cost_n_inducing_pts(3000, 100, 1, 24) == 24        # configs[4] at 64 GB: memory-limited below the cost optimum
+    assert I.cost_n_inducing_pts(2000, 42, 1, 350) < 60         # the 74 s case of profiles/r06_train_flow.txt
+    assert I.cost_n_inducing_pts(2000, 42, 27, 350) > I.cost_n_inducing_pts(2000, 42, 1, 350)  # dearer mat-vec -> more points
+    assert I.cost_n_inducing_pts(5000, 21, 1, 20) == 20         # never above the memory rule
+    assert I.cost_n_inducing_pts(5000, 21, 1, 144, world=2) == k2  # build and mat-vec both shard: same optimum
