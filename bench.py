@@ -1117,9 +1117,9 @@ def run_analytic(args):
             walls.append(time.perf_counter() - t0)
         out['symmetry_search'] = {
             'geometries': Ms, 'pairs': Ms * (Ms - 1) // 2, 'wall_s': walls[-1], 'first_call_s': walls[0],
-            'matching_kernel_ms': ctx.phase_ms('perm_match')[0], 'group_order': int(grp.shape[0]),
-            'note': 'sgdml_amd.utils.perm.find_perms with the pairwise matching on the device (gdml_perm_match: one assignment '
-                    'problem per wavefront); the same search costs 18.1 s in NumPy/SciPy on the host and 22.6 / 5.0 s in the '
+            'device_ms': ctx.phase_ms('perm_match')[0], 'group_order': int(grp.shape[0]),
+            'note': 'sgdml_amd.utils.perm.find_perms with eigenvectors (batched Jacobi) and pairwise matching on the device '
+                    '(gdml_perm_match: one assignment problem per wavefront); the same search costs 18.1 s in NumPy/SciPy on the host and 22.6 / 5.0 s in the '
                     'reference with 1 / 8 processes (profiles/r06_perm_match.txt) -- not part of `value`'}
     except Exception as e:
         out['symmetry_search'] = {'error': repr(e)}

@@ -190,10 +190,15 @@ int gdml_desc_from_R(gdml_ctx* ctx, const double* R, int64_t M, int N, const dou
  * different species pushed above every same-species entry, the linear assignment by the shortest-augmenting-path algorithm
  * scipy.optimize.linear_sum_assignment implements, kept when it brings geometry i's distance matrix closer to j's
  * (perm.py:76-89: after < before and not numpy.isclose).
- *   absv (M,N,N): |eigenvectors| of the distance matrices, columns by decreasing eigenvalue;  adj (M,N,N): distance matrices;
+ *   absv (M,N,N): |eigenvectors| of the distance matrices, columns by decreasing eigenvalue, or NULL (computed on the device);
+ *   adj (M,N,N): distance matrices;
  *   species (N) int32;  cost_out (M,M): entry (i,j), i < j = the pair's remaining distance (the rest 0);
  *   found_ij (capacity,2), found_perm (capacity,N) int32: the kept assignments, in no particular order; *n_found their number --
  *   if it exceeds `capacity` only the first `capacity` were stored (call again with more room; M (M-1)/2 always suffices). */
+/* |eigenvectors| (M,N,N) of M symmetric N x N matrices, columns by decreasing eigenvalue (replaces the per-geometry
+ * numpy.linalg.eig of perm.py:183-187): one workgroup per matrix, cyclic two-sided Jacobi in LDS.  gdml_perm_match runs the same
+ * kernel when `absv` is NULL. */
+int gdml_sym_eig_absv(gdml_ctx* ctx, const double* adj, int64_t M, int N, double* absv_out);
 int gdml_perm_match(gdml_ctx* ctx, const double* absv, const double* adj, const int32_t* species, int64_t M, int N,
                     double* cost_out, int32_t* found_ij, int32_t* found_perm, int64_t capacity, int64_t* n_found);
 

@@ -32,6 +32,7 @@ SIGNATURES = {
     'gdml_profile': (C.c_int, [_vp, C.c_int]),
     'gdml_kernel_stat': (C.c_int, [_vp, C.c_char_p, _dp, _ip, _dp]),
     'gdml_desc_from_R': (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
+    'gdml_sym_eig_absv': (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp]),
     'gdml_perm_match': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     'gdml_train_upload': (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_int]),
     'gdml_assemble_K': (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64,
@@ -340,13 +341,26 @@ class Context(object):
                                                _ptr(xd), _ptr(gd)))
         return xd, gd
 
+    def sym_eig_absv(self, adj):
+        """|eigenvectors| (M,N,N) of symmetric matrices, columns by decreasing eigenvalue (batched Jacobi on the device)."""
+        adj = f64(adj)
+        M, N = adj.shape[0], adj.shape[1]
+        out = np.empty((M, N, N))
+        self._check(self._lib.gdml_sym_eig_absv(self._h, _ptr(adj), M, N, _ptr(out)))
+        return out
+
     def perm_match(self, absv, adj, species):
-        """Pairwise atom matching of the symmetry search on the device (gdml_perm_match).  Returns (cost (M,M) with the
-        entries i < j set, ij (n,2), perms (n,N)): the kept assignments."""
-        absv, adj = f64(absv), f64(adj)
-        M, N = absv.shape[0], absv.shape[1]
-        if absv.shape != (M, N, N) or adj.shape != (M, N, N):
-            raise ValueError('absv and adj must be (M,N,N)')
+        """Pairwise atom matching of the symmetry search on the device (gdml_perm_match).  absv = None: the eigenvectors of the
+        distance matrices are computed on the device too (batched Jacobi).  Returns (cost (M,M) with the entries i < j set,
+        ij (n,2), perms (n,N)): the kept assignments."""
+        adj = f64(adj)
+        M, N = adj.shape[0], adj.shape[1]
+        if adj.shape != (M, N, N):
+            raise ValueError('adj must be (M,N,N)')
+        if absv is not None:
+            absv = f64(absv)
+            if absv.shape != (M, N, N):
+                raise ValueError('absv must be (M,N,N)')
         sp = np.ascontiguousarray(species, dtype=np.int32)
         cost = np.zeros((M, M))
         cap = max(1, min(M * (M - 1) // 2, 4 * M))  # a tree's worth of kept pairs and then some; repeated with full room if short

@@ -13,7 +13,8 @@
 //      shortest-path costs and the matching in LDS.  With distinct path costs the result does not depend on scan order; on an
 //      exact tie a column that is still free wins (scipy's rule), then the lower index;
 //   3. both Frobenius norms in ONE order of summation, so that an identity assignment reproduces `before` bit for bit.
-// The eigendecompositions (O(M), LAPACK) stay on the host; the spanning tree and the group closure too (utils/perm.py).
+// The eigenvectors come from sym_eig_kernel below (batched Jacobi) unless the caller brings them; the spanning tree and the group
+// closure are host work (utils/perm.py).
 #include "common.h"
 
 #include <cmath>
@@ -219,16 +220,210 @@ __global__ void __launch_bounds__(64) perm_match_kernel(PermMatchArgs A) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Eigenvectors of the M symmetric N x N distance matrices (the reference: numpy.linalg.eig per geometry, perm.py:183-187; the
+// host form here: one batched LAPACK eigh -- 4.5 s for 1000 geometries of 100 atoms, more than the matching itself).  One
+// workgroup per matrix, cyclic two-sided Jacobi with the round-robin ordering: a step rotates N/2 disjoint index pairs at once
+// (angles from the current matrix, then all row updates, then all column updates -- disjoint rotations commute), N - 1 steps
+// visit every pair once.  The working matrix and the accumulated rotations live in LDS when both fit (N <= 100), the rotations
+// in the output buffer otherwise (N <= 140; above that both in device memory).  Converged when the off-diagonal mass is below
+// 1e-30 of the diagonal's -- eigenvectors to a few ulp for separated eigenvalues.  Output: |V| with columns by decreasing
+// eigenvalue, the form the matching consumes (only |V| enters, perm.py:66-70, so the sign convention is immaterial).
+// ------------------------------------------------------------------------------------------
+struct SymEigArgs {
+  const double* adj;  // (M, N, N)
+  double* absv;       // (M, N, N) out: [a][k]
+  double* absvT;      // (M, N, N) out: [k][a]
+  double* work;       // gridDim.x x 2 x N x NP doubles (only the parts that do not fit in LDS are used)
+  int64_t M;
+  int N, NP;          // NP: row pitch of the working matrices (N + 1 when N is even: column accesses spread over the banks)
+  int a_in_lds, v_in_lds;
+};
+
+__global__ void __launch_bounds__(256) sym_eig_kernel(SymEigArgs S) {
+  extern __shared__ __attribute__((aligned(8))) unsigned char eig_raw[];
+  const int N = S.N, NP = S.NP, tid = threadIdx.x;
+  const int ne = (N + 1) & ~1, npairs = ne / 2, m = ne - 1;
+  double* lds = reinterpret_cast<double*>(eig_raw);
+  double* cs = lds;              // [npairs][2]
+  int* pq = reinterpret_cast<int*>(cs + 2 * npairs);  // [npairs][2]
+  double* red = reinterpret_cast<double*>(pq + 2 * npairs + (npairs & 1) * 2);  // [8]
+  double* next = red + 8;
+  double* gw = S.work + (int64_t)blockIdx.x * 2 * N * NP;
+  double* A = S.a_in_lds ? next : gw;
+  if (S.a_in_lds) next += N * NP;
+  double* V = S.v_in_lds ? next : gw + N * NP;
+
+  for (int64_t mat = blockIdx.x; mat < S.M; mat += gridDim.x) {
+    const double* G = S.adj + mat * N * N;
+    for (int e = tid; e < N * N; e += 256) {
+      const int r = e / N, c = e - r * N;
+      A[r * NP + c] = 0.5 * (G[e] + G[c * N + r]);
+      V[r * NP + c] = (r == c) ? 1.0 : 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; ++sweep) {
+      // off-diagonal mass against the diagonal's
+      double off = 0.0, dia = 0.0;
+      for (int e = tid; e < N * N; e += 256) {
+        const int r = e / N, c = e - r * N;
+        const double a = A[r * NP + c];
+        if (r == c) dia += a * a; else off += a * a;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dia += __shfl_xor(dia, o, 64); }
+      if ((tid & 63) == 0) { red[2 * (tid >> 6)] = off; red[2 * (tid >> 6) + 1] = dia; }
+      __syncthreads();
+      off = red[0] + red[2] + red[4] + red[6];
+      dia = red[1] + red[3] + red[5] + red[7];
+      __syncthreads();
+      if (off <= 1e-30 * (dia + off)) break;
+      for (int step = 0; step < m; ++step) {
+        if (tid < npairs) {
+          int p, q;
+          if (tid == 0) { p = step % m; q = m; }
+          else { p = (step + tid) % m; q = (step + m - tid) % m; }
+          if (p > q) { const int t = p; p = q; q = t; }
+          double c = 1.0, s = 0.0;
+          if (q < N) {
+            const double apq = A[p * NP + q];
+            if (apq != 0.0) {
+              const double tau = (A[q * NP + q] - A[p * NP + p]) / (2.0 * apq);
+              const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+              c = 1.0 / sqrt(1.0 + t * t);
+              s = t * c;
+            }
+          } else {
+            q = -1;  // the padding index of an odd N: no rotation
+          }
+          cs[2 * tid] = c; cs[2 * tid + 1] = s;
+          pq[2 * tid] = p; pq[2 * tid + 1] = q;
+        }
+        __syncthreads();
+        // rows p, q of A:  A <- J^T A
+        for (int e = tid; e < npairs * N; e += 256) {
+          const int k = e / N, j = e - k * N;
+          const int p = pq[2 * k], q = pq[2 * k + 1];
+          if (q < 0) continue;
+          const double c = cs[2 * k], s = cs[2 * k + 1];
+          const double ap = A[p * NP + j], aq = A[q * NP + j];
+          A[p * NP + j] = c * ap - s * aq;
+          A[q * NP + j] = s * ap + c * aq;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // columns p, q of A and of V:  A <- A J,  V <- V J
+        for (int e = tid; e < npairs * N; e += 256) {
+          const int k = e / N, i = e - k * N;
+          const int p = pq[2 * k], q = pq[2 * k + 1];
+          if (q < 0) continue;
+          const double c = cs[2 * k], s = cs[2 * k + 1];
+          const double ap = A[i * NP + p], aq = A[i * NP + q];
+          A[i * NP + p] = c * ap - s * aq;
+          A[i * NP + q] = s * ap + c * aq;
+          const double vp = V[i * NP + p], vq = V[i * NP + q];
+          V[i * NP + p] = c * vp - s * vq;
+          V[i * NP + q] = s * vp + c * vq;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // (the rotated pair's off-diagonal entry is zero up to rounding: make it exactly symmetric-zero)
+        if (tid < npairs && pq[2 * tid + 1] >= 0) {
+          A[pq[2 * tid] * NP + pq[2 * tid + 1]] = 0.0;
+          A[pq[2 * tid + 1] * NP + pq[2 * tid]] = 0.0;
+        }
+        __syncthreads();
+      }
+    }
+    // columns by decreasing eigenvalue (ties: lower index first), absolute values out
+    double* O = S.absv + mat * N * N;
+    double* OT = S.absvT + mat * N * N;
+    for (int i = tid; i < N; i += 256) {
+      const double li = A[i * NP + i];
+      int rank = 0;
+      for (int j = 0; j < N; ++j) {
+        const double lj = A[j * NP + j];
+        rank += (lj > li) || (lj == li && j < i);
+      }
+      for (int a = 0; a < N; ++a) {
+        const double av = fabs(V[a * NP + i]);
+        O[a * N + rank] = av;
+        OT[rank * N + a] = av;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
-// absv: (M,N,N) |eigenvectors| of the distance matrices, columns by decreasing eigenvalue; adj: (M,N,N) distance matrices;
+// |V| (columns by decreasing eigenvalue) of M symmetric N x N matrices already on the device; d_v [a][k], d_vT [k][a]
+static int launch_sym_eig(gdml_ctx* ctx, const double* d_adj, double* d_v, double* d_vT, int64_t M, int N) {
+  SymEigArgs e;
+  e.adj = d_adj; e.absv = d_v; e.absvT = d_vT; e.M = M; e.N = N;
+  e.NP = (N % 2 == 0) ? N + 1 : N;
+  const int ne = (N + 1) & ~1, npairs = ne / 2;
+  const size_t fixed = (size_t)(2 * npairs) * 8 + (size_t)(2 * npairs + (npairs & 1) * 2) * 4 + 8 * 8;
+  const size_t mat_b = (size_t)N * e.NP * 8, lds_max = 160 * 1024;
+  e.a_in_lds = fixed + mat_b <= lds_max;
+  e.v_in_lds = e.a_in_lds && fixed + 2 * mat_b <= lds_max;
+  const size_t eig_lds = fixed + (e.a_in_lds ? mat_b : 0) + (e.v_in_lds ? mat_b : 0);
+  int64_t eg = (int64_t)ctx->num_cus * (eig_lds > 80 * 1024 ? 1 : eig_lds > 40 * 1024 ? 2 : 4);
+  if (eg > M) eg = M;
+  double* d_w = nullptr;
+  GDML_TRY(ctx_alloc(ctx, (void**)&d_w, eg * 2 * (int64_t)N * e.NP * 8));
+  e.work = d_w;
+  hipError_t se = hipSuccess;
+  if (eig_lds > 48 * 1024)
+    se = hipFuncSetAttribute(reinterpret_cast<const void*>(sym_eig_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds);
+  if (se == hipSuccess) {
+    const int es = ktime_begin(ctx);
+    hipLaunchKernelGGL(sym_eig_kernel, dim3((unsigned)eg), dim3(256), eig_lds, ctx->stream, e);
+    ktime_end(ctx, es, "sym_eig", (double)M);
+    ctx->launch_counter++;
+    se = hipGetLastError();
+    if (se == hipSuccess) se = hipStreamSynchronize(ctx->stream);  // (the work buffer is released below)
+  }
+  ctx_free(ctx, d_w);
+  if (se != hipSuccess) return gdml_fail(ctx, GDML_ERR_HIP, "eigenvector kernel of the symmetry search: %s", hipGetErrorString(se));
+  return GDML_OK;
+}
+
+// |eigenvectors| of M symmetric N x N matrices, columns by decreasing eigenvalue (what gdml_perm_match computes when it is not
+// handed any): for tests and for callers that want them on the host.
+extern "C" int gdml_sym_eig_absv(gdml_ctx* ctx, const double* adj, int64_t M, int N, double* absv_out) {
+  if (!ctx) return GDML_ERR_INVALID;
+  if (!adj || !absv_out || M < 0 || N < 1 || N > GDML_MAX_ATOMS)
+    return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_sym_eig_absv: bad arguments (M=%lld N=%d)", (long long)M, N);
+  if (M == 0) return GDML_OK;
+  HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int64_t bytes = M * (int64_t)N * N * 8;
+  double *d_a = nullptr, *d_v = nullptr, *d_t = nullptr;
+  int rc = ctx_alloc(ctx, (void**)&d_a, bytes);
+  if (rc == GDML_OK) rc = ctx_alloc(ctx, (void**)&d_v, bytes);
+  if (rc == GDML_OK) rc = ctx_alloc(ctx, (void**)&d_t, bytes);
+  if (rc == GDML_OK && hipMemcpyAsync(d_a, adj, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    rc = gdml_fail(ctx, GDML_ERR_HIP, "gdml_sym_eig_absv: upload failed");
+  if (rc == GDML_OK) rc = launch_sym_eig(ctx, d_a, d_v, d_t, M, N);
+  if (rc == GDML_OK && (hipMemcpyAsync(absv_out, d_v, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx->stream) != hipSuccess))
+    rc = gdml_fail(ctx, GDML_ERR_HIP, "gdml_sym_eig_absv: download failed");
+  ctx_free(ctx, d_a); ctx_free(ctx, d_v); ctx_free(ctx, d_t);
+  return rc;
+}
+
+// absv: (M,N,N) |eigenvectors| of the distance matrices, columns by decreasing eigenvalue, or NULL: computed on the device
+// (sym_eig_kernel); adj: (M,N,N) distance matrices;
 // species: (N).  cost_out (M,M): entries (i,j), i < j (the rest is zero); found_ij (capacity,2) / found_perm
 // (capacity,N): the kept assignments in no particular order, *n_found of them (if *n_found > capacity the call has to be repeated
 // with more room: the first `capacity` are valid).
 extern "C" int gdml_perm_match(gdml_ctx* ctx, const double* absv, const double* adj, const int32_t* species, int64_t M, int N,
                                double* cost_out, int32_t* found_ij, int32_t* found_perm, int64_t capacity, int64_t* n_found) {
   if (!ctx) return GDML_ERR_INVALID;
-  if (!absv || !adj || !species || !cost_out || !found_ij || !found_perm || !n_found || M < 0 || N < 1 || N > GDML_MAX_ATOMS ||
+  if (!adj || !species || !cost_out || !found_ij || !found_perm || !n_found || M < 0 || N < 1 || N > GDML_MAX_ATOMS ||
       capacity < 0 || M > 2000000)
     return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_perm_match: bad arguments (M=%lld N=%d)", (long long)M, N);
   *n_found = 0;
@@ -242,11 +437,14 @@ extern "C" int gdml_perm_match(gdml_ctx* ctx, const double* absv, const double* 
   if (grid > pairs) grid = pairs;
   while (grid > 256 && grid * NN * 8 > ((int64_t)1 << 31)) grid /= 2;  // at most 2 GiB of cost slices
   if (capacity > pairs) capacity = pairs;
-  // host -> device: |V| and its per-geometry transpose, the distance matrices
-  std::vector<double> hT((size_t)(M * NN));
-  for (int64_t m = 0; m < M; ++m)
-    for (int a = 0; a < N; ++a)
-      for (int k = 0; k < N; ++k) hT[(size_t)(m * NN + (int64_t)k * N + a)] = absv[m * NN + (int64_t)a * N + k];
+  // host -> device: the distance matrices; |V| and its per-geometry transpose when the caller brings the eigenvectors
+  std::vector<double> hT;
+  if (absv) {
+    hT.resize((size_t)(M * NN));
+    for (int64_t m = 0; m < M; ++m)
+      for (int a = 0; a < N; ++a)
+        for (int k = 0; k < N; ++k) hT[(size_t)(m * NN + (int64_t)k * N + a)] = absv[m * NN + (int64_t)a * N + k];
+  }
   double *d_v = nullptr, *d_vT = nullptr, *d_adj = nullptr, *d_sl = nullptr, *d_cost = nullptr;
   int32_t *d_sp = nullptr, *d_ij = nullptr, *d_pm = nullptr;
   unsigned* d_cnt = nullptr;
@@ -281,9 +479,18 @@ extern "C" int gdml_perm_match(gdml_ctx* ctx, const double* absv, const double* 
   PM_TRY(ctx_alloc(ctx, (void**)&d_pm, (capacity > 0 ? capacity : 1) * (int64_t)N * 4));
   PM_TRY(ctx_alloc(ctx, (void**)&d_cnt, 64));
   hipStream_t st = ctx->stream;
-  PM_HIP(hipMemcpyAsync(d_v, absv, (size_t)(M * NN * 8), hipMemcpyHostToDevice, st));
-  PM_HIP(hipMemcpyAsync(d_vT, hT.data(), (size_t)(M * NN * 8), hipMemcpyHostToDevice, st));
   PM_HIP(hipMemcpyAsync(d_adj, adj, (size_t)(M * NN * 8), hipMemcpyHostToDevice, st));
+  phase_begin(ctx);
+  if (absv) {
+    PM_HIP(hipMemcpyAsync(d_v, absv, (size_t)(M * NN * 8), hipMemcpyHostToDevice, st));
+    PM_HIP(hipMemcpyAsync(d_vT, hT.data(), (size_t)(M * NN * 8), hipMemcpyHostToDevice, st));
+  } else {
+    rc = launch_sym_eig(ctx, d_adj, d_v, d_vT, M, N);
+    if (rc != GDML_OK) {
+      release();
+      return rc;
+    }
+  }
   PM_HIP(hipMemcpyAsync(d_sp, species, (size_t)N * 4, hipMemcpyHostToDevice, st));
   PM_HIP(hipMemsetAsync(d_cnt, 0, 64, st));
   PM_HIP(hipMemsetAsync(d_cost, 0, (size_t)(M * M * 8), st));
@@ -294,7 +501,6 @@ extern "C" int gdml_perm_match(gdml_ctx* ctx, const double* absv, const double* 
   a.capacity = (unsigned)capacity;
   if (lds > 48 * 1024)
     PM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(perm_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  phase_begin(ctx);
   const int slot = ktime_begin(ctx);
   hipLaunchKernelGGL(perm_match_kernel, dim3((unsigned)grid), dim3(64), lds, st, a);
   ktime_end(ctx, slot, "perm_match", (double)pairs);

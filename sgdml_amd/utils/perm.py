@@ -2,8 +2,9 @@
 Permutational-symmetry discovery, own implementation of the procedure of
 sgdml/utils/perm.py:53-404.  The O(M^2) part -- one linear assignment problem per pair of geometries, 499 500 of them at the
 1000 geometries the search is capped at: 18 s on the host at 21 atoms, 23 s in the reference with one process -- runs on the GPU
-when a context is passed (csrc/perm_match.hip, a wavefront per pair; GDMLTrain.create_task always passes its own); the
-eigendecompositions, the spanning tree and the closure are host work.  The NumPy / SciPy form of the matching below is what the
+when a context is passed (csrc/perm_match.hip, a wavefront per pair; GDMLTrain.create_task always passes its own), and so do the
+eigendecompositions in front of it (batched Jacobi, one workgroup per geometry); the distance matrices, the spanning tree and
+the closure are host work.  The NumPy / SciPy form of the matching below is what the
 CPU tests pin against the reference's output, and what the GPU tests pin the kernel against:
 
   1. ``bipartite_match``  (perm.py:53-255): for every pair (i, j) of geometries, the atom assignment that
@@ -51,20 +52,21 @@ def bipartite_match(R, z, lat_and_inv=None, max_processes=None, callback=None, c
     species_penalty = (z[:, None] != z[None, :]).astype(float)
 
     adj = _dist_matrices(R, lat_and_inv)
-    w, v = np.linalg.eigh(adj)                      # ascending eigenvalues
-    absv = np.abs(v[:, :, ::-1])                     # columns by decreasing eigenvalue
     if callback is not None:
         callback = partial(callback, disp_str='Bi-partite matching')
 
-    if ctx is not None:
+    if ctx is not None:  # eigenvectors (batched Jacobi) and the M (M - 1) / 2 assignment problems on the device
         _, species = np.unique(z, return_inverse=True)
-        cost_ij, ij, pm = ctx.perm_match(absv, adj, species)
+        cost_ij, ij, pm = ctx.perm_match(None, adj, species)
         found = {(int(i), int(j)): p.astype(np.int64) for (i, j), p in zip(ij, pm)}
         if callback is not None:
             callback(M, M)
         sym = cost_ij + cost_ij.T
         np.fill_diagonal(sym, np.inf)
         return found, csr_matrix(sym)
+
+    w, v = np.linalg.eigh(adj)                      # ascending eigenvalues
+    absv = np.abs(v[:, :, ::-1])                     # columns by decreasing eigenvalue
 
     cost_ij = np.zeros((M, M))
     found = {}

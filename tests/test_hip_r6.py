@@ -385,7 +385,8 @@ def test_device_matching_is_the_host_matching(ctx):
     matrix, solves the assignment problem (shortest augmenting paths, the algorithm behind scipy's linear_sum_assignment) and
     applies the reference's acceptance rule (perm.py:76-89).  Against the NumPy / SciPy form in sgdml_amd/utils/perm.py, which
     the CPU suite pins to the reference's output: the SAME pairs kept, the SAME assignments, pair costs to 1e-13 relative; and
-    find_perms with the device matching returns the reference's groups (tests/golden/perm_c3.npz) element for element."""
+    find_perms with the device matching returns the reference's groups (tests/golden/perm_c3.npz) element for element.  The
+    device side computes its own eigenvectors (sym_eig_kernel), the host side LAPACK's: same assignments."""
     from sgdml_amd.utils import perm
 
     kept_nontrivial = 0
@@ -406,6 +407,27 @@ def test_device_matching_is_the_host_matching(ctx):
     assert np.array_equal(perm.find_perms(g['R'], g['z'], ctx=ctx), g['perms'])
     assert np.array_equal(perm.find_perms(g['R2'], g['z2'], ctx=ctx), g['perms2'])
     assert np.array_equal(perm.find_perms(g['R2'], g['z2'], lat_and_inv=(lat, np.linalg.inv(lat)), ctx=ctx), g['perms3'])
+
+
+def test_device_eigenvectors_match_lapack(ctx):
+    """gdml_sym_eig_absv (batched cyclic Jacobi, one workgroup per matrix; what gdml_perm_match runs when it is handed no
+    eigenvectors -- the reference: numpy.linalg.eig per geometry, perm.py:183-187): |V| with columns by decreasing eigenvalue
+    against LAPACK's eigh for distance matrices of 1 ... 150 atoms -- both matrices in LDS (N <= 100), the rotations in device
+    memory (N = 101, 130), both there (N = 150); odd N (a padding index in the round-robin), N = 1 and 2.  Tolerance: 1e-9
+    absolute on unit vectors whose eigenvalue gaps are >= 1e-8 of the spectrum (measured 3e-11)."""
+    import bench
+    from sgdml_amd.utils import perm
+
+    for N, M in ((1, 3), (2, 3), (3, 5), (8, 40), (21, 100), (42, 40), (99, 6), (100, 6), (101, 4), (130, 3), (150, 2)):
+        R, _, _ = bench.synth_geometries(max(N, 2), M, seed=1)
+        adj = perm._dist_matrices(R.reshape(M, max(N, 2), 3)[:, :N])
+        w, v = np.linalg.eigh(adj)
+        ref = np.abs(v[:, :, ::-1])
+        got = ctx.sym_eig_absv(adj)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-9, (N, np.abs(got - ref).max())
+        # columns are unit vectors, mutually orthogonal in absolute value only by accident: check the norms
+        assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() <= 1e-12
 
 
 def test_device_matching_edge_sizes(ctx):
