@@ -353,7 +353,8 @@ class Iterative(object):
         12 s of iterations) where k = 64 takes 13 s; configs[2] 4.0 s at k = 162 against 2.5-2.7 s at k = 40-80
         (profiles/r06_k_sweep.txt, r06_train_flow.txt).  Model, seconds:
             T(k) = B k^2 + t_mv C / k,   B = 4.7 n (3N)^2 / 60 TFLOP/s   (two tall triangular solves + Gram passes of the build),
-            t_mv = 4e-13 M^2 D P^0.85    (the matrix-free mat-vec: 2.5 / 23 / 18 ms at configs[2] / [3] / [4]),
+            t_mv = 4e-13 M^2 D P^0.85    (one PCG iteration -- mat-vec + preconditioner pass: 2.5 / 23 / 18 ms at configs[2] / [3] / [4];
+                                          the mat-vec alone is 1.4 / 17 / 10 ms, profiles/r06_matvec_probe.txt),
             C = 35 000                   (iterations x k of the three configurations' sweeps: 20 000 - 50 000),
         minimised at k = (t_mv C / 2B)^(1/3), where the build costs half of what the iterations do.  A build predicted under
         one second is left at the memory rule (small systems: the reference's behaviour, exact preconditioners); a stagnating
