@@ -372,3 +372,27 @@ def test_cost_rule_for_the_number_of_inducing_points():
     assert I.cost_n_inducing_pts(2000, 42, 27, 350) > I.cost_n_inducing_pts(2000, 42, 1, 350)  # dearer mat-vec -> more points
     assert I.cost_n_inducing_pts(5000, 21, 1, 20) == 20         # never above the memory rule
     assert I.cost_n_inducing_pts(5000, 21, 1, 144, world=2) == k2  # build and mat-vec both shard: same optimum
+
+
+def test_chunked_host_helpers_keep_their_bits():
+    """Round 6: the distance matrices of the symmetry search and J v of create_model run in chunks of geometries (cache-sized
+    temporaries); same bits as the one-shot NumPy expressions they replace, with and without a lattice, ragged last chunk."""
+    from sgdml_amd.utils import perm
+    from sgdml_amd.utils.desc import Desc
+
+    rs = np.random.RandomState(5)
+    R = rs.normal(size=(70, 9, 3)) * 3
+    lat = np.diag([7.0, 8.0, 9.0]) + 0.3 * rs.normal(size=(3, 3))
+    for li in (None, (lat, np.linalg.inv(lat))):
+        diff = R[:, :, None, :] - R[:, None, :, :]
+        if li is not None:
+            diff = diff - np.einsum('ij,mabj->mabi', li[0], np.rint(np.einsum('ij,mabj->mabi', li[1], diff)))
+        assert np.array_equal(perm._dist_matrices(R, li), np.sqrt((diff**2).sum(-1)))
+        assert np.array_equal(perm._dist_matrices(R, li, chunk=7), perm._dist_matrices(R, li, chunk=1000))
+    d = Desc(9)
+    gd, a = rs.normal(size=(130, 36, 3)), rs.normal(size=(130, 27))
+    i, j = d.tril_indices
+    v = a.reshape(130, -1, 3)
+    assert np.array_equal(d.d_desc_dot_vec(gd, a), np.sum(gd * (v[:, j, :] - v[:, i, :]), axis=-1))
+    assert d.d_desc_dot_vec(gd[0], a[0]).shape == (1, 36)
+    assert np.array_equal(d.d_desc_dot_vec(gd[:1], a), np.sum(gd[:1] * (v[:, j, :] - v[:, i, :]), axis=-1))  # broadcast form
