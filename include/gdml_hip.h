@@ -128,6 +128,9 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   gemm.persist (0)      1: fused trailing updates of at least four rounds run as 2 resident workgroups per CU that pull tiles
  *                         from per-XCD counters (round 6; measured 1.5 % slower than one workgroup per tile: off)
  *   gemm.n64 (0)          1: trailing updates on 128 x 64 tiles with three workgroups per CU (A/B: profiles/r06_gemm_n64_ab.txt)
+ *   gemm.fill_tiles (0)   prediction contractions (D > 256): 128 x 64 tiles when they fill the chip better than 128 x 128 ones
+ *                         (measured slower on the launch it was meant for: profiles/r06_matvec_probe.txt)
+ *   predict.wide_pad (1)  the same contractions on tables / queries padded to whole tiles (no edge tiles); 0 = round 5's shapes
  *   gemm.trace (0)        k > 0: the k-th fused launch runs the traced instantiation and leaves gemm_trace.bin (tools/gemm_trace.py)
  *   gemm.nt_c (0)         non-temporal loads / stores of the C tile (after rocBLAS's Tensile kernel for this shape:
  *                         profiles/r03_vendor_kernels.txt; no gain measured)

@@ -616,7 +616,7 @@ static bool gemm_use_n64(gdml_ctx* ctx) { return ctx_opt_i(ctx, "gemm.n64", 0) !
 static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
                                    const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
                                    int64_t N, int64_t K, int lower, double f0, double f1, bool timed,
-                                   const DiagJob* diag = nullptr, const CyclicLower* cyc = nullptr) {
+                                   const DiagJob* diag = nullptr, const CyclicLower* cyc = nullptr, int tile_n64 = -1) {
   if (M <= 0 || N <= 0 || K <= 0) return GDML_OK;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -633,7 +633,7 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
               (lda % 2 == 0) && (ldb % 2 == 0);
   // gemm.n64: 128 x 64 tiles, three workgroups per CU (gemm_nt_sub_n64_kernel); super tiles stay 1024 x 1024
-  const bool n64 = gemm_use_n64(ctx) && !cyc && g.dbg == 0;
+  const bool n64 = (tile_n64 >= 0 ? tile_n64 != 0 : gemm_use_n64(ctx)) && !cyc && g.dbg == 0;
   const int TN = n64 ? G6N : GT, super_cols = n64 ? 16 : 8;
   g.tiles_m = (int)((M + GT - 1) / GT);
   g.tiles_n = (int)((N + TN - 1) / TN);
@@ -727,6 +727,22 @@ int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t l
                               const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
                               int64_t N, int64_t K, int lower) {
   return launch_gemm_nt_sub_part(ctx, st, A, lda, B, ldb, C, ldc, M, N, K, lower, 0.0, 1.0, true);
+}
+
+// Plain product whose tile shape is chosen by how well the tile count fills the chip: 128 x 128 tiles run two workgroups per CU
+// (512 slots), 128 x 64 tiles three (768 slots) at 0.93 of the wide tile's rate inside the k loop (profiles/r06_gemm_n64_ab.txt).
+// A launch of 1128 wide tiles (the configs[4] mat-vec: 6016 x 3072) is 2.2 rounds of 512 -- 0.73 full; as 2256 narrow tiles it
+// is 2.94 rounds of 768 -- 0.98 full.  Only for callers that ask (the prediction contractions), and OFF by default (option
+// gemm.fill_tiles): measured on exactly that launch the narrow tiles lose -- mat-vec 9.37 ms against 8.43 ms with wide tiles
+// (profiles/r06_matvec_probe.txt): the wide launch's third round is short, not a full round long.
+int launch_gemm_nt_sub_fill(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
+                            double* C, int64_t ldc, int64_t M, int64_t N, int64_t K) {
+  const int64_t slots = 2 * (int64_t)ctx->num_cus;
+  const int64_t t_w = (int64_t)ceil_div(M, GT) * ceil_div(N, GT), t_n = (int64_t)ceil_div(M, GT) * ceil_div(N, G6N);
+  const double fill_w = (double)t_w / (double)((int64_t)ceil_div(t_w, slots) * slots);
+  const double fill_n = 0.93 * (double)t_n / (double)((int64_t)ceil_div(t_n, slots * 3 / 2) * (slots * 3 / 2));
+  const int pick = ctx_opt_i(ctx, "gemm.fill_tiles", 0) != 0 && fill_n > fill_w ? 1 : 0;
+  return launch_gemm_nt_sub_part(ctx, st, A, lda, B, ldb, C, ldc, M, N, K, 0, 0.0, 1.0, true, nullptr, nullptr, pick);
 }
 
 int launch_gemm_nt_sub_cyclic(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,

@@ -298,37 +298,48 @@ int predict_wide_device(gdml_ctx* ctx, const double* d_xq, int64_t B, double* pa
   const int64_t MP = md.M * md.P;
   hipStream_t st = ctx->stream;
   // query chunk: two MP x Bc pair-scalar matrices below ~2 GB
-  int64_t Bc = (int64_t)(1.0e9 / (8.0 * (double)MP));
+  // Round 6 (option predict.wide_pad): table rows padded to a multiple of 64 (the stack [X; JA] is then whole 128-row tiles) and
+  // query chunks to a multiple of 128 with zero rows -- no edge tiles in the two contractions (their guarded path is 2-3 x
+  // slower per tile and used to be the launch's tail: configs[4] 6000 x 3000 had 70 of 1128)
+  const bool pad = ctx_opt_i(ctx, "predict.wide_pad", 1) != 0;
+  const int64_t MPp = pad ? (MP + 63) / 64 * 64 : MP;
+  int64_t Bc = (int64_t)(1.0e9 / (8.0 * (double)MPp));
   Bc = Bc / 128 * 128;
   if (Bc < 256) Bc = 256;
-  if (Bc > B) Bc = (B + 1) / 2 * 2;
+  if (Bc > B) Bc = pad ? (B + 127) / 128 * 128 : (B + 1) / 2 * 2;
   const int rows_per = 512;
   const int nparts = (int)((MP + rows_per - 1) / rows_per);
   const int Dp = (D + 15) / 16 * 16;
   double* w;
-  GDML_TRY(ctx_slot(ctx, 7, (2 * MP * Bc + 2 * MP + Bc + 2 * (int64_t)nparts * Bc + (2 * MP + Bc) * (int64_t)Dp) * 8, &w));
+  GDML_TRY(ctx_slot(ctx, 7, (2 * MPp * Bc + 2 * MP + Bc + 2 * (int64_t)nparts * Bc + (2 * MPp + Bc) * (int64_t)Dp) * 8, &w));
   double* S = w;
-  double* T = S + MP * Bc;
-  double* nX = T + MP * Bc;
+  double* T = S + MPp * Bc;
+  double* nX = T + MPp * Bc;
   double* cX = nX + MP;
   double* nx = cX + MP;
   double* pw = nx + Bc;
   double* pe = pw + (int64_t)nparts * Bc;
   double* Xpad = pe + (int64_t)nparts * Bc;
-  double* Jpad = Xpad + MP * Dp;
-  double* Qpad = Jpad + MP * Dp;
+  double* Jpad = Xpad + MPp * Dp;
+  double* Qpad = Jpad + MPp * Dp;
   hipLaunchKernelGGL(wide_row_stats_kernel, dim3(ceil_div(MP, 4)), dim3(256), 0, st, md.xp, md.jap, MP, D, nX, cX);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(ceil_div(MP * Dp, 256)), dim3(256), 0, st, md.xp, MP, D, Dp, Xpad);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(ceil_div(MP * Dp, 256)), dim3(256), 0, st, md.jap, MP, D, Dp, Jpad);
+  if (MPp > MP) {
+    HIP_CHECK(ctx, hipMemsetAsync(Xpad + MP * Dp, 0, (size_t)((MPp - MP) * Dp * 8), st));
+    HIP_CHECK(ctx, hipMemsetAsync(Jpad + MP * Dp, 0, (size_t)((MPp - MP) * Dp * 8), st));
+  }
   for (int64_t q0 = 0; q0 < B; q0 += Bc) {
     const int64_t bc = (B - q0 < Bc) ? B - q0 : Bc;
     const double* xq = d_xq + q0 * D;
-    HIP_CHECK(ctx, hipMemsetAsync(S, 0, 2 * MP * Bc * 8, st));
+    const int64_t bcp = pad ? (bc + 127) / 128 * 128 : bc;  // <= Bc
+    HIP_CHECK(ctx, hipMemsetAsync(S, 0, 2 * MPp * Bc * 8, st));
     hipLaunchKernelGGL(query_norm_kernel, dim3(ceil_div(bc, 4)), dim3(256), 0, st, xq, bc, D, nx);
     hipLaunchKernelGGL(pad_rows_kernel, dim3(ceil_div(bc * Dp, 256)), dim3(256), 0, st, xq, bc, D, Dp, Qpad);
+    if (bcp > bc) HIP_CHECK(ctx, hipMemsetAsync(Qpad + bc * Dp, 0, (size_t)((bcp - bc) * Dp * 8), st));
     // S = -X_p X_q^T, T = -JA_p X_q^T  (zero padding contributes nothing)
     // one launch for both: [Xpad; Jpad] and [S; T] are contiguous stacks of 2 MP rows
-    GDML_TRY(launch_gemm_nt_sub(ctx, st, Xpad, Dp, Qpad, Dp, S, Bc, 2 * MP, bc, Dp, 0));
+    GDML_TRY(launch_gemm_nt_sub_fill(ctx, st, Xpad, Dp, Qpad, Dp, S, Bc, 2 * MPp, bcp, Dp));
     hipLaunchKernelGGL(matern_pairs_kernel, dim3(ceil_div(bc, 256), nparts), dim3(256), 0, st, S, T, Bc, MP, bc, nx, nX, cX,
                        md.has_aE ? md.aE : nullptr, md.sig, rows_per, pw, pe);
     double* Fx = part_F + q0 * D;
@@ -336,7 +347,7 @@ int predict_wide_device(gdml_ctx* ctx, const double* d_xq, int64_t B, double* pa
     // F_x -= W1^T X_p + B2^T JA_p as ONE contraction over the 2 MP stacked rows ([S; T] and [Xpad; Jpad] are contiguous),
     // split over the table rows so that the launch fills the chip
     {
-      const int64_t tiles = (int64_t)ceil_div(D, WT) * ceil_div(bc, WT), nt = (2 * MP + WBK - 1) / WBK;
+      const int64_t tiles = (int64_t)ceil_div(D, WT) * ceil_div(bc, WT), nt = (2 * MPp + WBK - 1) / WBK;
       int nz = (int)((3 * 512 + tiles - 1) / tiles);
       if (nz > 32) nz = 32;
       if ((int64_t)nz * 64 > nt) nz = (int)(nt / 64);  // at least 64 k-tiles per split
@@ -344,7 +355,7 @@ int predict_wide_device(gdml_ctx* ctx, const double* d_xq, int64_t B, double* pa
       double* Pp;
       GDML_TRY(ctx_slot(ctx, 9, (int64_t)nz * bc * D * 8, &Pp));
       dim3 grid((unsigned)ceil_div(D, WT), (unsigned)ceil_div(bc, WT), (unsigned)nz);
-      hipLaunchKernelGGL(gemm_tn_split_kernel, grid, dim3(256), 0, st, S, Bc, Xpad, (int64_t)Dp, (int64_t)Dp, Pp, bc, (int64_t)D, 2 * MP);
+      hipLaunchKernelGGL(gemm_tn_split_kernel, grid, dim3(256), 0, st, S, Bc, Xpad, (int64_t)Dp, (int64_t)Dp, Pp, bc, (int64_t)D, 2 * MPp);
       hipLaunchKernelGGL(reduce_tn_kernel, dim3(ceil_div(bc * D, 256)), dim3(256), 0, st, Pp, bc * D, nz, Fx);
     }
     ctx->launch_counter += 7;
