@@ -219,6 +219,8 @@ def assemble_K(
     tril_perms = tril_perms_from_lin(tril_perms_lin, D)
     K = _full_K(R_desc, R_d_desc, tril_perms, sig, use_E_cstr)
     n_rows = K.shape[0]
+    if isinstance(col_idxs, slice) and col_idxs == slice(None) and alloc_extra_rows == 0:
+        return K  # every column, nothing appended: no gather copy (it was a sixth of the slowest CPU test)
     if isinstance(col_idxs, slice):
         cols = np.arange(n_rows)[col_idxs]
     else:
