@@ -150,8 +150,9 @@ __device__ __forceinline__ void gemm_tn_tile(const double* __restrict__ A, int64
     }
 }
 
-// b_cols: columns of B that may be READ (its rows are padded to that many doubles; >= n)
-__global__ void __launch_bounds__(256, 2) gemm_tn_split_kernel(const double* __restrict__ A, int64_t lda,
+// a_cols, b_cols: columns of A / B that may be READ without checks (>= m, n: memory that exists behind the operands' used
+// columns; what is read there only reaches output entries that are not stored)
+__global__ void __launch_bounds__(256, 2) gemm_tn_split_kernel(const double* __restrict__ A, int64_t lda, int64_t a_cols,
                                                                const double* __restrict__ B, int64_t ldb, int64_t b_cols,
                                                                double* __restrict__ P, int64_t m, int64_t n, int64_t nk) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][WBK * WT];
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_split_kernel(const double* __r
   double* Pz = P + (int64_t)blockIdx.z * m * n;
   const bool aligned = (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0) && (lda % 2 == 0) &&
                        (ldb % 2 == 0) && 16 * lda * 8 < ((int64_t)1 << 32) && 16 * ldb * 8 < ((int64_t)1 << 32);
-  if (aligned && row0 + WT <= m && col0 + WT <= b_cols)
+  if (aligned && row0 + WT <= a_cols && col0 + WT <= b_cols)
     gemm_tn_tile<true>(A, lda, B, ldb, Pz, m, n, nk, kt0, kt1, row0, col0, lds);
   else
     gemm_tn_tile<false>(A, lda, B, ldb, Pz, m, n, nk, kt0, kt1, row0, col0, lds);
@@ -355,7 +356,11 @@ int predict_wide_device(gdml_ctx* ctx, const double* d_xq, int64_t B, double* pa
       double* Pp;
       GDML_TRY(ctx_slot(ctx, 9, (int64_t)nz * bc * D * 8, &Pp));
       dim3 grid((unsigned)ceil_div(D, WT), (unsigned)ceil_div(bc, WT), (unsigned)nz);
-      hipLaunchKernelGGL(gemm_tn_split_kernel, grid, dim3(256), 0, st, S, Bc, Xpad, (int64_t)Dp, (int64_t)Dp, Pp, bc, (int64_t)D, 2 * MPp);
+      // unchecked loads wherever memory exists: S / T have Bc columns (a multiple of 128 when padded: zeros past bc), and a
+      // table row's columns past Dp are the next row's (the last row's: the query block behind the tables) -- they only feed
+      // output columns >= D, which are not stored.  Before: 14 % (configs[3]) of the tiles took the checked path
+      const int64_t a_cols = pad ? Bc : bc, b_cols = pad ? ((int64_t)D + WT - 1) / WT * WT : (int64_t)Dp;
+      hipLaunchKernelGGL(gemm_tn_split_kernel, grid, dim3(256), 0, st, S, Bc, a_cols, Xpad, (int64_t)Dp, b_cols, Pp, bc, (int64_t)D, 2 * MPp);
       hipLaunchKernelGGL(reduce_tn_kernel, dim3(ceil_div(bc * D, 256)), dim3(256), 0, st, Pp, bc * D, nz, Fx);
     }
     ctx->launch_counter += 7;
