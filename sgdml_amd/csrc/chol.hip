@@ -184,6 +184,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   // C -= A B^T as acc = C; acc += (-A) B^T; C = acc for interior tiles: the 64 C loads per lane are issued with the first
   // operand tiles (their latency is paid once, together with the prologue's), the epilogue is stores only -- instead of
   // four load->store round trips after the last MFMA.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 r.
+  constexpr bool OW = (FLAGS & 4) != 0;  // overwrite: C = -A B^T (C is not read: the caller need not clear it)
   constexpr bool CIN = FULL && !ABL && CACC;
   constexpr double SGN = PIPE ? -1.0 : 1.0;  // 16-byte layout: the accumulator holds -C + A B^T
   double* Cw = g.C + (row0 + wm * 64 + lk) * g.ldc + col0 + wn * 64 + li;
@@ -196,7 +197,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (CIN) {
+      if (CIN && !OW) {
         if (g.nt_c) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[i][j][r] = SGN * __builtin_nontemporal_load((Ct + (int64_t)(i * 16 + 4 * r) * g.ldc) + coff + j * 16);
@@ -479,6 +480,20 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, double (*lds)[
     trace_out();
     return;
   }
+  if constexpr (OW) {  // edge tile of an overwriting product: guarded stores, nothing read
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t gc = col0 + wn * 64 + j * 16 + li;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gr = row0 + wm * 64 + i * 16 + lk + 4 * r;
+          if (gc < g.N && gr < g.M) g.C[gr * g.ldc + gc] = SGN * acc[i][j][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     double cv[4][4];
@@ -577,7 +592,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, double (*lds)[2][G
   if (full)
     gemm_tile_body<true, ABL, PIPE, CACC, CKS, FLAGS>(g, lds, row0, col0, b_launch, s_next);
   else
-    gemm_tile_body<false, ABL, PIPE, CACC, CKS, (FLAGS & 2)>(g, lds, row0, col0);
+    gemm_tile_body<false, ABL, PIPE, CACC, CKS, (FLAGS & 6)>(g, lds, row0, col0);
   if (g.ready && g.tiles2 == 0 && ti < g.ready_rows && tj < g.ready_rows) {  // publish the tile (release: every thread's stores, then one count)
     __threadfence();
     __syncthreads();
@@ -593,6 +608,13 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sub_kernel(GemmArgs g) {
   gemm_block<ABL, !ABL, true, ABL ? GEMM_COMMIT_KS : 5>(g, lds, blockIdx.x);
 }
 
+
+// C = -A B^T: the production loop with the accumulators starting at zero and the epilogue's stores only -- for callers whose C
+// is a fresh work buffer (the prediction contractions cleared 1.8 GB per mat-vec at configs[3] only to have it read back)
+__global__ void __launch_bounds__(256, 2) gemm_nt_neg_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][GT * GPITCH];
+  gemm_block<false, true, true, 5, 4>(g, lds, blockIdx.x);
+}
 
 // f0, f1: the launch covers the super tiles [f0 * n_super, f1 * n_super) (whole update: 0, 1);
 // timed: bracket with the per-kernel timers (only launches on the timing stream)
@@ -616,7 +638,8 @@ static bool gemm_use_n64(gdml_ctx* ctx) { return ctx_opt_i(ctx, "gemm.n64", 0) !
 static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda,
                                    const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M,
                                    int64_t N, int64_t K, int lower, double f0, double f1, bool timed,
-                                   const DiagJob* diag = nullptr, const CyclicLower* cyc = nullptr, int tile_n64 = -1) {
+                                   const DiagJob* diag = nullptr, const CyclicLower* cyc = nullptr, int tile_n64 = -1,
+                                   bool overwrite = false) {
   if (M <= 0 || N <= 0 || K <= 0) return GDML_OK;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -633,7 +656,7 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
   g.aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
               (lda % 2 == 0) && (ldb % 2 == 0);
   // gemm.n64: 128 x 64 tiles, three workgroups per CU (gemm_nt_sub_n64_kernel); super tiles stay 1024 x 1024
-  const bool n64 = (tile_n64 >= 0 ? tile_n64 != 0 : gemm_use_n64(ctx)) && !cyc && g.dbg == 0;
+  const bool n64 = (tile_n64 >= 0 ? tile_n64 != 0 : gemm_use_n64(ctx)) && !cyc && g.dbg == 0 && !overwrite;
   const int TN = n64 ? G6N : GT, super_cols = n64 ? 16 : 8;
   g.tiles_m = (int)((M + GT - 1) / GT);
   g.tiles_n = (int)((N + TN - 1) / TN);
@@ -707,7 +730,9 @@ static int launch_gemm_nt_sub_part(gdml_ctx* ctx, hipStream_t st, const double* 
     if (ctx_opt_i(ctx, "gemm.lds16", 3) == 2) hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 4>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_nt_sub_diag_kernel<true, true, 5>), grid, dim3(256), 0, st, g);
     }
-  } else if (n64)
+  } else if (overwrite)
+    hipLaunchKernelGGL(gemm_nt_neg_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+  else if (n64)
     hipLaunchKernelGGL(gemm_nt_sub_n64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
   else if (g.dbg)
     hipLaunchKernelGGL(gemm_nt_sub_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
@@ -735,6 +760,11 @@ int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t l
 // is 2.94 rounds of 768 -- 0.98 full.  Only for callers that ask (the prediction contractions), and OFF by default (option
 // gemm.fill_tiles): measured on exactly that launch the narrow tiles lose -- mat-vec 9.37 ms against 8.43 ms with wide tiles
 // (profiles/r06_matvec_probe.txt): the wide launch's third round is short, not a full round long.
+int launch_gemm_nt_neg(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
+                       double* C, int64_t ldc, int64_t M, int64_t N, int64_t K) {  // C = -A B^T, C not read
+  return launch_gemm_nt_sub_part(ctx, st, A, lda, B, ldb, C, ldc, M, N, K, 0, 0.0, 1.0, true, nullptr, nullptr, 0, true);
+}
+
 int launch_gemm_nt_sub_fill(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                             double* C, int64_t ldc, int64_t M, int64_t N, int64_t K) {
   const int64_t slots = 2 * (int64_t)ctx->num_cus;

@@ -244,6 +244,8 @@ int chol_solve_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, dou
 int operator_model_from_trainset(gdml_ctx* ctx, double sig);
 int launch_gemm_nt_sub(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B,
                        int64_t ldb, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int lower);
+int launch_gemm_nt_neg(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
+                       double* C, int64_t ldc, int64_t M, int64_t N, int64_t K);  // C = -A B^T (C is not read)
 int launch_gemm_nt_sub_fill(gdml_ctx* ctx, hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                             double* C, int64_t ldc, int64_t M, int64_t N, int64_t K);  // tile shape by chip fill
 // lower structure of a block-row-cyclic local matrix (see GemmArgs in chol.hip)

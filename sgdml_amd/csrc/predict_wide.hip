@@ -334,13 +334,16 @@ int predict_wide_device(gdml_ctx* ctx, const double* d_xq, int64_t B, double* pa
     const int64_t bc = (B - q0 < Bc) ? B - q0 : Bc;
     const double* xq = d_xq + q0 * D;
     const int64_t bcp = pad ? (bc + 127) / 128 * 128 : bc;  // <= Bc
-    HIP_CHECK(ctx, hipMemsetAsync(S, 0, 2 * MPp * Bc * 8, st));
+    // (padded: the first contraction OVERWRITES its whole 2 MPp x bcp block -- no clearing, and the product does not read S back;
+    //  configs[3] cleared and re-read 1.8 GB per mat-vec)
+    if (!pad) HIP_CHECK(ctx, hipMemsetAsync(S, 0, 2 * MPp * Bc * 8, st));
     hipLaunchKernelGGL(query_norm_kernel, dim3(ceil_div(bc, 4)), dim3(256), 0, st, xq, bc, D, nx);
     hipLaunchKernelGGL(pad_rows_kernel, dim3(ceil_div(bc * Dp, 256)), dim3(256), 0, st, xq, bc, D, Dp, Qpad);
     if (bcp > bc) HIP_CHECK(ctx, hipMemsetAsync(Qpad + bc * Dp, 0, (size_t)((bcp - bc) * Dp * 8), st));
     // S = -X_p X_q^T, T = -JA_p X_q^T  (zero padding contributes nothing)
     // one launch for both: [Xpad; Jpad] and [S; T] are contiguous stacks of 2 MP rows
-    GDML_TRY(launch_gemm_nt_sub_fill(ctx, st, Xpad, Dp, Qpad, Dp, S, Bc, 2 * MPp, bcp, Dp));
+    if (pad) GDML_TRY(launch_gemm_nt_neg(ctx, st, Xpad, Dp, Qpad, Dp, S, Bc, 2 * MPp, bcp, Dp));
+    else GDML_TRY(launch_gemm_nt_sub_fill(ctx, st, Xpad, Dp, Qpad, Dp, S, Bc, 2 * MPp, bcp, Dp));
     hipLaunchKernelGGL(matern_pairs_kernel, dim3(ceil_div(bc, 256), nparts), dim3(256), 0, st, S, T, Bc, MP, bc, nx, nX, cX,
                        md.has_aE ? md.aE : nullptr, md.sig, rows_per, pw, pe);
     double* Fx = part_F + q0 * D;
@@ -359,7 +362,7 @@ int predict_wide_device(gdml_ctx* ctx, const double* d_xq, int64_t B, double* pa
       // unchecked loads wherever memory exists: S / T have Bc columns (a multiple of 128 when padded: zeros past bc), and a
       // table row's columns past Dp are the next row's (the last row's: the query block behind the tables) -- they only feed
       // output columns >= D, which are not stored.  Before: 14 % (configs[3]) of the tiles took the checked path
-      const int64_t a_cols = pad ? Bc : bc, b_cols = pad ? ((int64_t)D + WT - 1) / WT * WT : (int64_t)Dp;
+      const int64_t a_cols = pad ? bcp : bc, b_cols = pad ? ((int64_t)D + WT - 1) / WT * WT : (int64_t)Dp;
       hipLaunchKernelGGL(gemm_tn_split_kernel, grid, dim3(256), 0, st, S, Bc, a_cols, Xpad, (int64_t)Dp, b_cols, Pp, bc, (int64_t)D, 2 * MPp);
       hipLaunchKernelGGL(reduce_tn_kernel, dim3(ceil_div(bc * D, 256)), dim3(256), 0, st, Pp, bc * D, nz, Fx);
     }

@@ -484,3 +484,42 @@ def test_create_task_discovers_the_group_on_the_device():
         assert tr._context().phase_ms('perm_match')[1] >= 1  # the device kernel ran
     finally:
         tr.__del__()
+
+
+def test_wide_contractions_on_padded_tables_and_query_chunks(ctx):
+    """Round 6, csrc/predict_wide.hip (D > 256): tables padded to a multiple of 64 rows, query chunks to a multiple of 128, the
+    first contraction overwriting its block (gemm_nt_neg_kernel: nothing cleared, nothing read back), the back contraction loading
+    unchecked behind the used columns.  (a) against round 5's shapes (predict.wide_pad = 0) at sizes where nothing is a multiple
+    of anything -- M P = 27 x 31 = 837 rows, D = 861, 333 queries; (b) a batch that needs TWO query chunks (M P = 54 000 table
+    rows: chunks of 2 304, the second one 696 = 5.4 tiles) against the same queries in single-chunk calls; (c) both against the
+    oracle on a few queries."""
+    import bench
+    from sgdml_amd.utils.desc import Desc
+
+    N = 42
+    perms = bench.perm_group(N, 'c3x3')
+    tril = np.array([Desc.perm(p_) for p_ in perms])
+    rs = np.random.RandomState(11)
+    for M, B in ((31, 333), (2000, 3000)):
+        R, _, _ = bench.synth_trajectory(N, M, seed=3, n_modes=8, amp=0.15, noise=0.01)
+        xd, gd = ctx.desc_from_R(R.reshape(M, -1), N)
+        alphas = rs.normal(size=(M, 3 * N))
+        JA = Desc(N).d_desc_dot_vec(gd, alphas)
+        ctx.predict_upload_model(xd, JA, tril, 60.0, None)
+        Rq = R.reshape(M, -1)[rs.randint(0, M, size=B)] + 0.02 * rs.normal(size=(B, 3 * N))
+        E1, F1 = ctx.predict(Rq, None)
+        if M == 31:
+            ctx.set_option('predict.wide_pad', 0)
+            try:
+                E0, F0 = ctx.predict(Rq, None)
+            finally:
+                ctx.set_option('predict.wide_pad', 1)
+            assert np.abs(F1 - F0).max() <= 1e-12 * np.abs(F0).max() and np.abs(E1 - E0).max() <= 1e-12 * np.abs(E0).max()
+            xq, gq = orc.desc_from_R(Rq[:4])
+            Eo, Fo = orc.predict_from_desc(xq, gq, xd, JA, tril, 60.0)
+            assert np.abs(F1[:4] - Fo).max() <= 1e-10 * np.abs(Fo).max() and np.abs(E1[:4] - Eo).max() <= 1e-10 * np.abs(Eo).max()
+        else:
+            for lo in (0, 1000, 2000):  # one chunk each
+                Es, Fs = ctx.predict(Rq[lo:lo + 1000], None)
+                assert np.abs(F1[lo:lo + 1000] - Fs).max() <= 1e-12 * np.abs(F1).max()
+                assert np.abs(E1[lo:lo + 1000] - Es).max() <= 1e-12 * np.abs(E1).max()
