@@ -131,6 +131,7 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   gemm.fill_tiles (0)   prediction contractions (D > 256): 128 x 64 tiles when they fill the chip better than 128 x 128 ones
  *                         (measured slower on the launch it was meant for: profiles/r06_matvec_probe.txt)
  *   predict.wide_pad (1)  the same contractions on tables / queries padded to whole tiles (no edge tiles); 0 = round 5's shapes
+ *   nys.trsm_left (1)     tall triangular solves of the Nystroem build left-looking (one deep product per 512-column strip); 0 = right-looking
  *   gemm.trace (0)        k > 0: the k-th fused launch runs the traced instantiation and leaves gemm_trace.bin (tools/gemm_trace.py)
  *   gemm.nt_c (0)         non-temporal loads / stores of the C tile (after rocBLAS's Tensile kernel for this shape:
  *                         profiles/r03_vendor_kernels.txt; no gain measured)
@@ -364,8 +365,9 @@ int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world);
 int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out);
 /* gdml_comm_suspend(ctx, 1) parks the communicator: until gdml_comm_suspend(ctx, 0) the context behaves like a single GPU
  * without one (rank 0 of 1: unsharded assembly, local Cholesky / LU / PCG, no collective).  For work every rank performs
- * redundantly on its own GPU because the sharded solvers do not carry it: energy constraints (train.py:235-300) and the LU
- * branch of a matrix that is not positive definite (analytic.py:101-114). */
+ * redundantly on its own GPU because the sharded solvers do not carry it: energy constraints (train.py:235-300) in the
+ * iterative solver (the distributed Cholesky carries them) and the LU branch of a matrix that is not positive definite
+ * (analytic.py:101-114). */
 int gdml_comm_suspend(gdml_ctx* ctx, int suspend);
 
 /* Distributed analytic solve (new; Analytic.solve, analytic.py:65-99, for systems beyond one GPU -- BASELINE.json
@@ -373,8 +375,9 @@ int gdml_comm_suspend(gdml_ctx* ctx, int suspend);
  * (512-row blocks, every rank only its own rows: n^2 * 8 / world bytes per GPU), factored by a right-looking blocked
  * Cholesky (diagonal block broadcast, row-local panel solve, panel all-gather over RCCL, local fp64-MFMA trailing
  * update) with the right-hand side carried as a replicated extra row, and solved back; every rank receives
- * alphas = -(A^-1 y).  Needs gdml_train_upload (any P; no energy constraints) and a communicator (gdml_comm_init /
- * gdml_comm_init_host; without one it runs on a single GPU).  *info as gdml_chol_factor. */
+ * alphas = -(A^-1 y).  n = 3N M, or 3N M + M for a system with energy constraints (train.py:235-300: y then carries the M
+ * energy labels behind the forces, the energy rows are assembled on the ranks that own them).  Needs gdml_train_upload (any P)
+ * and a communicator (gdml_comm_init / gdml_comm_init_host; without one it runs on a single GPU).  *info as gdml_chol_factor. */
 int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const double* y, int64_t n, double* alphas_out,
                          int* info);
 

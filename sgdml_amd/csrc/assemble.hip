@@ -48,7 +48,22 @@ struct EColArgs {
   double* K;
   int64_t ld;
   int64_t i0;               // first row point of this launch
+  // row mode (distributed Cholesky with energy constraints, assemble_erows_cyclic_launch): the same values written as ROW
+  // out_cols[.] of A = -K + lam I -- K is symmetric (train.py:235-248 and :281-296 are one formula with the roles of the two
+  // points exchanged), the factorisation reads rows, and a rank of the block-row-cyclic layout stores only its own
+  int row_mode;
+  double lam;
 };
+
+// where the value of (row point i, component t) / the energy-energy value of row point i goes
+__device__ __forceinline__ void ecol_store(const EColArgs& A, int64_t i, int t, int64_t col, double v) {
+  if (A.row_mode) A.K[col * A.ld + i * (3 * A.N) + t] = -v;
+  else A.K[(i * (3 * A.N) + t) * A.ld + col] = v;
+}
+__device__ __forceinline__ void ecol_store_ee(const EColArgs& A, int64_t i, int64_t jj, int64_t col, double v) {
+  if (A.row_mode) A.K[col * A.ld + A.M * (3 * A.N) + i] = (i == jj) ? A.lam - v : -v;
+  else A.K[(A.M * (3 * A.N) + i) * A.ld + col] = v;
+}
 
 __global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -103,9 +118,9 @@ __global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
     }
     ee -= (1.0 + (nrm * inv_sig) * (1.0 + nrm / (3.0 * sig))) * ex;
   }
-  if (tid < N3) A.K[(i * N3 + tid) * A.ld + col] = out0;
-  if (tid + T < N3) A.K[(i * N3 + tid + T) * A.ld + col] = out1;
-  if (tid == 0) A.K[(A.M * N3 + i) * A.ld + col] = ee;
+  if (tid < N3) ecol_store(A, i, tid, col, out0);
+  if (tid + T < N3) ecol_store(A, i, tid + T, col, out1);
+  if (tid == 0) ecol_store_ee(A, i, jj, col, ee);
 }
 
 // The same columns for molecules beyond the kernel above (3N > 512, or descriptors that do not fit its LDS tables): nothing
@@ -158,9 +173,71 @@ __global__ void __launch_bounds__(256) ecol_big_kernel(EColArgs A) {
       }
       out -= wS[p] * s;
     }
-    A.K[(i * N3 + t) * A.ld + col] = out;
+    ecol_store(A, i, t, col, out);
   }
-  if (tid == 0) A.K[(A.M * N3 + i) * A.ld + col] = ee;
+  if (tid == 0) ecol_store_ee(A, i, jj, col, ee);
+}
+
+// Launch of the energy-constraint kernels: n_e requested points (d_ep) with their output columns -- or, in row mode, output
+// rows -- (d_ec), all M partner points.
+static int ecol_launch(gdml_ctx* ctx, double sig, const int32_t* d_ep, const int32_t* d_ec, int64_t n_e, double* K, int64_t ld,
+                       int row_mode, double lam) {
+  TrainSet& ts = ctx->ts;
+  const int64_t M = ts.M;
+  const int N = ts.N, N3 = 3 * N;
+  EColArgs E;
+  E.x = ts.x; E.g = ts.g; E.tp = ts.tp; E.perm = ts.perm; E.pinv = ts.pinv;
+  E.M = M; E.N = N; E.D = ts.D; E.P = ts.P; E.sig = sig;
+  E.jj_list = d_ep; E.out_cols = d_ec; E.K = K; E.ld = ld;
+  E.row_mode = row_mode; E.lam = lam;
+  // two outputs per thread and the descriptor tables in LDS, or (large molecules) the table-free kernel
+  const bool small = N3 <= 512 && (size_t)(2 * ts.D + 32) * 8 <= (size_t)160 * 1024;
+  const size_t lds = small ? (size_t)(2 * ts.D + 32) * 8 : (size_t)(ts.P + 32) * 8;
+  if (small) hipFuncSetAttribute((const void*)ecol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  else hipFuncSetAttribute((const void*)ecol_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int64_t i0 = 0; i0 < M; i0 += 65535) {  // grid.y limit
+    E.i0 = i0;
+    const int64_t ny = (M - i0 < 65535) ? M - i0 : 65535;
+    const dim3 grid((unsigned)n_e, (unsigned)ny);
+    if (small) hipLaunchKernelGGL(ecol_kernel, grid, dim3(256), lds, ctx->stream, E);
+    else hipLaunchKernelGGL(ecol_big_kernel, grid, dim3(256), lds, ctx->stream, E);
+    ctx->launch_counter++;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return gdml_fail(ctx, GDML_ERR_HIP, "ecol launch: %s", hipGetErrorString(e));
+  return GDML_OK;
+}
+
+// Energy-constraint ROWS of A = -K + lam I owned by this rank in the block-row-cyclic layout (global rows 3N M + e, e < M):
+// force columns in full, energy columns with the regularised diagonal.  The reference assembles them as rows AND columns
+// (train.py:235-248, :250-300); the distributed Cholesky reads the lower triangle, so the rows are all it needs.
+int assemble_erows_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int64_t ld, int cyc_W, int cyc_rank,
+                                 int cyc_nb) {
+  TrainSet& ts = ctx->ts;
+  const int64_t n_ff = ts.M * 3 * (int64_t)ts.N;
+  const int W = cyc_W > 0 ? cyc_W : 1;
+  std::vector<int32_t> e_pts, e_rows;
+  for (int64_t e = 0; e < ts.M; ++e) {
+    const int64_t g = n_ff + e, b = g / cyc_nb;
+    if ((int)(b % W) != cyc_rank) continue;
+    e_pts.push_back((int32_t)e);
+    e_rows.push_back((int32_t)((b / W) * cyc_nb + g % cyc_nb));
+  }
+  if (e_pts.empty()) return GDML_OK;
+  int32_t *d_ep = nullptr, *d_er = nullptr;
+  GDML_TRY(ctx_alloc(ctx, (void**)&d_ep, e_pts.size() * 4));
+  int rc = ctx_alloc(ctx, (void**)&d_er, e_rows.size() * 4);
+  if (rc == GDML_OK) {
+    hipError_t h = hipMemcpyAsync(d_ep, e_pts.data(), e_pts.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (h == hipSuccess) h = hipMemcpyAsync(d_er, e_rows.data(), e_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (h == hipSuccess) h = hipStreamSynchronize(ctx->stream);  // the host vectors leave scope
+    if (h != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "assemble_erows_cyclic: %s", hipGetErrorString(h));
+  }
+  if (rc == GDML_OK) rc = ecol_launch(ctx, sig, d_ep, d_er, (int64_t)e_pts.size(), K, ld, 1, lam);
+  if (rc == GDML_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "assemble_erows_cyclic: sync");
+  if (d_ep) ctx_free(ctx, d_ep);
+  if (d_er) ctx_free(ctx, d_er);
+  return rc;
 }
 
 // Rows of A = -K + lam I owned by this rank in the block-row-cyclic layout of the distributed Cholesky (any P,
@@ -330,25 +407,7 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
                                 dense ? nullptr : colmap.data());
   }
   if (rc == GDML_OK && !e_pts.empty()) {
-    EColArgs E;
-    E.x = ts.x; E.g = ts.g; E.tp = ts.tp; E.perm = ts.perm; E.pinv = ts.pinv;
-    E.M = M; E.N = N; E.D = ts.D; E.P = ts.P; E.sig = sig;
-    E.jj_list = d_ep; E.out_cols = d_ec; E.K = ctx->K; E.ld = ld;
-    // two outputs per thread and the descriptor tables in LDS, or (large molecules) the table-free kernel
-    const bool small = N3 <= 512 && (size_t)(2 * ts.D + 32) * 8 <= (size_t)160 * 1024;
-    const size_t lds = small ? (size_t)(2 * ts.D + 32) * 8 : (size_t)(ts.P + 32) * 8;
-    if (small) hipFuncSetAttribute((const void*)ecol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else hipFuncSetAttribute((const void*)ecol_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int64_t i0 = 0; i0 < M; i0 += 65535) {  // grid.y limit
-      E.i0 = i0;
-      const int64_t ny = (M - i0 < 65535) ? M - i0 : 65535;
-      const dim3 grid((unsigned)e_pts.size(), (unsigned)ny);
-      if (small) hipLaunchKernelGGL(ecol_kernel, grid, dim3(256), lds, ctx->stream, E);
-      else hipLaunchKernelGGL(ecol_big_kernel, grid, dim3(256), lds, ctx->stream, E);
-      ctx->launch_counter++;
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "ecol launch: %s", hipGetErrorString(e));
+    rc = ecol_launch(ctx, sig, d_ep, d_ec, (int64_t)e_pts.size(), ctx->K, ld, 0, 0.0);
   }
   if (rc == GDML_OK) rc = phase_end(ctx, "assemble");
   if (d_jlist) ctx_free(ctx, d_jlist);

@@ -627,11 +627,18 @@ __global__ void __launch_bounds__(256) vec_axpy_kernel(double* __restrict__ y, c
 }
 
 // X[:, 0:m] <- X L^-T  for the n rows of X (L: m x m lower), blocked 512 / 64 like the Cholesky.
+// Round 6: LEFT-looking (option nys.trsm_left, default 1): a 512-column strip receives everything the solved strips to its left
+// owe it in ONE product of depth k0 and is then solved, instead of being read, updated by 512 and written back once per earlier
+// strip -- m / 1024 times less traffic on X and long k loops (the K = 512 update ran at 0.55 of the MFMA peak inside the
+// configs[3] build, profiles/r06_cfg34_kernel_stats.txt).  Same flops, same operations in another order.
 static int tall_trsm(gdml_ctx* ctx, const double* L, double* X, int64_t n, int64_t m, int64_t ld) {
   const int64_t NB = 512;
   hipStream_t st = ctx->stream;
+  const bool left = ctx_opt_i(ctx, "nys.trsm_left", 1) != 0;
   for (int64_t k0 = 0; k0 < m; k0 += NB) {
     const int64_t nb = (m - k0 < NB) ? m - k0 : NB;
+    if (left && k0 > 0)  // X[:, k0:k0+nb] -= X[:, 0:k0] L[k0:k0+nb, 0:k0]^T
+      GDML_TRY(launch_gemm_nt_sub(ctx, st, X, ld, L + k0 * ld, ld, X + k0, ld, n, nb, k0, 0));
     const bool aligned = ((reinterpret_cast<uintptr_t>(L) | reinterpret_cast<uintptr_t>(X)) & 31) == 0 && (ld % 4 == 0);
     if (nb % 64 == 0 && aligned && ctx_opt_i(ctx, "chol.panel_kernel", 1)) {
       // whole NB-wide strip in one row-local launch (the kernel of the Cholesky panels) instead of 8 x (trsm64 + K = 64 GEMM)
@@ -647,7 +654,7 @@ static int tall_trsm(gdml_ctx* ctx, const double* L, double* X, int64_t n, int64
                                     ncols, w, 0));
     }
     const int64_t t0 = k0 + nb;
-    if (t0 < m)
+    if (!left && t0 < m)
       GDML_TRY(launch_gemm_nt_sub(ctx, st, X + k0, ld, L + t0 * ld + k0, ld, X + t0, ld, n, m - t0, nb, 0));
   }
   return GDML_OK;

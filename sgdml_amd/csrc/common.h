@@ -277,6 +277,8 @@ static inline bool comm_active(const gdml_ctx* ctx) { return (ctx->comm || ctx->
 bool assemble_wave_applicable(const gdml_ctx* ctx);
 bool assemble_strip_applicable(const gdml_ctx* ctx);
 int assemble_strip_launch(gdml_ctx* ctx, double sig, double* K, int64_t ld, int lower, double lam);
+int assemble_erows_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int64_t ld, int cyc_W, int cyc_rank,
+                                 int cyc_nb);
 int assemble_cyclic_launch(gdml_ctx* ctx, double sig, double lam, double* K, int64_t ld, int cyc_W, int cyc_rank,
                            int cyc_nb);
 bool assemble_perm2_applicable(const gdml_ctx* ctx);

@@ -117,14 +117,20 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
   if (!ts.x) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_dist_chol_solve: call gdml_train_upload first");
   if (ctx->virtual_rank) return gdml_fail(ctx, GDML_ERR_STATE, "gdml_dist_chol_solve needs a real communicator");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  const int64_t N3 = 3 * (int64_t)ts.N, n = ts.M * N3;
-  if (n_in != n) return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_dist_chol_solve: n mismatch");
+  // Energy constraints (train.py:235-300, round 6): y carries the M energy labels behind the forces, the system has M more
+  // rows / columns.  The force rows keep their place in the block-row-cyclic layout (it is defined by the global row index),
+  // the energy rows 3N M + e follow in the last row blocks and are assembled by assemble_erows_cyclic_launch on their owners.
+  const int64_t N3 = 3 * (int64_t)ts.N, n_ff = ts.M * N3;
+  const bool use_E = n_in == n_ff + ts.M;
+  const int64_t n = n_ff + (use_E ? ts.M : 0);
+  if (n_in != n)
+    return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_dist_chol_solve: y must hold 3N M values, or 3N M + M with energy constraints");
   if ((ctx->world <= 1) && ctx_opt_i(ctx, "dist.force_panels", 0) == 0) {
     // One rank: the block-row-cyclic layout IS the plain layout and no collective moves data, so the single-GPU schedule
     // applies as it stands -- K = 1024 trailing updates with the diagonal block factored inside them (chol.hip) instead of
     // this file's K = 512 panels (1.39-1.53 s against 1.27 s at n = 63 000, profiles/r03_dist_chol_lookahead_1rank.txt).
     // Option dist.force_panels = 1 keeps the panel schedule (tests and probes of the distributed code on one rank).
-    GDML_TRY(gdml_assemble_A(ctx, sig, lam, 0, 1));
+    GDML_TRY(gdml_assemble_A(ctx, sig, lam, use_E ? 1 : 0, 1));
     GDML_TRY(gdml_chol_set_rhs(ctx, y, n));
     int inf = 0;
     const int rc1 = gdml_chol_factor(ctx, lam, &inf);
@@ -178,6 +184,7 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
     // ---- assembly of my rows (lower blocks of A = -K + lam I) and the right-hand side
     phase_begin(ctx);
     GDML_TRY(assemble_cyclic_launch(ctx, sig, lam, A, ld, c.W, c.rank, (int)nb));
+    if (use_E) GDML_TRY(assemble_erows_cyclic_launch(ctx, sig, lam, A, ld, c.W, c.rank, (int)nb));
     GDML_TRY(phase_end(ctx, "assemble"));
     HIP_CHECK(ctx, hipMemcpyAsync(A + Lr * ld, y, n * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(ctx, hipStreamSynchronize(st));  // y is the caller's pageable array

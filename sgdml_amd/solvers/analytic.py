@@ -31,10 +31,9 @@ class Analytic(object):
         ctx.train_upload(R_desc, R_d_desc, _lib.tril_perms_from_lin(tril_perms_lin, dim_d))
 
         if ctx.comm_info()[1] > 1:
-            if use_E_cstr:  # GDMLTrain.train parks the communicator for such tasks; a direct caller gets told
-                raise NotImplementedError('the distributed analytic solver does not support energy constraints')
             # GDMLTrain.init_distributed: the system matrix is partitioned block-row-cyclic over the ranks and
-            # factored by the distributed Cholesky (csrc/dist_chol.hip); every rank gets the coefficients
+            # factored by the distributed Cholesky (csrc/dist_chol.hip); every rank gets the coefficients.  With energy
+            # constraints y carries the M energy labels and the library appends the M energy rows (train.py:235-300)
             if self.callback is not None:
                 cb = partial(self.callback, disp_str='Solving linear system (distributed Cholesky factorization)')
                 cb(NOT_DONE)
@@ -46,7 +45,7 @@ class Analytic(object):
                 # whole matrix fits one GPU every rank runs the single-GPU LU branch on its own device, redundantly (the
                 # failing pivot is a property of the replicated inputs, so every rank arrives here together).
                 n = len(y)
-                need = Analytic.est_device_memory(n_train, (1 + int(np.sqrt(8 * dim_d + 1))) // 2, False)
+                need = Analytic.est_device_memory(n_train, (1 + int(np.sqrt(8 * dim_d + 1))) // 2, use_E_cstr)
                 _, free_b, _ = ctx.mem_info()
                 fits = need <= free_b + ctx.resident_K_bytes()
                 # free HBM differs between ranks: the decision is collective (minimum over the ranks), or one rank re-raises
@@ -61,7 +60,7 @@ class Analytic(object):
                     cb(NOT_DONE)
                 self.used_lu = True
                 with ctx.comm_suspended():
-                    ctx.assemble_K(sig, False)
+                    ctx.assemble_K(sig, use_E_cstr)
                     alphas = ctx.lu_solve(lam, y)
             if self.callback is not None:
                 dur_s = timeit.default_timer() - start

@@ -313,18 +313,24 @@ class GDMLTrain(object):
             self._desc_cache = (key, R_desc, R_d_desc)
         return R_desc, R_d_desc
 
+    def _iterative_solve(self, iterative, task, R_desc, R_d_desc, tril_perms_lin, y, y_std, save_progr_callback):
+        ctx = self._context()
+        if ctx.comm_info()[1] > 1 and task['use_E_cstr']:
+            # The row-sharded Nystroem / PCG code carries force rows only (train.py:235-300 is not sharded there; the
+            # distributed Cholesky of the analytic branch does carry the energy rows).  After init_distributed() such a task
+            # is solved by every rank on its own GPU, redundantly and identically (random draws stay rank 0's): the
+            # communicator is parked for the duration of the solve.
+            self.log.info('Energy constraints: iterative solve runs redundantly on every rank (single-GPU solver)')
+            with ctx.comm_suspended():
+                return iterative.solve(task, R_desc, R_d_desc, tril_perms_lin, y, y_std,
+                                       save_progr_callback=save_progr_callback)
+        return iterative.solve(task, R_desc, R_d_desc, tril_perms_lin, y, y_std, save_progr_callback=save_progr_callback)
+
     def train(self, task, save_progr_callback=None, callback=None):
         """Train a model from a task (train.py:836-1088)."""
         task = dict(task)
         n_train, n_atoms = task['R_train'].shape[:2]
         ctx = self._context()
-        if ctx.comm_info()[1] > 1 and task['use_E_cstr']:
-            # The sharded solvers carry force rows only (train.py:235-300 is not distributed).  After init_distributed()
-            # such a task is trained by every rank on its own GPU, redundantly and identically (random draws stay rank
-            # 0's): the communicator is parked for the duration of the call.
-            self.log.info('Energy constraints: training redundantly on every rank (single-GPU solvers)')
-            with ctx.comm_suspended():
-                return self.train(task, save_progr_callback=save_progr_callback, callback=callback)
         desc = Desc(n_atoms, max_processes=self._max_processes)
         desc._ctx = ctx
 
@@ -364,9 +370,9 @@ class GDMLTrain(object):
         budget = self._device_budget_bytes()
         est_analytic = Analytic.est_device_memory(n_train, n_atoms, task['use_E_cstr'])
         world = self._context().comm_info()[1]
-        if world > 1 and not task['use_E_cstr']:
+        if world > 1:
             # distributed Cholesky: every rank holds 1/world of the matrix plus panel buffers
-            n_sys = n_train * 3 * n_atoms
+            n_sys = n_train * 3 * n_atoms + (n_train if task['use_E_cstr'] else 0)
             est_analytic = est_analytic / world + (2 * n_sys + 600000) * 512 * 8
         use_analytic_solver = est_analytic < 0.95 * budget
         if self._force_solver is not None:
@@ -397,8 +403,7 @@ class GDMLTrain(object):
                 train_rmse,
                 solver_keys['inducing_pts_idxs'],
                 is_conv,
-            ) = iterative.solve(task, R_desc, R_d_desc, tril_perms_lin, y, y_std,
-                                save_progr_callback=save_progr_callback)
+            ) = self._iterative_solve(iterative, task, R_desc, R_d_desc, tril_perms_lin, y, y_std, save_progr_callback)
             solver_keys['norm_y_train'] = np.linalg.norm(y)
             self._last_precon_form = getattr(iterative, 'precon_form', None)  # 'stored' / 'matrix-free' (diagnostics)
             if not is_conv:

@@ -38,15 +38,18 @@ def main():
 
     from sgdml_amd.train import GDMLTrain
 
-    # solver 'ecstr' / 'lu': what the sharded solvers do not carry, run by every rank redundantly (parked communicator)
-    fixture = {'ecstr': 'n5_p2_ecstr', 'ecstr_cg': 'n5_p2_ecstr', 'lu': 'lu_branch'}.get(solver, 'pcg_n9_m400')
+    # solver 'ecstr' / 'ecstr_dist': energy constraints through the distributed Cholesky (round 6: the energy rows ride in
+    # its last row blocks); 'ecstr_cg' / 'lu': what the sharded solvers do not carry, run by every rank redundantly (parked
+    # communicator)
+    fixture = {'ecstr': 'n5_p2_ecstr', 'ecstr_dist': 'ecstr_n9_p6_m40', 'ecstr_cg': 'n5_p2_ecstr',
+               'lu': 'lu_branch'}.get(solver, 'pcg_n9_m400')
     g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', fixture + '.npz')))
     M, N = g['R_train'].shape[:2]
     task = {
         'type': 't', 'code_version': '1.0.3', 'dataset_name': np.array('synth'), 'dataset_theory': np.array('pair'),
         'z': g['z'] if 'z' in g else np.full(N, 6), 'R_train': g['R_train'], 'F_train': g['F_train'], 'E_train': g['E_train'],
         'idxs_train': np.arange(M), 'md5_train': 'x', 'idxs_valid': np.arange(0), 'md5_valid': 'x',
-        'sig': int(g['sig']), 'lam': float(g['lam']), 'use_E': True, 'use_E_cstr': solver in ('ecstr', 'ecstr_cg'),
+        'sig': int(g['sig']), 'lam': float(g['lam']), 'use_E': True, 'use_E_cstr': solver in ('ecstr', 'ecstr_dist', 'ecstr_cg'),
         'use_sym': g['perms'].shape[0] > 1, 'perms': g['perms'],
     }
     if solver == 'ecstr_cg':
@@ -81,7 +84,7 @@ def main():
         tr.__del__()
         finish()
         return
-    if solver in ('ecstr', 'lu'):
+    if solver in ('ecstr', 'ecstr_dist', 'lu'):
         from sgdml_amd.solvers.analytic import Analytic
         took, orig = [], Analytic.solve
 
@@ -94,15 +97,18 @@ def main():
         tr = GDMLTrain()
         tr._force_solver = 'analytic'
         tr.init_distributed(backend=backend)
+        if solver == 'ecstr_dist':
+            tr._context().set_option('dist.nb', 128)  # n = 1120: nine row blocks, the energy rows in the ninth
         model = tr.train(task)
         assert tr._context().comm_info() == (rank, world)  # the communicator is back after the redundant solve
         chk = all_gather(float(np.abs(model['alphas_F']).sum()))
         assert len(set(chk)) == 1, chk
+        calls, _ = tr._context().comm_stats()
         if rank == 0:  # what GDMLPredict reads from a model (predict.py:326-354)
             keep = {k: model[k] for k in ('z', 'R_desc', 'R_d_desc_alpha', 'sig', 'c', 'std', 'perms', 'tril_perms_lin')}
             if 'alphas_E' in model:
                 keep['alphas_E'] = model['alphas_E']
-            np.savez(out_path, used_lu=np.array(took), **keep)
+            np.savez(out_path, used_lu=np.array(took), coll_calls=calls, alphas_F=model['alphas_F'], **keep)
         tr.__del__()
         finish()
         return

@@ -234,9 +234,10 @@ def _dist_chol_worker(rank, world, port, case, nb, out_dir):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        g = dict(np.load(os.path.join(GOLDEN, case + '.npz')))
+        keep_E = case.endswith('+E')  # energy-constraint rows stay in the system (they fill the last row blocks)
+        g = _load_system(case)
         lam = float(g['lam'])
-        n = g['K'].shape[0] - (g['R_train'].shape[0] if bool(g['use_E_cstr']) else 0)
+        n = g['K'].shape[0] - (g['R_train'].shape[0] if bool(g['use_E_cstr']) and not keep_E else 0)
         A_full = -g['K'][:n, :n] + lam * np.eye(n)
         y = g['y'][:n]
         nblk = -(-n // nb)
@@ -283,12 +284,32 @@ def _dist_chol_worker(rank, world, port, case, nb, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case,world,nb', [('n6_p1', 2, 32), ('n9_p1', 3, 64), ('n5_p4', 2, 48)])
+def _load_system(case):
+    """Fixture by name; 'name+E' = the same fixture with its energy-constraint rows kept.  A fixture without the full matrix
+    (ecstr_n9_p6_m40 stores the energy rows only) gets it from the oracle, which the test below first pins on those rows."""
+    g = dict(np.load(os.path.join(GOLDEN, case.replace('+E', '') + '.npz')))
+    if 'K' not in g:
+        M = g['R_train'].shape[0]
+        xd, gd = orc.desc_from_R(g['R_train'].reshape(M, -1))
+        tpl = orc.tril_perms_lin_from_tril_perms(orc.tril_perms_from_atom_perms(g['perms']))
+        g['K'] = orc.assemble_K(xd, gd, tpl, float(g['sig']), use_E_cstr=True)
+        g['use_E_cstr'] = np.bool_(True)
+    return g
+
+
+@pytest.mark.parametrize('case,world,nb', [('n6_p1', 2, 32), ('n9_p1', 3, 64), ('n5_p4', 2, 48), ('n5_p2_ecstr+E', 2, 32),
+                                           ('ecstr_n9_p6_m40+E', 3, 128)])
 def test_block_row_cyclic_cholesky_matches_direct_solve(tmp_path, case, world, nb):
+    """'+E' cases (round 6): the M energy-constraint rows / columns of train.py:235-300 stay in the system -- the distributed
+    Cholesky carries them in its last row blocks (csrc/dist_chol.hip, assemble_erows_cyclic_launch)."""
     mp.spawn(_dist_chol_worker, args=(world, _free_port(), case, nb, str(tmp_path)), nprocs=world, join=True)
-    g = dict(np.load(os.path.join(GOLDEN, case + '.npz')))
+    g = _load_system(case)
     lam = float(g['lam'])
     n = g['K'].shape[0]
+    if case.endswith('+E'):
+        assert n == g['R_train'].shape[0] * (3 * g['R_train'].shape[1] + 1)
+        if 'K_E_rows' in g:  # the oracle's energy rows against the reference's (train.py:235-300)
+            assert np.abs(g['K'][-g['K_E_rows'].shape[0]:] - g['K_E_rows']).max() <= 1e-13 * np.abs(g['K_E_rows']).max()
     A = -g['K'] + lam * np.eye(n)
     for r in range(world):
         x = np.load(os.path.join(str(tmp_path), 'c%d.npz' % r))['x']

@@ -533,18 +533,20 @@ def test_redundant_iterative_solve_has_one_checkpoint_writer(tmp_path):
     assert not os.path.exists(out + '.ckpt.rank1')
 
 
-@pytest.mark.parametrize('mode', ['ecstr', 'lu'])
+@pytest.mark.parametrize('mode', ['ecstr', 'ecstr_dist', 'lu'])
 def test_distributed_mode_redundant_solves(tmp_path, mode):
-    """After init_distributed the sharded solvers carry force rows and positive definite systems only.  What they do not
-    carry is solved by every rank on its own GPU with the communicator parked (gdml_comm_suspend), like a single-GPU run:
-    energy constraints (train.py:235-300; fixture n5_p2_ecstr) and the LU branch of a system on which the (distributed)
-    Cholesky fails (analytic.py:101-114; fixture lu_branch).  Two processes sharing the GPU: the model equals the reference's."""
+    """After init_distributed: energy constraints (train.py:235-300) go through the distributed Cholesky, whose last row blocks
+    hold the M energy rows (round 6; fixtures n5_p2_ecstr -- one row block, the second rank owns nothing -- and
+    ecstr_n9_p6_m40 with dist.nb = 128: nine row blocks over two ranks, the reference's coefficients compared directly).
+    What the sharded solvers do not carry is solved by every rank on its own GPU with the communicator parked
+    (gdml_comm_suspend), like a single-GPU run: the LU branch of a system on which the (distributed) Cholesky fails
+    (analytic.py:101-114; fixture lu_branch).  Two processes sharing the GPU: the model equals the reference's."""
     from sgdml_amd.predict import GDMLPredict
 
-    g = load('n5_p2_ecstr' if mode == 'ecstr' else 'lu_branch')
+    g = load({'ecstr': 'n5_p2_ecstr', 'ecstr_dist': 'ecstr_n9_p6_m40', 'lu': 'lu_branch'}[mode])
     out = str(tmp_path / 'redundant.npz')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
-    port = 29700 + (os.getpid() % 200) + (3 if mode == 'lu' else 0)
+    port = 29700 + (os.getpid() % 200) + {'ecstr': 0, 'lu': 3, 'ecstr_dist': 5}[mode]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(ROOT, 'tests', '_sharded_worker.py'), out, 'host', mode]
@@ -552,10 +554,47 @@ def test_distributed_mode_redundant_solves(tmp_path, mode):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     r = dict(np.load(out))
     assert list(r['used_lu']) == [mode == 'lu']
-    model = {k: r[k] for k in r if k != 'used_lu'}
+    assert int(r['coll_calls']) > 0  # the factorisation ran through the communicator (the LU case: its failing first attempt)
+    model = {k: r[k] for k in r if k not in ('used_lu', 'coll_calls', 'alphas_F')}
     model.update(type='m', sig=int(r['sig']), c=float(r['c']), std=float(r['std']))
     nt = len(g['R_test'])
     E, F = GDMLPredict(model).predict(g['R_test'].reshape(nt, -1))
-    tol = 1e-6 if mode == 'lu' else 2e-4  # as in the single-GPU tests of the two fixtures
+    tol = {'lu': 1e-6, 'ecstr': 2e-4, 'ecstr_dist': 1e-7}[mode]  # as in the single-GPU tests of the fixtures (lam = 1e-10 / 1e-8)
     assert np.abs(F - g['F_test']).max() <= tol * np.abs(g['F_test']).max()
     assert np.abs(E - g['E_test']).max() <= tol * max(1.0, np.abs(g['E_test']).max())
+    if mode == 'ecstr_dist':  # cond(A) ~ 1e9 at lam = 1e-8: coefficients of two correct solves agree to ~1e-6
+        assert np.abs(r['alphas_F'] - g['alphas_F']).max() <= 1e-5 * np.abs(g['alphas_F']).max()
+        assert np.abs(r['alphas_E'] - g['alphas_E']).max() <= 1e-5 * np.abs(g['alphas_E']).max()
+
+
+def _ecstr_system(ctx, g):
+    """Uploads the energy-constraint fixture; returns (label vector, mat-vec of A = -K + lam I with the energy rows)."""
+    M, N = g['R_train'].shape[:2]
+    xd, gd = ctx.desc_from_R(g['R_train'].reshape(M, -1), N)
+    tp = orc.tril_perms_from_atom_perms(g['perms'])
+    ctx.train_upload(xd, gd, tp)
+    ctx.predict_upload_model(xd, np.zeros_like(xd), tp, float(g['sig']), np.zeros(M))
+    return g['y'], (lambda v: ctx.kernel_matvec(float(g['lam']), True, v))
+
+
+@pytest.mark.parametrize('lookahead', [0, 1])
+@pytest.mark.parametrize('nb', [128, 256, 512])
+def test_distributed_cholesky_energy_constraints_single_rank(ctx, nb, lookahead):
+    """gdml_dist_chol_solve on a system with energy constraints (n = 3N M + M, round 6): the panel schedule of the distributed
+    code on one rank (dist.force_panels) -- force rows from the row-cyclic assembly, the M energy rows from
+    assemble_erows_cyclic_launch, in row blocks 8 (nb = 128: 56 force rows + 40 energy rows), 4 and 2 -- against the reference's
+    coefficients (fixture ecstr_n9_p6_m40: GDMLTrain.train with use_E_cstr) and by the residual through the reference-pinned
+    mat-vec; then the one-rank default (the single-GPU schedule behind the same entry point)."""
+    g = load('ecstr_n9_p6_m40')
+    y, Aop = _ecstr_system(ctx, g)
+    a_ref = np.hstack((g['alphas_F'], g['alphas_E']))
+    ctx.set_option('dist.nb', nb)
+    ctx.set_option('dist.lookahead', lookahead)
+    for force in (1, 0):
+        ctx.set_option('dist.force_panels', force)
+        a = ctx.dist_chol_solve(float(g['sig']), float(g['lam']), y)
+        assert a.shape == a_ref.shape
+        assert np.linalg.norm(Aop(-a) + y) <= 1e-10 * np.linalg.norm(y)
+        assert np.abs(a - a_ref).max() <= 1e-5 * np.abs(a_ref).max()
+    with pytest.raises(Exception):  # neither 3N M nor 3N M + M values
+        ctx.dist_chol_solve(float(g['sig']), float(g['lam']), y[:-1])
