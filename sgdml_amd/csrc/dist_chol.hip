@@ -28,6 +28,7 @@
 // broadcast of step 4 queues behind the gather of step 5 (shorter than step 6 from W = 2 on).  The host-staged backend
 // (ranks sharing a GPU: tests) runs every collective synchronously.  The RCCL branch has not run on more than one GPU
 // yet (tests/test_hip_scale.py::test_distributed_cholesky_rccl_one_gpu_per_rank is skipped on one-GPU boxes).
+// Energy constraints (train.py:235-300): n = 3N M + M; the energy rows are the last M global rows (assemble_erows_cyclic_launch).
 // The right-hand side is carried by EVERY rank as one extra local row (replicated, 1 row), so the forward
 // substitution happens inside steps 1/3/6 like on one GPU (gdml_chol_set_rhs).  Backward substitution: the owner of
 // block k solves L_kk^T x_k = z_k - sum_{i>k} L[i,k]^T x_i; the sum is spread over the ranks that own the rows i, each
