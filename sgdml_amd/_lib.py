@@ -395,6 +395,7 @@ class Context(object):
                    for_cholesky=None):
         """Returns the host copy (rows+extra, cols) if to_host else None (matrix stays on the GPU).
         for_cholesky=lam: all columns, device only, assembled as A = -K + lam I for chol_factor (gdml_assemble_A)."""
+        self._last_use_E = bool(use_E_cstr)
         if for_cholesky is not None:
             if points is not None or idx is not None or to_host:
                 raise ValueError('for_cholesky assembles the full device-resident system matrix')
@@ -550,9 +551,11 @@ class Context(object):
 
     def _n_lev(self):
         n_rows, _, _ = self.K_shape()  # rows held by this rank
-        n_glob = self.n_train * 3 * self.n_atoms + (0 if n_rows % (3 * self.n_atoms) == 0 else self.n_train)
         _, world = self.comm_info()
-        return n_glob if world > 1 else n_rows
+        if world <= 1:
+            return n_rows
+        # sharded: the scores of ALL rows come back, in the reference order (forces, then energy constraints)
+        return self.n_train * 3 * self.n_atoms + (self.n_train if getattr(self, '_last_use_E', False) else 0)
 
     def nystroem_factor(self, lam, idx, want_factor=False, want_lev=True):
         """(leverage scores or None, factor or None, info).  info is a bit field (gdml_nystroem_factor): bit 0 = the second

@@ -53,16 +53,19 @@ struct EColArgs {
   // points exchanged), the factorisation reads rows, and a rank of the block-row-cyclic layout stores only its own
   int row_mode;
   double lam;
+  // column mode with row-sharded storage (sharded Nystroem matrix): force rows of point i at 3N (i - i_beg), its energy row
+  // at e_row0 + i (unsharded: i_beg = 0, e_row0 = 3N M)
+  int64_t i_beg, e_row0;
 };
 
 // where the value of (row point i, component t) / the energy-energy value of row point i goes
 __device__ __forceinline__ void ecol_store(const EColArgs& A, int64_t i, int t, int64_t col, double v) {
   if (A.row_mode) A.K[col * A.ld + i * (3 * A.N) + t] = -v;
-  else A.K[(i * (3 * A.N) + t) * A.ld + col] = v;
+  else A.K[((i - A.i_beg) * (3 * A.N) + t) * A.ld + col] = v;
 }
 __device__ __forceinline__ void ecol_store_ee(const EColArgs& A, int64_t i, int64_t jj, int64_t col, double v) {
   if (A.row_mode) A.K[col * A.ld + A.M * (3 * A.N) + i] = (i == jj) ? A.lam - v : -v;
-  else A.K[(A.M * (3 * A.N) + i) * A.ld + col] = v;
+  else A.K[(A.e_row0 + i) * A.ld + col] = v;
 }
 
 __global__ void __launch_bounds__(256) ecol_kernel(EColArgs A) {
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(256) ecol_big_kernel(EColArgs A) {
 // Launch of the energy-constraint kernels: n_e requested points (d_ep) with their output columns -- or, in row mode, output
 // rows -- (d_ec), all M partner points.
 static int ecol_launch(gdml_ctx* ctx, double sig, const int32_t* d_ep, const int32_t* d_ec, int64_t n_e, double* K, int64_t ld,
-                       int row_mode, double lam) {
+                       int row_mode, double lam, int64_t i_beg = 0, int64_t i_end = -1) {
   TrainSet& ts = ctx->ts;
   const int64_t M = ts.M;
   const int N = ts.N, N3 = 3 * N;
@@ -190,14 +193,17 @@ static int ecol_launch(gdml_ctx* ctx, double sig, const int32_t* d_ep, const int
   E.M = M; E.N = N; E.D = ts.D; E.P = ts.P; E.sig = sig;
   E.jj_list = d_ep; E.out_cols = d_ec; E.K = K; E.ld = ld;
   E.row_mode = row_mode; E.lam = lam;
+  if (i_end < 0) i_end = M;
+  E.i_beg = row_mode ? 0 : i_beg;
+  E.e_row0 = (i_beg == 0 && i_end == M) ? M * N3 : (i_end - i_beg) * N3 - i_beg;
   // two outputs per thread and the descriptor tables in LDS, or (large molecules) the table-free kernel
   const bool small = N3 <= 512 && (size_t)(2 * ts.D + 32) * 8 <= (size_t)160 * 1024;
   const size_t lds = small ? (size_t)(2 * ts.D + 32) * 8 : (size_t)(ts.P + 32) * 8;
   if (small) hipFuncSetAttribute((const void*)ecol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   else hipFuncSetAttribute((const void*)ecol_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  for (int64_t i0 = 0; i0 < M; i0 += 65535) {  // grid.y limit
+  for (int64_t i0 = i_beg; i0 < i_end; i0 += 65535) {  // grid.y limit
     E.i0 = i0;
-    const int64_t ny = (M - i0 < 65535) ? M - i0 : 65535;
+    const int64_t ny = (i_end - i0 < 65535) ? i_end - i0 : 65535;
     const dim3 grid((unsigned)n_e, (unsigned)ny);
     if (small) hipLaunchKernelGGL(ecol_kernel, grid, dim3(256), lds, ctx->stream, E);
     else hipLaunchKernelGGL(ecol_big_kernel, grid, dim3(256), lds, ctx->stream, E);
@@ -335,11 +341,10 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
   int64_t i_beg = 0, i_end = M;
   const bool sharded = ctx->world > 1 && col_kind == GDML_COLS_INDEX && alloc_extra_rows > 0;
   if (sharded) {
-    if (use_E_cstr)
-      return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "sharded assembly does not support energy constraints");
+    // energy constraints (round 6): a rank holds the force rows of its points followed by THEIR energy rows
     shard_points(ctx, M, &i_beg, &i_end, nullptr);
   }
-  const int64_t n_rows_store = sharded ? (i_end - i_beg) * N3 : n_rows;
+  const int64_t n_rows_store = sharded ? (i_end - i_beg) * (N3 + (use_E_cstr ? 1 : 0)) : n_rows;
 
   // ---- (re)allocate the device matrix
   const int64_t tot_rows = n_rows_store + alloc_extra_rows;
@@ -407,7 +412,7 @@ static int assemble_impl(gdml_ctx* ctx, double sig, int use_E_cstr, int col_kind
                                 dense ? nullptr : colmap.data());
   }
   if (rc == GDML_OK && !e_pts.empty()) {
-    rc = ecol_launch(ctx, sig, d_ep, d_ec, (int64_t)e_pts.size(), ctx->K, ld, 0, 0.0);
+    if (i_end > i_beg) rc = ecol_launch(ctx, sig, d_ep, d_ec, (int64_t)e_pts.size(), ctx->K, ld, 0, 0.0, i_beg, i_end);
   }
   if (rc == GDML_OK) rc = phase_end(ctx, "assemble");
   if (d_jlist) ctx_free(ctx, d_jlist);

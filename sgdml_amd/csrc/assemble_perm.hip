@@ -39,6 +39,7 @@ struct PermArgs {
   int N, P;
   double sig;
   int use_E;             // also write the energy-constraint row K[3N M + i, .]  (train.py:235-248)
+  int64_t e_row0;        // that row is row e_row0 + i of K: 3N M, or (sharded rows) 3N (i_end - i_beg) - i_beg
   const int32_t* jlist;  // virtual column point -> training point (null: j0 + v)
   const int32_t* colmap; // (n_j, 3N) output column or -1 (null: col0 + 3N v + c)
   // compact index-list mode: strips are 64 REQUESTED column atoms (entry = virtual point * N + atom, -1 = idle lane) of at
@@ -708,7 +709,7 @@ __global__ void __launch_bounds__(64 * W, 2) assemble_perm_kernel(PermArgs A) {
         }
       }
       if (A.use_E && w == 0 && r == 0) {
-        double* dst = A.K + (A.M * N3 + i) * A.ld;
+        double* dst = A.K + (A.e_row0 + i) * A.ld;
         if (outcol[0] >= 0) dst[outcol[0]] = erow[0];
         if (outcol[1] >= 0) dst[outcol[1]] = erow[1];
         if (outcol[2] >= 0) dst[outcol[2]] = erow[2];
@@ -800,6 +801,7 @@ int assemble_perm_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   memset(&A, 0, sizeof(A));
   A.XF = ts.XF; A.GD = ts.GD; A.perm = ts.perm; A.pinv = ts.pinv;
   A.M = ts.M; A.N = N; A.P = P; A.sig = sig; A.use_E = use_E;
+  A.e_row0 = (i_beg == 0 && i_end == ts.M) ? ts.M * 3 * (int64_t)N : (i_end - i_beg) * 3 * (int64_t)N - i_beg;
   A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.n_j = n_j; A.col0 = col0;
   A.i_beg = i_beg; A.i_end = i_end; A.lower = (lower || cyc_W > 0) ? 1 : 0; A.lam = lam;
   A.cyc_W = cyc_W; A.cyc_rank = cyc_rank; A.cyc_nb = cyc_nb;

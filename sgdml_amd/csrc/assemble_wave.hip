@@ -53,6 +53,7 @@ struct WaveArgs {
   int N;
   double sig;
   int use_E;
+  int64_t e_row0;  // energy-constraint row of point i is row e_row0 + i of K: 3N M, or (sharded rows) 3N (i_end - i_beg) - i_beg
   const int32_t* jlist;
   const int32_t* colmap;
   int64_t j0, n_j;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(64) assemble_wave_kernel(WaveArgs A) {
           dst += 3 * A.ld;
         }
       }
-      if (A.use_E) A.K[(A.M * N3 + i) * A.ld + outcol] = -e_fact * (nrm + sig) * ex * u;  // train.py:235-248 (never with lower)
+      if (A.use_E) A.K[(A.e_row0 + i) * A.ld + outcol] = -e_fact * (nrm + sig) * ex * u;  // train.py:235-248 (never with lower)
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -230,6 +231,7 @@ int assemble_wave_launch(gdml_ctx* ctx, double sig, int use_E, const int32_t* d_
   GDML_TRY(build_dense_tables(ctx));
   WaveArgs A;
   A.XF = ts.XF; A.GD = ts.GD; A.M = ts.M; A.N = ts.N; A.sig = sig; A.use_E = use_E;
+  A.e_row0 = (i_beg == 0 && i_end == ts.M) ? ts.M * 3 * (int64_t)ts.N : (i_end - i_beg) * 3 * (int64_t)ts.N - i_beg;
   A.jlist = d_jlist; A.colmap = d_colmap; A.j0 = j0; A.n_j = n_j; A.K = K; A.ld = ld;
   A.i_beg = i_beg;
   A.lower = lower;

@@ -691,26 +691,20 @@ static int cho_factor_stable_dev(gdml_ctx* ctx, double* A, int64_t m, int64_t ld
   return GDML_OK;
 }
 
-// Row-shard geometry of the resident Nystroem matrix: this rank's rows are global rows
-// [row0, row0 + n_loc); vectors are replicated, padded to n_pad = world * chunk doubles.
-struct ShardGeo {
-  int64_t n, n_loc, row0, chunk, n_pad;
-};
+// Row-shard geometry of the resident Nystroem matrix: this rank's n_loc rows are the entries [row0, row0 + n_loc) of the
+// replicated device vectors, which are padded to n_pad = world * chunk doubles (VecLayout, common.h: the reference order when
+// only forces are trained; rank-major with each rank's energy rows behind its force rows under energy constraints).
+typedef VecLayout ShardGeo;
 static ShardGeo shard_geo(const gdml_ctx* ctx) {
-  ShardGeo g;
-  const int64_t N3 = 3 * (int64_t)ctx->ts.N;
   if (ctx->K_sharded) {
-    int64_t p0, p1, per;
-    shard_points(ctx, ctx->ts.M, &p0, &p1, &per);
+    ShardGeo g = vec_layout(ctx, ctx->K_use_E);
     g.n = ctx->K_rows_global;
-    g.n_loc = (p1 - p0) * N3;
-    g.row0 = p0 * N3;
-    g.chunk = per * N3;
-    g.n_pad = g.chunk * ctx->world;
-  } else {
-    g.n = g.n_loc = g.chunk = g.n_pad = ctx->K_rows;
-    g.row0 = 0;
+    return g;
   }
+  ShardGeo g;
+  g.M = ctx->ts.M; g.N3 = 3 * (int64_t)ctx->ts.N; g.n_ff = g.M * g.N3; g.per = g.M;
+  g.n = g.n_loc = g.chunk = g.n_pad = ctx->K_rows;
+  g.row0 = 0;
   return g;
 }
 
@@ -718,12 +712,11 @@ static ShardGeo shard_geo(const gdml_ctx* ctx) {
 __global__ void __launch_bounds__(256) gather_neg_rows_sharded_kernel(const double* __restrict__ X,
                                                                       double* __restrict__ S, int64_t ld,
                                                                       const int64_t* __restrict__ idx,
-                                                                      int64_t m, int64_t row0,
-                                                                      int64_t n_loc) {
+                                                                      int64_t m, VecLayout L) {
   const int64_t q = blockIdx.x;
-  const int64_t r = idx[q] - row0;
+  const int64_t r = L.pos(idx[q]) - L.row0;  // idx: reference order; the rank's rows: one run of the vector layout
   double* dst = S + q * ld;
-  if (r >= 0 && r < n_loc) {
+  if (r >= 0 && r < L.n_loc) {
     const double* src = X + r * ld;
     for (int64_t c = threadIdx.x; c < m; c += 256) dst[c] = -src[c];
   } else {
@@ -920,9 +913,7 @@ static int lev_scores_to_host(gdml_ctx* ctx, const ShardGeo& sg, double* lev_sco
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3(ceil_div(n_loc, 4)), dim3(256), 0, ctx->stream, X, ld, n_loc, m,
                        d_lev + sg.row0);
   GDML_TRY(comm_allgather_inplace(ctx, d_lev, sg.chunk));
-  HIP_CHECK(ctx, hipMemcpyAsync(lev_scores_out, d_lev, sg.n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return GDML_OK;
+  return vec_download(ctx, sg, d_lev, lev_scores_out);  // reference order
 }
 
 extern "C" int gdml_nystroem_lev_scores(gdml_ctx* ctx, double* lev_scores_out) {
@@ -987,7 +978,7 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
     }
     // K_mm = -K[idx, :]: every rank contributes the rows it owns, the sum replicates the block
     hipLaunchKernelGGL(gather_neg_rows_sharded_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, X, S,
-                       ld, d_idx, m, sg.row0, n_loc);
+                       ld, d_idx, m, sg);
     GDML_TRY(comm_allreduce_sum(ctx, S, m * ld));
     int ok = 0;
     int n_jit = 0;
@@ -1129,6 +1120,8 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
 static int precon_apply_mf(gdml_ctx* ctx, double lam, const double* d_v, double* d_out) {
   const int64_t m = ctx->precon_m, n = ctx->precon_n, ld = ctx->K_ld;
   if (!ctx->precon_Z || !ctx->precon_idx) return gdml_fail(ctx, GDML_ERR_STATE, "matrix-free preconditioner not resident");
+  if (ctx->world > 1 && ctx->precon_use_E)
+    return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "matrix-free preconditioner: not with sharded energy constraints");
   Model& md = ctx->model;
   if (!md.xp || md.M != ctx->ts.M || md.N != ctx->ts.N || md.P != ctx->ts.P || md.sig != ctx->precon_sig)
     GDML_TRY(operator_model_from_trainset(ctx, ctx->precon_sig));
@@ -1272,14 +1265,10 @@ extern "C" int gdml_precon_apply(gdml_ctx* ctx, double lam, const double* v, int
   double* dout = dv + sg.n_pad;
   int rc = GDML_OK;
   hipError_t e = hipMemsetAsync(dv, 0, 2 * sg.n_pad * 8, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(dv, v, n * 8, hipMemcpyHostToDevice, ctx->stream);
-  if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+  if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "memset: %s", hipGetErrorString(e));
+  if (rc == GDML_OK) rc = vec_upload(ctx, sg, v, dv);
   if (rc == GDML_OK) rc = precon_apply_device(ctx, lam, dv, dout);
-  if (rc == GDML_OK) {
-    e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "D2H: %s", hipGetErrorString(e));
-  }
+  if (rc == GDML_OK) rc = vec_download(ctx, sg, dout, out);
   int rc2 = ctx_free(ctx, buf);
   return rc != GDML_OK ? rc : rc2;
 }
@@ -1301,6 +1290,7 @@ struct PcgRun {
   double* xring = nullptr;  // (depth + 1) x n_pad iterates
   int64_t n_pad = 0;
   int64_t cb_iter = -1;     // iteration the callback is reporting (gdml_pcg_x), -1 outside a callback
+  VecLayout lay;            // order of the device vectors (reference order unless sharded with energy constraints)
 };
 static thread_local PcgRun* g_pcg_run = nullptr;
 static thread_local gdml_ctx* g_pcg_ctx = nullptr;
@@ -1313,9 +1303,7 @@ extern "C" int gdml_pcg_x(gdml_ctx* ctx, double* x_host_out) {
   // x_s is complete (its residual has been read) and its slot is not rewritten before the callback returns: copy it on the
   // second stream, past the iterations queued on the compute stream
   const double* xs = run->xring + (run->cb_iter % (run->depth + 1)) * run->n_pad;
-  HIP_CHECK(ctx, hipMemcpyAsync(x_host_out, xs, run->n * 8, hipMemcpyDeviceToHost, ctx->stream2));
-  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
-  return GDML_OK;
+  return vec_download(ctx, run->lay, xs, x_host_out, ctx->stream2);
 }
 
 extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double* y, const double* x0,
@@ -1329,16 +1317,15 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
     return gdml_fail(ctx, GDML_ERR_STATE,
                      "gdml_pcg: training set and operator model must be resident "
                      "(gdml_train_upload + gdml_predict_upload_model)");
-  if (ctx->world > 1 && use_E_cstr)
-    return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "sharded PCG does not support energy constraints");
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int64_t n_pad = n;
-  if (ctx->world > 1) {
-    int64_t p0, p1, per;
-    shard_points(ctx, ctx->ts.M, &p0, &p1, &per);
-    n_pad = per * 3 * ctx->ts.N * ctx->world;
-  }
-  n_pad = (n_pad + 31) / 32 * 32;
+  // device vectors in the layout of VecLayout (common.h).  Sharded with energy constraints the entries are rank-major with
+  // zero padding inside: the vector kernels then run over all n_pad entries (nv) instead of the first n
+  const VecLayout lay = vec_layout(ctx, use_E_cstr);
+  if (lay.n != n) return gdml_fail(ctx, GDML_ERR_INVALID, "gdml_pcg: n mismatch");
+  if (use_precon && ctx->world > 1 && (ctx->precon_use_E != 0) != (use_E_cstr != 0))
+    return gdml_fail(ctx, GDML_ERR_STATE, "gdml_pcg: the resident preconditioner was built with another use_E_cstr");
+  const int64_t nv = lay.two_seg ? lay.n_pad : n;
+  int64_t n_pad = (lay.n_pad + 31) / 32 * 32;
   int depth = ctx_opt_i(ctx, "pcg.depth", 2);
   if (depth < 0) depth = 0;
   if (depth > 14) depth = 14;
@@ -1365,7 +1352,7 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
   double* h_rr = nullptr;
   std::vector<hipEvent_t> ev((size_t)RING, nullptr);
   PcgRun run;
-  run.n = n; run.depth = depth; run.ring = RING; run.xring = xring; run.n_pad = n_pad;
+  run.n = n; run.depth = depth; run.ring = RING; run.xring = xring; run.n_pad = n_pad; run.lay = lay;
   int rc = GDML_OK, info = 1;
   int64_t it = 0;
   double rn = 0.0;
@@ -1379,9 +1366,9 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
     for (auto& e : ev) HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     hipStream_t st = ctx->stream;
     HIP_CHECK(ctx, hipMemsetAsync(buf, 0, (n_vec * n_pad + tail) * 8, st));
-    HIP_CHECK(ctx, hipMemcpyAsync(b, y, n * 8, hipMemcpyHostToDevice, st));
+    GDML_TRY(vec_upload(ctx, lay, y, b));
     // ||b||: the one synchronous read of the solve
-    hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, b, b, n, part_rr);
+    hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, b, b, nv, part_rr);
     hipLaunchKernelGGL(pcg_publish_kernel, dim3(1), dim3(256), 0, st, part_rr, rr_dev, h_rr_dev);
     HIP_CHECK(ctx, hipStreamSynchronize(st));
     const double bnrm = sqrt(h_rr[0]);
@@ -1393,14 +1380,14 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
     const double atol = rtol * bnrm;
     double* x = xs(0);
     if (x0) {
-      HIP_CHECK(ctx, hipMemcpyAsync(x, x0, n * 8, hipMemcpyHostToDevice, st));
+      GDML_TRY(vec_upload(ctx, lay, x0, x));
       GDML_TRY(matvec_device(ctx, lam, use_E_cstr, x, n, q));  // q = K x - lam x = -A x
-      HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, st));
-      hipLaunchKernelGGL(vec_axpy_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, r, q, 1.0, n);  // r = b - A x
+      HIP_CHECK(ctx, hipMemcpyAsync(r, b, nv * 8, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(vec_axpy_kernel, dim3(ceil_div(nv, 256)), dim3(256), 0, st, r, q, 1.0, nv);  // r = b - A x
     } else {
-      HIP_CHECK(ctx, hipMemcpyAsync(r, b, n * 8, hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(ctx, hipMemcpyAsync(r, b, nv * 8, hipMemcpyDeviceToDevice, st));
     }
-    hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, r, r, n, part_rr);
+    hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, r, r, nv, part_rr);
     hipLaunchKernelGGL(pcg_publish_kernel, dim3(1), dim3(256), 0, st, part_rr, rr_dev, h_rr_dev + 0);
     HIP_CHECK(ctx, hipEventRecord(ev[0], st));
 
@@ -1450,13 +1437,13 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
         GDML_TRY(precon_apply_device(ctx, lam, r, z));
         zz = z;
       }
-      hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, r, zz, n, part_rho[cur]);
+      hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, r, zz, nv, part_rho[cur]);
       hipLaunchKernelGGL(pcg_p_update_kernel, dim3(PCG_PARTS), dim3(256), 0, st, p, zz, part_rho[cur], part_rho[cur ^ 1],
-                         enq == 0 ? 1 : 0, n);
+                         enq == 0 ? 1 : 0, nv);
       GDML_TRY(matvec_device(ctx, lam, use_E_cstr, p, n, q));  // q = -(A p)
-      hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, p, q, n, part_pq);
+      hipLaunchKernelGGL(dot_part_kernel, dim3(PCG_PARTS), dim3(256), 0, st, p, q, nv, part_pq);
       hipLaunchKernelGGL(pcg_xr_update_kernel, dim3(PCG_PARTS), dim3(256), 0, st, xs(enq), xs(enq + 1), r, p, q,
-                         part_rho[cur], part_pq, part_rr, counter, rr_dev, h_rr_dev + ((enq + 1) % RING), n);
+                         part_rho[cur], part_pq, part_rr, counter, rr_dev, h_rr_dev + ((enq + 1) % RING), nv);
       ctx->launch_counter += 4;
       HIP_CHECK(ctx, hipGetLastError());
       HIP_CHECK(ctx, hipEventRecord(ev[(enq + 1) % RING], st));
@@ -1474,9 +1461,8 @@ extern "C" int gdml_pcg(gdml_ctx* ctx, double lam, int use_E_cstr, const double*
   if (rc == GDML_OK) {
     // the iterations queued beyond x_final are discarded; they still have to drain before the buffers go away
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(x_out, xs(x_final < 0 ? 0 : x_final), n * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "sync: %s", hipGetErrorString(e));
+    if (rc == GDML_OK) rc = vec_download(ctx, lay, xs(x_final < 0 ? 0 : x_final), x_out);
   } else {
     (void)hipStreamSynchronize(ctx->stream);
   }

@@ -192,6 +192,55 @@ void shard_points(const gdml_ctx* ctx, int64_t M, int64_t* p0, int64_t* p1, int6
   if (pts_per) *pts_per = per;
 }
 
+VecLayout vec_layout(const gdml_ctx* ctx, int use_E_cstr) {
+  VecLayout L;
+  const TrainSet& ts = ctx->ts;
+  L.M = ts.M; L.N3 = 3 * (int64_t)ts.N; L.n_ff = L.M * L.N3;
+  L.n = L.n_ff + (use_E_cstr ? L.M : 0);
+  if (ctx->world > 1) {
+    int64_t p0, p1, per;
+    shard_points(ctx, ts.M, &p0, &p1, &per);
+    L.per = per;
+    L.two_seg = use_E_cstr ? 1 : 0;
+    L.chunk = per * (L.N3 + (use_E_cstr ? 1 : 0));
+    L.n_pad = L.chunk * ctx->world;
+    L.row0 = use_E_cstr ? (int64_t)ctx->rank * L.chunk : p0 * L.N3;
+    L.n_loc = (p1 - p0) * (L.N3 + (use_E_cstr ? 1 : 0));
+  } else {
+    L.per = L.M;
+    L.chunk = L.n_pad = L.n_loc = L.n;
+  }
+  return L;
+}
+
+int vec_upload(gdml_ctx* ctx, const VecLayout& L, const double* host_ref, double* dev) {
+  HIP_CHECK(ctx, hipMemsetAsync(dev, 0, L.n_pad * 8, ctx->stream));
+  if (!L.two_seg) {
+    HIP_CHECK(ctx, hipMemcpyAsync(dev, host_ref, L.n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return GDML_OK;
+  }
+  std::vector<double> h((size_t)L.n_pad, 0.0);
+  for (int64_t g = 0; g < L.n; ++g) h[(size_t)L.pos(g)] = host_ref[g];
+  HIP_CHECK(ctx, hipMemcpyAsync(dev, h.data(), L.n_pad * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return GDML_OK;
+}
+
+int vec_download(gdml_ctx* ctx, const VecLayout& L, const double* dev, double* host_ref, hipStream_t st) {
+  if (!st) st = ctx->stream;
+  if (!L.two_seg) {
+    HIP_CHECK(ctx, hipMemcpyAsync(host_ref, dev, L.n * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return GDML_OK;
+  }
+  std::vector<double> h((size_t)L.n_pad);
+  HIP_CHECK(ctx, hipMemcpyAsync(h.data(), dev, L.n_pad * 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(ctx, hipStreamSynchronize(st));
+  for (int64_t g = 0; g < L.n; ++g) host_ref[g] = h[(size_t)L.pos(g)];
+  return GDML_OK;
+}
+
 extern "C" int gdml_comm_init_host(gdml_ctx* ctx, int rank, int world, gdml_host_allreduce allreduce,
                                    gdml_host_allgather allgather, void* user) {
   if (!ctx || !allreduce || !allgather) return GDML_ERR_INVALID;

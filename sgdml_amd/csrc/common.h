@@ -145,8 +145,8 @@ struct gdml_ctx {
   // scratch
   double* scratch = nullptr;
   int64_t scratch_bytes = 0;
-  double* slot[12] = {};  // cached work buffers (ctx_slot)
-  int64_t slot_bytes[12] = {};
+  double* slot[13] = {};  // cached work buffers (ctx_slot)
+  int64_t slot_bytes[13] = {};
   int* d_info = nullptr;
 
   // comm
@@ -263,6 +263,34 @@ int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int6
 int chol_bwd_device(gdml_ctx* ctx, const double* L, int64_t n, int64_t ld, double* d_z, double* d_x);
 int ctx_slot(gdml_ctx* ctx, int slot, int64_t bytes, double** out);
 void shard_points(const gdml_ctx* ctx, int64_t M, int64_t* p0, int64_t* p1, int64_t* pts_per);
+// Layout of the replicated device vectors of the sharded solvers (Nystroem factor rows, PCG vectors, mat-vec in / out).
+//   no communicator (world <= 1): the reference order, n entries, no padding;
+//   sharded, forces only: the reference order padded to world * chunk, chunk = 3N per (per = points per rank): a rank's
+//     rows [row0, row0 + n_loc) are one contiguous run and one all-gather of `chunk` entries replicates a result;
+//   sharded WITH energy constraints (round 6; train.py:235-300 appends the M energy entries behind the 3N M force entries):
+//     rank-major -- rank r's chunk of (3N + 1) per entries = [force entries of its points | their energy entries | padding] --
+//     so that a rank's n_loc local rows are STILL one contiguous run and everything between the boundaries (factor rows,
+//     GEMVs, all-gathers, CG vector updates over n_pad entries with zero padding) runs unchanged.  The order exists only
+//     inside the library: vectors are permuted where they enter / leave (vec_upload / vec_download, pos()).
+struct VecLayout {
+  int64_t n = 0, n_ff = 0, M = 0, N3 = 0, per = 0;
+  int64_t chunk = 0, n_pad = 0, row0 = 0, n_loc = 0;
+  int two_seg = 0;
+  __host__ __device__ int64_t pos(int64_t g) const {  // reference index -> position in the device vector
+    if (!two_seg) return g;
+    if (g < n_ff) {
+      const int64_t pt = g / N3, r = pt / per;
+      return r * chunk + (pt - r * per) * N3 + (g - pt * N3);
+    }
+    const int64_t e = g - n_ff, r = e / per;
+    const int64_t cnt = (M - r * per < per) ? M - r * per : per;
+    return r * chunk + cnt * N3 + (e - r * per);
+  }
+};
+VecLayout vec_layout(const gdml_ctx* ctx, int use_E_cstr);
+// host vector (reference order, L.n entries) -> zero-padded device vector of L.n_pad entries, and back (synchronous)
+int vec_upload(gdml_ctx* ctx, const VecLayout& L, const double* host_ref, double* dev);
+int vec_download(gdml_ctx* ctx, const VecLayout& L, const double* dev, double* host_ref, hipStream_t st = nullptr);
 int comm_allgather_inplace(gdml_ctx* ctx, double* buf, int64_t chunk);
 int comm_allreduce_sum(gdml_ctx* ctx, double* buf, int64_t count);
 int comm_allgather_inplace_on(gdml_ctx* ctx, double* buf, int64_t chunk, hipStream_t st);

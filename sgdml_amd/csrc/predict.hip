@@ -1585,6 +1585,12 @@ __global__ void __launch_bounds__(256) matvec_finish_kernel(const double* __rest
     out[t] = -E[t - nF] - lam * v[t];
 }
 
+// coefficients in the reference order from a vector in the sharded layout (VecLayout::pos)
+__global__ void __launch_bounds__(256) vec_to_ref_kernel(const double* __restrict__ v, VecLayout L, double* __restrict__ ref) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g < L.n) ref[g] = v[L.pos(g)];
+}
+
 int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, int64_t n,
                   double* d_out) {
   Model& md = ctx->model;
@@ -1593,15 +1599,21 @@ int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, 
     return gdml_fail(ctx, GDML_ERR_STATE, "kernel_matvec: training set / operator model not resident");
   const int64_t M = ts.M, N3 = 3 * (int64_t)ts.N, nF = M * N3, nE = use_E_cstr ? M : 0;
   if (n != nF + nE) return gdml_fail(ctx, GDML_ERR_INVALID, "kernel_matvec: n mismatch");
-  GDML_TRY(set_alphas_device(ctx, d_v, use_E_cstr ? d_v + nF : nullptr));
   // query shard of this rank (all training points when there is no communicator); d_v / d_out are
-  // replicated vectors, padded to world * chunk doubles when sharded
-  int64_t p0 = 0, p1 = M, per = M;
-  if (ctx->world > 1) {
-    if (use_E_cstr)
-      return gdml_fail(ctx, GDML_ERR_UNSUPPORTED, "sharded mat-vec does not support energy constraints");
-    shard_points(ctx, M, &p0, &p1, &per);
+  // replicated vectors in the layout of VecLayout (common.h): padded to world * chunk doubles when sharded, and with energy
+  // constraints rank-major -- the coefficients are brought back into the reference order for set_alphas, the rank's outputs
+  // (forces of its query points, then their energies) are exactly its contiguous chunk
+  const VecLayout L = vec_layout(ctx, use_E_cstr);
+  if (L.two_seg) {
+    double* vref;
+    GDML_TRY(ctx_slot(ctx, 12, n * 8, &vref));
+    hipLaunchKernelGGL(vec_to_ref_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_v, L, vref);
+    GDML_TRY(set_alphas_device(ctx, vref, vref + nF));
+  } else {
+    GDML_TRY(set_alphas_device(ctx, d_v, use_E_cstr ? d_v + nF : nullptr));
   }
+  int64_t p0 = 0, p1 = M, per = M;
+  if (ctx->world > 1) shard_points(ctx, M, &p0, &p1, &per);
   const int64_t B = p1 - p0;
   double* dF;
   GDML_TRY(ctx_slot(ctx, 1, (B * N3 + B + 8) * 8, &dF));
@@ -1609,8 +1621,8 @@ int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, 
   if (B > 0) {
     GDML_TRY(predict_device(ctx, ts.x + p0 * ts.D, ts.g + p0 * ts.D * 3, B, use_E_cstr ? dE : nullptr, dF));
     if (ctx->world > 1) {
-      hipLaunchKernelGGL(matvec_finish_kernel, dim3(ceil_div(B * N3, 256)), dim3(256), 0, ctx->stream, dF,
-                         dE, d_v + p0 * N3, B * N3, (int64_t)0, lam, d_out + p0 * N3);
+      hipLaunchKernelGGL(matvec_finish_kernel, dim3(ceil_div(L.n_loc, 256)), dim3(256), 0, ctx->stream, dF,
+                         dE, d_v + L.row0, B * N3, use_E_cstr ? B : (int64_t)0, lam, d_out + L.row0);
     } else {
       hipLaunchKernelGGL(matvec_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, dF, dE,
                          d_v, nF, nE, lam, d_out);
@@ -1619,7 +1631,7 @@ int matvec_device(gdml_ctx* ctx, double lam, int use_E_cstr, const double* d_v, 
     HIP_CHECK(ctx, hipGetLastError());
   }
   // with a communicator the gather is issued for every world size (a one-rank communicator runs the same call)
-  if (ctx->world > 1 || comm_active(ctx)) GDML_TRY(comm_allgather_inplace(ctx, d_out, per * N3));
+  if (ctx->world > 1 || comm_active(ctx)) GDML_TRY(comm_allgather_inplace(ctx, d_out, L.chunk));
   return GDML_OK;
 }
 
@@ -1656,31 +1668,24 @@ extern "C" int gdml_kernel_matvec(gdml_ctx* ctx, double lam, int use_E_cstr, con
                                   int64_t n, double* out) {
   if (!ctx || !v || !out) return GDML_ERR_INVALID;
   HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int64_t n_pad = n;
-  if (ctx->world > 1 && ctx->ts.x) {
-    int64_t p0, p1, per;
-    shard_points(ctx, ctx->ts.M, &p0, &p1, &per);
-    n_pad = per * 3 * ctx->ts.N * ctx->world;
-    if (n_pad < n) n_pad = n;
-  }
+  if (!ctx->ts.x) return gdml_fail(ctx, GDML_ERR_STATE, "kernel_matvec: training set / operator model not resident");
+  const VecLayout L = vec_layout(ctx, use_E_cstr);
+  if (n != L.n) return gdml_fail(ctx, GDML_ERR_INVALID, "kernel_matvec: n mismatch");
+  const int64_t n_pad = L.n_pad;
   void* buf = nullptr;
   GDML_TRY(ctx_alloc(ctx, &buf, 2 * n_pad * 8));
   double* dv = (double*)buf;
   double* dout = dv + n_pad;
   int rc = GDML_OK;
   hipError_t e = hipMemsetAsync(buf, 0, 2 * n_pad * 8, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(dv, v, n * 8, hipMemcpyHostToDevice, ctx->stream);
-  if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+  if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "memset: %s", hipGetErrorString(e));
+  if (rc == GDML_OK) rc = vec_upload(ctx, L, v, dv);
   if (rc == GDML_OK) {
     phase_begin(ctx);
     rc = matvec_device(ctx, lam, use_E_cstr, dv, n, dout);
     if (rc == GDML_OK) rc = phase_end(ctx, "matvec");
   }
-  if (rc == GDML_OK) {
-    e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = gdml_fail(ctx, GDML_ERR_HIP, "D2H: %s", hipGetErrorString(e));
-  }
+  if (rc == GDML_OK) rc = vec_download(ctx, L, dout, out);
   int rc2 = ctx_free(ctx, buf);
   return rc != GDML_OK ? rc : rc2;
 }

@@ -313,19 +313,6 @@ class GDMLTrain(object):
             self._desc_cache = (key, R_desc, R_d_desc)
         return R_desc, R_d_desc
 
-    def _iterative_solve(self, iterative, task, R_desc, R_d_desc, tril_perms_lin, y, y_std, save_progr_callback):
-        ctx = self._context()
-        if ctx.comm_info()[1] > 1 and task['use_E_cstr']:
-            # The row-sharded Nystroem / PCG code carries force rows only (train.py:235-300 is not sharded there; the
-            # distributed Cholesky of the analytic branch does carry the energy rows).  After init_distributed() such a task
-            # is solved by every rank on its own GPU, redundantly and identically (random draws stay rank 0's): the
-            # communicator is parked for the duration of the solve.
-            self.log.info('Energy constraints: iterative solve runs redundantly on every rank (single-GPU solver)')
-            with ctx.comm_suspended():
-                return iterative.solve(task, R_desc, R_d_desc, tril_perms_lin, y, y_std,
-                                       save_progr_callback=save_progr_callback)
-        return iterative.solve(task, R_desc, R_d_desc, tril_perms_lin, y, y_std, save_progr_callback=save_progr_callback)
-
     def train(self, task, save_progr_callback=None, callback=None):
         """Train a model from a task (train.py:836-1088)."""
         task = dict(task)
@@ -403,7 +390,8 @@ class GDMLTrain(object):
                 train_rmse,
                 solver_keys['inducing_pts_idxs'],
                 is_conv,
-            ) = self._iterative_solve(iterative, task, R_desc, R_d_desc, tril_perms_lin, y, y_std, save_progr_callback)
+            ) = iterative.solve(task, R_desc, R_d_desc, tril_perms_lin, y, y_std,
+                                save_progr_callback=save_progr_callback)
             solver_keys['norm_y_train'] = np.linalg.norm(y)
             self._last_precon_form = getattr(iterative, 'precon_form', None)  # 'stored' / 'matrix-free' (diagnostics)
             if not is_conv:

@@ -39,8 +39,8 @@ def main():
     from sgdml_amd.train import GDMLTrain
 
     # solver 'ecstr' / 'ecstr_dist': energy constraints through the distributed Cholesky (round 6: the energy rows ride in
-    # its last row blocks); 'ecstr_cg' / 'lu': what the sharded solvers do not carry, run by every rank redundantly (parked
-    # communicator)
+    # its last row blocks); 'ecstr_cg': through the sharded iterative solver; 'lu': what the sharded solvers do not carry, run
+    # by every rank redundantly (parked communicator)
     fixture = {'ecstr': 'n5_p2_ecstr', 'ecstr_dist': 'ecstr_n9_p6_m40', 'ecstr_cg': 'n5_p2_ecstr',
                'lu': 'lu_branch'}.get(solver, 'pcg_n9_m400')
     g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', fixture + '.npz')))
@@ -53,8 +53,8 @@ def main():
         'use_sym': g['perms'].shape[0] > 1, 'perms': g['perms'],
     }
     if solver == 'ecstr_cg':
-        # energy constraints through the ITERATIVE solver, redundantly on every rank, with a checkpoint writer: the writer
-        # must be the group's rank 0 only although gdml_comm_info says "rank 0" on every rank while the communicator is parked
+        # energy constraints through the ITERATIVE solver (row-sharded since round 6) with a checkpoint writer: the writer must be
+        # the group's rank 0 only
         from sgdml_amd.solvers import iterative as it_mod
 
         class FakeClock(object):  # 60 s per timer call: a checkpoint is due every tenth iteration (iterative.py:675-680)
@@ -79,8 +79,9 @@ def main():
         assert tr._context().comm_info() == (rank, world)
         chk = all_gather(float(np.abs(model['alphas_F']).sum()))
         assert len(set(chk)) == 1, chk
+        calls, _ = tr._context().comm_stats()
         if rank == 0:
-            np.savez(out_path, iters=model['solver_iters'], alphas=model['alphas_F'])
+            np.savez(out_path, iters=model['solver_iters'], alphas=model['alphas_F'], coll_calls=calls)
         tr.__del__()
         finish()
         return

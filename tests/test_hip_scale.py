@@ -513,11 +513,14 @@ def test_dropin_train_distributed_analytic(tmp_path):
     assert abs(float(r['c']) - model['c']) <= 1e-6 * max(1.0, abs(model['c']))
 
 
-def test_redundant_iterative_solve_has_one_checkpoint_writer(tmp_path):
-    """Energy constraints after init_distributed: every rank trains redundantly under a parked communicator, where
-    gdml_comm_info answers rank 0 of 1 on EVERY rank.  The checkpoint writer is gated on the group's rank (round-4 advisor
-    finding): with two processes and a clock that makes every tenth iteration a checkpoint, only rank 0 calls
-    save_progr_callback."""
+def test_sharded_iterative_energy_constraints_one_checkpoint_writer(tmp_path):
+    """Energy constraints through GDMLTrain.train with the iterative solver after init_distributed (round 6: row-sharded like
+    the force-only systems -- until then every rank solved redundantly under a parked communicator).  Two processes sharing
+    the GPU, a clock that makes every tenth iteration a checkpoint: only the group's rank 0 calls save_progr_callback, both
+    ranks end with the same coefficients, and they are the single-process solve's (same seed = same inducing columns) to
+    the solver's tolerance."""
+    from sgdml_amd.train import GDMLTrain
+
     out = str(tmp_path / 'ecstr_cg.npz')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
     port = 29900 + (os.getpid() % 40)
@@ -528,9 +531,25 @@ def test_redundant_iterative_solve_has_one_checkpoint_writer(tmp_path):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     r = dict(np.load(out))
     assert int(r['iters']) >= 20, int(r['iters'])  # long enough for checkpoints to be due
+    assert int(r['coll_calls']) > int(r['iters'])  # sharded: collectives in every iteration
     written = [ln for ln in open(out + '.ckpt.rank0').read().split() if ln]
     assert len(written) >= 1 and all(int(v) % 10 == 1 for v in written), written  # solver_iters = iteration + 1
     assert not os.path.exists(out + '.ckpt.rank1')
+    g = dict(load('n5_p2_ecstr'))
+    g.setdefault('z', np.full(g['R_train'].shape[1], 6))
+    task = make_task(g, use_E_cstr=True)
+    tr = GDMLTrain()
+    try:
+        tr._force_solver = 'cg'
+        tr._force_n_inducing_pts = 1
+        np.random.seed(5)  # rank 0's seed in the worker: the same inducing columns
+        model = tr.train(task)
+    finally:
+        tr.__del__()
+    assert abs(int(model['solver_iters']) - int(r['iters'])) <= max(3, int(r['iters']) // 10)
+    # lam = 1e-10 (cond ~ 1e10) at solver_tol = 1e-4: two correct iterate sequences that differ in the order of their sums end
+    # percent-level apart in the coefficients (observed 0.7 %); a wrong layout would be an O(1) difference
+    assert np.abs(r['alphas'] - model['alphas_F']).max() <= 5e-2 * np.abs(model['alphas_F']).max()
 
 
 @pytest.mark.parametrize('mode', ['ecstr', 'ecstr_dist', 'lu'])
@@ -598,3 +617,41 @@ def test_distributed_cholesky_energy_constraints_single_rank(ctx, nb, lookahead)
         assert np.abs(a - a_ref).max() <= 1e-5 * np.abs(a_ref).max()
     with pytest.raises(Exception):  # neither 3N M nor 3N M + M values
         ctx.dist_chol_solve(float(g['sig']), float(g['lam']), y[:-1])
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_nystroem_pcg_with_energy_constraints(tmp_path, ctx, world):
+    """Energy constraints in the ROW-SHARDED iterative path (round 6): every rank holds the force rows of its points followed
+    by their energy rows; the replicated device vectors are rank-major inside the library (VecLayout, csrc/common.h) and
+    permuted where they enter and leave.  `world` processes sharing the GPU (host-staged collectives; 40 points over 3 ranks =
+    14 + 14 + 12: a ragged last shard) against the same calls on one context: leverage scores, one preconditioner
+    application, the mat-vec, the PCG solution, an iterate fetched inside the callback, a warm start."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _ecstr_shard_worker as w
+
+    g = load('ecstr_n9_p6_m40')
+    out = str(tmp_path / 'ecstr_shard.npz')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+    port = 29500 + (os.getpid() % 90) + 3 * world
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'tests', '_ecstr_shard_worker.py'), out]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r = dict(np.load(out))
+    idx, v = w.inputs(g)
+    one = w.run(ctx, g, idx, v)
+    M, N = g['R_train'].shape[:2]
+    per = -(-M // world)
+    assert list(r['rows']) == [max(0, min(M, (k + 1) * per) - k * per) * (3 * N + 1) for k in range(world)]  # 1/world each
+    assert np.abs(r['Kv'] - one['Kv']).max() <= 1e-11 * np.abs(one['Kv']).max()
+    # factor rows are the same numbers up to the order of the m x m sums: lam = 1e-8, cond ~ 1e9
+    assert np.abs(r['lev'] - one['lev']).max() <= 1e-5 * np.abs(one['lev']).max()
+    assert np.abs(r['z'] - one['z']).max() <= 1e-5 * np.abs(one['z']).max()
+    assert int(r['pinfo']) == 0 and int(one['pinfo']) == 0
+    assert abs(int(r['iters']) - int(one['iters'])) <= max(3, int(one['iters']) // 10)
+    y = g['y']
+    Aop = lambda a: ctx.kernel_matvec(float(g['lam']), True, a)
+    for x in (r['x'], one['x']):
+        assert np.linalg.norm(-Aop(x) - y) <= 2e-5 * np.linalg.norm(y)   # A x = y, A v = -(K v - lam v)
+    assert np.abs(r['x5'] - one['x5']).max() <= 1e-4 * np.abs(one['x5']).max()  # the iterate of iteration 5, reference order
+    assert int(r['iters_w']) <= 1
