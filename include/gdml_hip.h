@@ -356,7 +356,9 @@ int gdml_pcg_x(gdml_ctx* ctx, double* x_host_out);
  *   - the iterative path is sharded over the training points (contiguous row shards):
  *     gdml_assemble_K(GDML_COLS_INDEX, ..., alloc_extra_rows > 0) assembles the rank's rows of K_nm,
  *     gdml_nystroem_factor / gdml_precon_apply / gdml_kernel_matvec / gdml_pcg exchange m- and n-vectors with
- *     RCCL all-reduce / all-gather over xGMI;
+ *     RCCL all-reduce / all-gather over xGMI; with use_E_cstr a rank holds the force rows of its points followed by their
+ *     energy rows (vectors cross the ABI in the reference order -- forces, then energies -- on every rank; the rank-major
+ *     order of the device vectors stays inside the library);
  *   - the analytic path is gdml_dist_chol_solve (block-row-cyclic matrix, below).
  * The collectives are issued for every communicator size, including one rank.  gdml_chol_* / gdml_lu_solve stay
  * single-GPU entry points. */
@@ -365,9 +367,8 @@ int gdml_comm_init(gdml_ctx* ctx, const void* id128, int rank, int world);
 int gdml_comm_info(gdml_ctx* ctx, int* rank_out, int* world_out);
 /* gdml_comm_suspend(ctx, 1) parks the communicator: until gdml_comm_suspend(ctx, 0) the context behaves like a single GPU
  * without one (rank 0 of 1: unsharded assembly, local Cholesky / LU / PCG, no collective).  For work every rank performs
- * redundantly on its own GPU because the sharded solvers do not carry it: energy constraints (train.py:235-300) in the
- * iterative solver (the distributed Cholesky carries them) and the LU branch of a matrix that is not positive definite
- * (analytic.py:101-114). */
+ * redundantly on its own GPU because the sharded solvers do not carry it: the LU branch of a matrix that is not positive
+ * definite (analytic.py:101-114).  (Energy constraints, train.py:235-300, are carried by both sharded solvers since round 6.) */
 int gdml_comm_suspend(gdml_ctx* ctx, int suspend);
 
 /* Distributed analytic solve (new; Analytic.solve, analytic.py:65-99, for systems beyond one GPU -- BASELINE.json

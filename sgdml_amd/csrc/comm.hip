@@ -137,9 +137,8 @@ void comm_destroy(gdml_ctx* ctx) {
 }
 
 // Park / restore the communicator: while suspended the context behaves like a single GPU without a communicator (every
-// entry point: unsharded assembly, local solves, no collective).  For work every rank does redundantly -- energy
-// constraints in the iterative solver and the LU fallback, which the sharded solvers do not carry (sgdml/train.py:235-300,
-// analytic.py:101-114; the distributed Cholesky does carry the energy rows).
+// entry point: unsharded assembly, local solves, no collective).  For work every rank does redundantly -- the LU fallback,
+// which the sharded solvers do not carry (analytic.py:101-114).
 extern "C" int gdml_comm_suspend(gdml_ctx* ctx, int suspend) {
   if (!ctx) return GDML_ERR_INVALID;
   if (suspend && !ctx->parked.on) {

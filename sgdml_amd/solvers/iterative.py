@@ -268,7 +268,7 @@ class Iterative(object):
                     E_pred, _ = ctx.predict(None)
                     unconv_model['c'] = np.mean(np.squeeze(task['E_train']) - E_pred * y_std)
                 # one writer: the group's rank 0 (comm_info() reports rank 0 on EVERY rank while the communicator is
-                # parked for a redundant solve, so the gate is the rank recorded by init_distributed)
+                # parked -- the redundant LU branch --, so the gate is the rank recorded by init_distributed)
                 if save_progr_callback is not None and getattr(ctx, '_dist_rank', 0) == 0:
                     save_progr_callback(unconv_model)
 

@@ -365,8 +365,7 @@ class GDMLTrain(object):
         if self._force_solver is not None:
             use_analytic_solver = self._force_solver == 'analytic'
         # free HBM differs between ranks (rank 0 usually holds more): every rank must take rank 0's branch, or one enters
-        # the distributed Cholesky's collectives (or, with a parked communicator, rank 0's broadcasts of the iterative
-        # solver's random draws) while another does not
+        # the distributed Cholesky's collectives while another enters the sharded iterative solver's
         bcast = getattr(self._context(), '_bcast', None)
         if bcast is not None:
             use_analytic_solver = bool(np.asarray(bcast(np.array([int(use_analytic_solver)], dtype=np.int64)))[0])
