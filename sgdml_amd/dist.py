@@ -23,6 +23,26 @@ def shard_range(rank, world, n_points):
     return a, b, per
 
 
+def sharded_vector_positions(world, n_points, dim_i, use_E_cstr):
+    """Position of every entry of a reference-order vector (forces of all points, then -- with energy constraints -- the
+    n_points energy entries) inside the replicated device vectors of the sharded solvers: same rule as
+    csrc/common.h::VecLayout::pos.  Returns (positions, chunk, n_pad).  Forces only: the identity, padded at the end.  With
+    energy constraints the order is rank-major, rank r's chunk = [force entries of its points | their energy entries | padding]
+    (a rank's local rows stay one contiguous run).  The order never crosses the C ABI; this restatement serves tests and tools."""
+    per = (n_points + world - 1) // world
+    n_ff = n_points * dim_i
+    if not use_E_cstr:
+        return np.arange(n_ff), per * dim_i, per * dim_i * world
+    chunk = per * (dim_i + 1)
+    pos = np.empty(n_ff + n_points, dtype=np.int64)
+    pt = np.arange(n_points)
+    r = pt // per
+    cnt = np.minimum(per, n_points - r * per)
+    pos[:n_ff] = (r[:, None] * chunk + (pt - r * per)[:, None] * dim_i + np.arange(dim_i)[None]).ravel()
+    pos[n_ff:] = r * chunk + cnt * dim_i + (pt - r * per)
+    return pos, chunk, chunk * world
+
+
 class _TorchGroup(object):
     """Adapter: a torch.distributed process group with the HostChannel interface (CPU tensors; nothing on the GPU path)."""
 

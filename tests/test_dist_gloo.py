@@ -19,7 +19,7 @@ import torch.distributed as dist  # noqa: E402
 import torch.multiprocessing as mp  # noqa: E402
 
 from oracle import gdml_oracle as orc  # noqa: E402
-from sgdml_amd.dist import init_comm_from_torch_distributed, shard_range  # noqa: E402
+from sgdml_amd.dist import init_comm_from_torch_distributed, shard_range, sharded_vector_positions  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -154,6 +154,101 @@ def test_sharded_pcg_matches_single_process(tmp_path, case, world):
         assert np.linalg.norm(A @ xs[r]['x'] - g['y']) <= 2e-6 * np.linalg.norm(g['y'])
         np.testing.assert_allclose(xs[r]['lev'], lev_ref, rtol=1e-5, atol=1e-8 * lev_ref.max())
     assert abs(int(xs[0]['iters']) - iters_ref) <= max(3, iters_ref // 5)
+
+
+def _sharded_solve_E(rank, world, case, rtol, out_dir):
+    """The row-sharded Nystroem / PCG algorithm WITH energy constraints (csrc/cg.hip since round 6): a rank holds the force rows
+    of its points followed by their energy rows, the replicated vectors are rank-major (sharded_vector_positions = VecLayout::pos),
+    every result is one all-gather of `chunk` entries, the CG runs over the padded vectors."""
+    import scipy.linalg as sla
+
+    g = dict(np.load(os.path.join(GOLDEN, case + '.npz')))
+    lam, sig = float(g['lam']), float(g['sig'])
+    M, N = g['R_train'].shape[:2]
+    N3, n_ff = 3 * N, M * 3 * N
+    n = n_ff + M
+    idx = g['col_idxs']
+    m = len(idx)
+    p0, p1, per = shard_range(rank, world, M)
+    pos, chunk, n_pad = sharded_vector_positions(world, M, N3, True)
+    loc_ref = np.concatenate([np.arange(p0 * N3, p1 * N3), n_ff + np.arange(p0, p1)])  # my rows, reference indices
+    row0, n_loc = rank * chunk, len(loc_ref)
+    assert np.array_equal(pos[loc_ref], row0 + np.arange(n_loc))  # ... are one contiguous run of the device order
+    to_dev = lambda v: np.bincount(pos, weights=v, minlength=n_pad).astype(np.float64)  # scatter; padding stays zero
+    K_nm = orc.assemble_K(g['R_desc'], g['R_d_desc'], g['tril_perms_lin'], sig, True, col_idxs=idx)
+    X = K_nm[loc_ref].copy()
+    S = np.zeros((m, m))
+    for q, gi in enumerate(idx):  # K_mm = -K[idx]: the owner of a row contributes it
+        r = pos[gi] - row0
+        if 0 <= r < n_loc:
+            S[q] = -X[r]
+    S = _allreduce(S)
+    L, lower = orc.cho_factor_stable(S, pre_reg=True)
+    X = sla.solve_triangular(L, X.T, lower=lower, trans='T', check_finite=False).T
+    inner = _allreduce(X.T @ X)
+    inner[np.diag_indices_from(inner)] += lam
+    L2, lower2 = orc.cho_factor_stable(inner, eps_mag_max=-14)
+    X = sla.solve_triangular(L2, X.T, lower=lower2, trans='T', check_finite=False).T
+    lev = _allgather_chunks(np.einsum('ij,ij->i', X, X), chunk, world)[pos]  # back to the reference order
+
+    def precon(v):  # device order in, device order out
+        t = _allreduce(X.T @ v[row0:row0 + n_loc])
+        return _allgather_chunks((X @ t - v[row0:row0 + n_loc]) / lam, chunk, world)
+
+    K_rows = g['K'][loc_ref]
+
+    def A_mv(v):  # the mat-vec brings the coefficients back to the reference order; its output is the rank's chunk
+        loc = -(K_rows @ v[pos] - lam * v[row0:row0 + n_loc])
+        return _allgather_chunks(loc, chunk, world)
+
+    x, info, iters, resid = orc.pcg(A_mv, to_dev(g['y']), M_mv=precon, rtol=rtol, maxiter=5000)
+    np.savez(os.path.join(out_dir, 'e%d.npz' % rank), x=x[pos], info=info, iters=iters, lev=lev, pad=np.abs(np.delete(x, pos)).sum())
+
+
+def _worker_E(rank, world, port, case, rtol, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        _sharded_solve_E(rank, world, case, rtol, out_dir)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_pcg_with_energy_constraints_matches_single_process(tmp_path, world):
+    """Fixture n5_p2_ecstr (8 points: shards 4 + 4 and 3 + 3 + 2; the inducing columns include an energy column)."""
+    case, rtol = 'n5_p2_ecstr', 1e-6
+    mp.spawn(_worker_E, args=(world, _free_port(), case, rtol, str(tmp_path)), nprocs=world, join=True)
+    g = dict(np.load(os.path.join(GOLDEN, case + '.npz')))
+    lam = float(g['lam'])
+    n = g['K'].shape[0]
+    assert g['col_idxs'].max() >= n - g['R_train'].shape[0]
+    A = -g['K'] + lam * np.eye(n)
+    Lf = orc.nystroem_factor(g['R_desc'], g['R_d_desc'], g['tril_perms_lin'], float(g['sig']), lam, g['col_idxs'], use_E_cstr=True)
+    x_ref, info_ref, iters_ref, _ = orc.pcg(lambda v: A @ v, g['y'], M_mv=lambda v: orc.precon_apply(Lf, lam, v),
+                                            rtol=rtol, maxiter=5000)
+    lev_ref = np.einsum('ij,ij->j', Lf, Lf)
+    xs = [np.load(os.path.join(str(tmp_path), 'e%d.npz' % r)) for r in range(world)]
+    for r in range(world):
+        assert int(xs[r]['info']) == 0 and float(xs[r]['pad']) == 0.0  # the padding of the device order stays zero
+        np.testing.assert_array_equal(xs[r]['x'], xs[0]['x'])
+        assert np.linalg.norm(A @ xs[r]['x'] - g['y']) <= 2e-6 * np.linalg.norm(g['y'])
+        np.testing.assert_allclose(xs[r]['lev'], lev_ref, rtol=1e-5, atol=1e-8 * lev_ref.max())
+    assert abs(int(xs[0]['iters']) - iters_ref) <= max(3, iters_ref // 5)
+
+
+def test_sharded_vector_positions_are_a_padded_permutation():
+    for M, W, d in ((8, 2, 15), (8, 3, 15), (40, 3, 27), (5, 8, 6), (1, 2, 3)):
+        for use_E in (False, True):
+            pos, chunk, n_pad = sharded_vector_positions(W, M, d, use_E)
+            assert len(pos) == M * d + (M if use_E else 0) and len(set(pos.tolist())) == len(pos)
+            assert pos.min() >= 0 and pos.max() < n_pad == chunk * W
+            for r in range(W):  # a rank's entries: one run at the start of its chunk, forces before energies
+                a, b, per = shard_range(r, W, M)
+                mine = np.concatenate([pos[a * d:b * d], pos[M * d + a:M * d + b] if use_E else pos[:0]])
+                first = r * chunk if use_E else a * d
+                assert np.array_equal(mine, first + np.arange(len(mine)))
 
 
 def test_shard_range_covers_points():
