@@ -523,3 +523,58 @@ def test_wide_contractions_on_padded_tables_and_query_chunks(ctx):
                 Es, Fs = ctx.predict(Rq[lo:lo + 1000], None)
                 assert np.abs(F1[lo:lo + 1000] - Fs).max() <= 1e-12 * np.abs(F1).max()
                 assert np.abs(E1[lo:lo + 1000] - Es).max() <= 1e-12 * np.abs(E1).max()
+
+
+def test_energy_constraint_system_of_several_row_blocks_against_the_reference(ctx):
+    """ecstr_n9_p6_m40 (make_golden_r6.py: N = 9, 6-element group, M = 40, use_E_cstr, n = 1120, lam = 1e-8): the energy ROWS of the
+    K the reference assembled (train.py:235-248) and, by the symmetry the distributed Cholesky relies on, its energy COLUMNS
+    (train.py:250-300) from the device assembly at 1e-12; a slice and an index list that mix force and energy columns; the
+    reference's coefficients through the single-GPU analytic solve by residual (1e-10) and value (cond ~ 1e9), and its predictions
+    for unseen geometries from the model GDMLTrain.train builds (energy-constraint term of predict.py included)."""
+    from sgdml_amd.predict import GDMLPredict
+    from sgdml_amd.train import GDMLTrain
+
+    g = load('ecstr_n9_p6_m40')
+    M, N = g['R_train'].shape[:2]
+    n_ff = 3 * N * M
+    sig, lam = float(g['sig']), float(g['lam'])
+    xd, gd = ctx.desc_from_R(g['R_train'].reshape(M, -1), N)
+    tp = orc.tril_perms_from_atom_perms(g['perms'])
+    ctx.train_upload(xd, gd, tp)
+    K = ctx.assemble_K(sig, True, to_host=True)
+    ref, scale = g['K_E_rows'], np.abs(g['K_E_rows']).max()
+    assert K.shape == (n_ff + M, n_ff + M)
+    assert np.abs(K[n_ff:] - ref).max() <= 1e-12 * scale
+    assert np.abs(K[:, n_ff:] - ref.T).max() <= 1e-12 * scale
+    Ks = ctx.assemble_K(sig, True, points=(M - 2, M + 5), to_host=True)  # two force points, five energy columns
+    assert np.abs(Ks[n_ff:] - np.hstack((ref[:, (M - 2) * 3 * N:n_ff], ref[:, n_ff:n_ff + 5]))).max() <= 1e-12 * scale
+    idx = np.sort(np.concatenate((np.random.RandomState(3).choice(n_ff, 85, replace=False), n_ff + np.array([1, 7, M - 1]))))
+    Ki = ctx.assemble_K(sig, True, idx=idx, to_host=True)
+    assert np.abs(Ki[n_ff:] - ref[:, idx]).max() <= 1e-12 * scale
+    # analytic solve on one GPU (chol.hip: full matrix, negated and regularised by the factorisation)
+    ctx.assemble_K(sig, True, alloc_extra_rows=1, for_cholesky=lam)
+    ctx.chol_set_rhs(g['y'])
+    ctx.chol_factor(lam)
+    a = ctx.chol_solve(None)
+    a_ref = np.hstack((g['alphas_F'], g['alphas_E']))
+    ctx.predict_upload_model(xd, np.zeros_like(xd), tp, sig, np.zeros(M))
+    assert np.linalg.norm(ctx.kernel_matvec(lam, True, -a) + g['y']) <= 1e-10 * np.linalg.norm(g['y'])
+    assert np.abs(a - a_ref).max() <= 1e-5 * np.abs(a_ref).max()
+    # drop-in training and prediction
+    task = {
+        'type': 't', 'code_version': '1.0.3', 'dataset_name': np.array('synth'), 'dataset_theory': np.array('pair'),
+        'z': g['z'], 'R_train': g['R_train'], 'F_train': g['F_train'], 'E_train': g['E_train'],
+        'idxs_train': np.arange(M), 'md5_train': 'x', 'idxs_valid': np.arange(0), 'md5_valid': 'x',
+        'sig': int(sig), 'lam': lam, 'use_E': True, 'use_E_cstr': True, 'use_sym': True, 'perms': g['perms'],
+    }
+    tr = GDMLTrain()
+    try:
+        model = tr.train(task)
+    finally:
+        tr.__del__()
+    assert model['solver_name'] == 'analytic' and 'alphas_E' in model
+    assert abs(float(model['c']) - float(g['model_c'])) <= 1e-6 * max(1.0, abs(float(g['model_c'])))
+    nt = len(g['R_test'])
+    E, F = GDMLPredict(model).predict(g['R_test'].reshape(nt, -1))
+    assert np.abs(F - g['F_test']).max() <= 1e-7 * np.abs(g['F_test']).max()
+    assert np.abs(E - g['E_test']).max() <= 1e-7 * max(1.0, np.abs(g['E_test']).max())
