@@ -144,6 +144,10 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   chol.lookahead (1)    factorisation schedule (fused_diag = 0: the round-1 second-stream look-ahead schedule)
  *   chol.outer (1024)     panel pairs: K = 2 nb trailing update in two launches (= chol.nb: single panels only)
  *   chol.outer_min_rows (16384)  trailing rows below which new panels are single again
+ *   chol.block (0)        W > 0 (multiple of 1024, >= 2048, n >= 3 W): two-level factorisation -- column blocks of W columns, each
+ *                         factored with all rows below it carried along, then one lower update of depth W (0.90 of the peak instead
+ *                         of 0.86) for everything to its right; the blocks' own factorisation eats the gain: 0.6-1.3 % slower
+ *                         (profiles/r06_chol_block.txt).  chol.block_f (2): weight of rows x columns in a tall block's thresholds
  *   chol.merge_gemm1 (1)  the pair's own columns as first super-tile column of the trailing-update launch
  *   chol.tail_lookahead (1)  tail: step chain of the next panel on the high-priority stream
  *   trsm.debug (0)        timing-only ablation mask of the row-local panel solve (results are wrong when set)

@@ -1978,7 +1978,7 @@ int panel_factor_steps(gdml_ctx* ctx, hipStream_t st, double* A, int64_t n, int6
 
 // n: order of the matrix; n_rows >= n: rows n..n_rows-1 are carried along (right-hand sides stored as extra
 // rows: they go through the panel solves and trailing updates, i.e. through the forward substitution)
-int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out, int64_t n_rows) {
+static int chol_factor_level(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out, int64_t n_rows) {
   if (n_rows < n) n_rows = n;
   HIP_CHECK(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   if (ctx->gemm_queue) {  // tile counters of the persistent trailing updates: one zeroed set per launch
@@ -2006,8 +2006,19 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
     int64_t OB = (int64_t)ctx_opt(ctx, "chol.outer", 1024);
     if (OB != 2 * NB) OB = NB;
     const int64_t outer_min_rows = (int64_t)ctx_opt(ctx, "chol.outer_min_rows", 16384);
+    // "how much trailing matrix is left behind column t": its columns for the square systems of rounds 1-5; for a TALL block
+    // (round 6, two-level schedule below: n columns, n_rows >> n rows carried along) the geometric mean of rows and columns,
+    // so that the long launches of a tall block keep the paired / fused forms.  floor(sqrt((n_rows - t)(n - t))) = n - t for
+    // n_rows = n and n_rows = n + 1 (carried right-hand side): the square schedule is unchanged.
+    const double tall_f = ctx_opt(ctx, "chol.block_f", 2.0);
+    auto left_at = [&](int64_t t) -> int64_t {
+      if (t >= n) return 0;
+      if (n_rows - n <= 1) return n - t;
+      // (tall: the update is a full rectangle, the square case's a triangle; chol.block_f weighs that -- tuned by measurement)
+      return (int64_t)sqrt(tall_f * (double)(n_rows - t) * (double)(n - t));
+    };
     auto width_at = [&](int64_t c0) -> int64_t {  // width of the panel that starts at column c0
-      const int64_t w = (OB > NB && n - (c0 + OB) >= outer_min_rows) ? OB : NB;
+      const int64_t w = (OB > NB && n - (c0 + OB) > 0 && left_at(c0 + OB) >= outer_min_rows) ? OB : NB;
       return (n - c0 < w) ? n - c0 : w;
     };
     // first panel: always one level (nothing to hide its diagonal block behind)
@@ -2021,7 +2032,7 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
       const int64_t nb2 = width_at(t0);
       const int64_t t1 = t0 + nb2;
       const double* P = A + t0 * ld + k0;
-      const bool fuse = (nb2 % 64 == 0) && (n - t1 >= min_rows) && (n_rows - t1 > 0);
+      const bool fuse = (nb2 % 64 == 0) && (left_at(t1) >= min_rows) && (n_rows - t1 > 0);
       // the merged schedule counts finished GT x GT tiles of a diagonal block: NB must be a whole number of tiles, or the
       // counter target is too small and the block is factored before its last update arrived
       const bool merged = fuse && nb2 == 2 * NB && NB % GT == 0 && ctx_opt_i(ctx, "chol.merge_gemm1", 1) != 0;
@@ -2145,6 +2156,38 @@ int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* inf
   HIP_CHECK(ctx, hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (info_out) *info_out = info;
+  return GDML_OK;
+}
+
+// Two-level schedule (round 6, option chol.block = W > 0): the matrix is factored in column blocks of W columns.  A block --
+// W columns, ALL rows below its diagonal carried along -- goes through the schedule above (its trailing updates stay inside the
+// block's columns), then ONE lower update of depth W brings everything right of the block up to date.  The bulk of the flops
+// (1 - 1.5 W / n of them) runs in products of depth W instead of 1024: a C tile is read and written n / W times instead of
+// n / 1024 times and the tile turnover that costs the K = 1024 update 14 % of its time shrinks with it (by shape, idle chip, zero
+// operands: K = 1024 0.885, K = 4096 0.927, K = 16384 0.934 of the peak: profiles/r06_gemm_shapes.txt).
+int chol_factor_device(gdml_ctx* ctx, double* A, int64_t n, int64_t ld, int* info_out, int64_t n_rows) {
+  if (n_rows < n) n_rows = n;
+  int64_t W = (int64_t)ctx_opt(ctx, "chol.block", 0);
+  if (W % 1024 != 0 || W < 2048) W = 0;
+  if (W == 0 || n < 3 * W || ctx_opt_i(ctx, "chol.fused_diag", 1) == 0 || ctx_opt_i(ctx, "chol.lookahead", 1) == 0)
+    return chol_factor_level(ctx, A, n, ld, info_out, n_rows);
+  if (info_out) *info_out = 0;
+  for (int64_t c0 = 0; c0 < n;) {
+    int64_t w = (n - c0 < W) ? n - c0 : W;
+    if (n - (c0 + w) < W / 2) w = n - c0;  // no sliver at the end: the last block takes it
+    int inf = 0;
+    GDML_TRY(chol_factor_level(ctx, A + c0 * ld + c0, w, ld, &inf, n_rows - c0));
+    if (inf != 0) {
+      if (info_out) *info_out = (int)(c0 + inf);
+      return GDML_OK;
+    }
+    const int64_t t1 = c0 + w;
+    if (t1 < n_rows && t1 < n) {
+      const double* P = A + t1 * ld + c0;  // rows below the block, the block's columns
+      GDML_TRY(launch_gemm_nt_sub(ctx, ctx->stream, P, ld, P, ld, A + t1 * ld + t1, ld, n_rows - t1, n - t1, w, 1));
+    }
+    c0 = t1;
+  }
   return GDML_OK;
 }
 

@@ -578,3 +578,47 @@ def test_energy_constraint_system_of_several_row_blocks_against_the_reference(ct
     E, F = GDMLPredict(model).predict(g['R_test'].reshape(nt, -1))
     assert np.abs(F - g['F_test']).max() <= 1e-7 * np.abs(g['F_test']).max()
     assert np.abs(E - g['E_test']).max() <= 1e-7 * max(1.0, np.abs(g['E_test']).max())
+
+
+@pytest.mark.parametrize('W,f', [(2048, 2.0), (2048, 64.0), (3072, 8.0)])
+def test_two_level_factorisation_solves_the_same_system(ctx, W, f):
+    """Option chol.block = W (csrc/chol.hip, round 6: column blocks of W columns, each factored with all rows below it carried along,
+    then ONE lower update of depth W for everything to its right; measured 0.8 % slower than the one-level schedule --
+    profiles/r06_chol_block.txt -- so it stays an A/B option): same system, residual inside the contract, same solution up to the
+    rounding of a different summation order.  n = 9450 with the carried right-hand-side row: four / three blocks, the last
+    taking the sliver; chol.block_f moves the point where a tall block leaves the fused / paired forms (both ends exercised).
+    A failing pivot is reported at its global position."""
+    N, M = 21, 150
+    ds = orc.synth_dataset(N, M, seed=4, jitter=0.3)
+    xd, gd = orc.desc_from_R(ds['R'].reshape(M, -1))
+    tp = orc.tril_perms_from_atom_perms(np.arange(N)[None])
+    y = ds['F'].ravel() / np.std(ds['F'])
+    ctx.train_upload(xd, gd, tp)
+    sols = {}
+    try:
+        for blk in (0, W):
+            ctx.set_option('chol.block', blk)
+            ctx.set_option('chol.block_f', f)
+            ctx.assemble_K(20.0, False, alloc_extra_rows=1, for_cholesky=1e-10)
+            ctx.chol_set_rhs(y)
+            assert ctx.chol_factor(1e-10) == 0
+            sols[blk] = ctx.chol_solve(None)
+        # not positive definite (lam far below zero): both schedules stop at the same leading minor
+        infos = []
+        for blk in (0, W):
+            ctx.set_option('chol.block', blk)
+            ctx.assemble_K(20.0, False, alloc_extra_rows=1, for_cholesky=-1e-3)
+            ctx.chol_set_rhs(y)
+            try:
+                infos.append(ctx.chol_factor(-1e-3))
+            except np.linalg.LinAlgError as e:
+                infos.append(str(e))
+        assert infos[0] == infos[1] and infos[0] != 0, infos
+    finally:
+        ctx.set_option('chol.block', 0)
+        ctx.set_option('chol.block_f', 2.0)
+    ctx.predict_upload_model(xd, np.zeros_like(xd), tp, 20.0, None)
+    for blk in (0, W):
+        r = ctx.kernel_matvec(1e-10, False, -sols[blk]) + y
+        assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(y)
+    assert np.linalg.norm(sols[W] - sols[0]) <= 1e-6 * np.linalg.norm(sols[0])
