@@ -131,6 +131,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   gemm.fill_tiles (0)   prediction contractions (D > 256): 128 x 64 tiles when they fill the chip better than 128 x 128 ones
  *                         (measured slower on the launch it was meant for: profiles/r06_matvec_probe.txt)
  *   predict.wide_pad (1)  the same contractions on tables / queries padded to whole tiles (no edge tiles); 0 = round 5's shapes
+ *   nys.syrk_split (1)    Gram matrix K_nm^T K_nm of the Nystroem build cut along the rows into up to 8 partial sums when its tile
+ *                         count is only a few rounds of the chip (a tile's k loop is as long as the factor is tall); 0 = one pass
  *   nys.trsm_left (1)     tall triangular solves of the Nystroem build left-looking (one deep product per 512-column strip); 0 = right-looking
  *   gemm.trace (0)        k > 0: the k-th fused launch runs the traced instantiation and leaves gemm_trace.bin (tools/gemm_trace.py)
  *   gemm.nt_c (0)         non-temporal loads / stores of the C tile (after rocBLAS's Tensile kernel for this shape:

@@ -179,6 +179,77 @@ __global__ void __launch_bounds__(256, 2) syrk_tn_kernel(const double* __restric
     syrk_tn_tile<false>(X, ldx, n, m, C, ldc, row0, col0, lds, accumulate);
 }
 
+// The same Gram tiles with the contraction cut into `splits` row ranges (round 6): block = (split, tile); split s sums rows
+// [s rows_per, (s + 1) rows_per) into its own m x ldc image C + s c_stride, gram_sum_parts_kernel adds the images in a fixed order.
+// A Gram tile's k loop is as long as the factor is tall (252 000 ... 900 000 rows), so a launch whose tile count is a few
+// rounds of the chip's 512 slots pays a whole tile time for its last, partly filled round (configs[4]: 1653 tiles = 3.2 rounds
+// -> 4; configs[2]: 666 tiles = 1.3 -> 2); cut in S the same work is S times as many units of 1 / S the length.
+__global__ void __launch_bounds__(256, 2) syrk_tn_split_kernel(const double* __restrict__ X, int64_t ldx, int64_t n, int64_t m,
+                                                               double* __restrict__ C, int64_t ldc, int tiles, int64_t ntile,
+                                                               int64_t rows_per, int64_t c_stride) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][TBK * TT];
+  const int64_t split = (int64_t)blockIdx.x / ntile, b = (int64_t)blockIdx.x - split * ntile;
+  int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > b) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+  const int64_t tj = b - ti * (ti + 1) / 2;
+  if (ti >= tiles) return;
+  const int64_t r0 = split * rows_per;
+  int64_t nn = n - r0;
+  if (nn > rows_per) nn = rows_per;
+  if (nn < 0) nn = 0;  // (an empty range still writes its zero tile)
+  X += r0 * ldx;
+  C += split * c_stride;
+  const int64_t row0 = ti * TT, col0 = tj * TT;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx % 2 == 0);
+  if (aligned && row0 + TT <= m && col0 + TT <= m && 16 * ldx * 8 < ((int64_t)1 << 32))
+    syrk_tn_tile<true>(X, ldx, nn, m, C, ldc, row0, col0, lds, 0);
+  else
+    syrk_tn_tile<false>(X, ldx, nn, m, C, ldc, row0, col0, lds, 0);
+}
+
+__global__ void __launch_bounds__(256) gram_sum_parts_kernel(double* __restrict__ out, const double* __restrict__ parts,
+                                                             int splits, int64_t stride, int64_t count, int64_t ldc) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  const int64_t r = e / ldc, c = e - r * ldc;
+  if (c / TT > r / TT) return;  // tiles above the diagonal: not written by the Gram kernel, left alone like it leaves them
+  double s = parts[e];
+  for (int k = 1; k < splits; ++k) s += parts[k * stride + e];
+  out[e] = s;
+}
+
+// C (m x m, lower tiles) = X^T X over the n rows of X; option nys.syrk_split (default 1): cut along the rows when the tile count
+// is only a few rounds of the chip
+static int gram_tn(gdml_ctx* ctx, const double* X, int64_t ldx, int64_t n, int64_t m, double* Cout, int64_t ldc) {
+  const int tiles = (int)((m + TT - 1) / TT);
+  const int64_t T = (int64_t)tiles * (tiles + 1) / 2;
+  int S = 1;
+  if (ctx_opt_i(ctx, "nys.syrk_split", 1) != 0 && T < 8192) {
+    S = (int)((8192 + T - 1) / T);
+    if (S > 8) S = 8;
+    while (S > 1 && n / S < 8192) --S;                             // every range long enough to be worth a tile's prologue
+    while (S > 1 && (int64_t)S * m * ldc * 8 > ((int64_t)2 << 30)) --S;  // at most 2 GiB of partial images (measured: no gain beyond)
+  }
+  if (S <= 1) {
+    hipLaunchKernelGGL(syrk_tn_kernel, dim3((unsigned)T), dim3(256), 0, ctx->stream, X, ldx, n, m, Cout, ldc, tiles, 0);
+    HIP_CHECK(ctx, hipGetLastError());
+    return GDML_OK;
+  }
+  void* parts = nullptr;
+  GDML_TRY(ctx_alloc(ctx, &parts, (int64_t)S * m * ldc * 8));
+  const int64_t rows_per = ((n + S - 1) / S + TBK - 1) / TBK * TBK;
+  hipLaunchKernelGGL(syrk_tn_split_kernel, dim3((unsigned)(T * S)), dim3(256), 0, ctx->stream, X, ldx, n, m, (double*)parts, ldc,
+                     tiles, T, rows_per, m * ldc);
+  hipLaunchKernelGGL(gram_sum_parts_kernel, dim3((unsigned)ceil_div(m * ldc, 256)), dim3(256), 0, ctx->stream, Cout,
+                     (const double*)parts, S, m * ldc, m * ldc, ldc);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the images go back before the next allocation needs them
+  int rc = ctx_free(ctx, parts);
+  if (e != hipSuccess) return gdml_fail(ctx, GDML_ERR_HIP, "gram_tn: %s", hipGetErrorString(e));
+  return rc;
+}
+
 // out[r] = sum_c X[r][c]^2   (leverage scores, iterative.py:107-109)
 __global__ void __launch_bounds__(256) row_sqnorm_kernel(const double* __restrict__ X, int64_t ld,
                                                          int64_t n, int64_t m, double* __restrict__ out) {
@@ -990,9 +1061,7 @@ extern "C" int gdml_nystroem_factor(gdml_ctx* ctx, double lam, const int64_t* id
     GDML_TRY(tall_trsm(ctx, S, X, n_loc, m, ld));  // K_nm <- K_nm L_mm^-T  (iterative.py:276-286)
     if (Z) GDML_TRY(tall_trsm(ctx, S, Z, m, m, ld));
     // inner = K_nm^T K_nm + lam I  (iterative.py:293-294): local SYRK, summed over the shards
-    const int tiles = (int)((m + TT - 1) / TT);
-    hipLaunchKernelGGL(syrk_tn_kernel, dim3((unsigned)(tiles * (tiles + 1) / 2)), dim3(256), 0,
-                       ctx->stream, X, ld, n_loc, m, S, ld, tiles, 0);
+    GDML_TRY(gram_tn(ctx, X, ld, n_loc, m, S, ld));
     GDML_TRY(comm_allreduce_sum(ctx, S, m * ld));
     hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, S, ld, m, lam);
     GDML_TRY(cho_factor_stable_dev(ctx, S, m, ld, backup, false, -14, &ok));  // iterative.py:304-306
