@@ -131,6 +131,8 @@ int gdml_kernel_stat(gdml_ctx* ctx, const char* kernel, double* ms_out, int64_t*
  *   gemm.fill_tiles (0)   prediction contractions (D > 256): 128 x 64 tiles when they fill the chip better than 128 x 128 ones
  *                         (measured slower on the launch it was meant for: profiles/r06_matvec_probe.txt)
  *   predict.wide_pad (1)  the same contractions on tables / queries padded to whole tiles (no edge tiles); 0 = round 5's shapes
+ *   predict.tn_fill (1)   split count of the prediction back contraction (D > 256) chosen so that its units fill whole rounds of the
+ *                         chip (0 = round 5's rule: at least three rounds' worth)
  *   nys.syrk_split (1)    Gram matrix K_nm^T K_nm of the Nystroem build cut along the rows into up to 8 partial sums when its tile
  *                         count is only a few rounds of the chip (a tile's k loop is as long as the factor is tall); 0 = one pass
  *   nys.trsm_left (1)     tall triangular solves of the Nystroem build left-looking (one deep product per 512-column strip); 0 = right-looking

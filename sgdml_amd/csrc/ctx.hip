@@ -30,7 +30,7 @@ extern "C" int gdml_abi_version(void) { return 4; }
 static const char* kKnownOptions[] = {
     "asm.wave", "asm.j_chunk", "asm.lower", "asm.strip", "asm.i_chunk",
     "asm.pts", "asm.pts_nv", "asm.pts_nt", "asm.pts_xcd", "asm.pts_i_chunk", "asm.pts_debug", "asm.perm_debug", "asm.perm_w", "asm.perm_lds_kb", "asm.perm_level", "asm.perm_nimg", "asm.perm_pg", "asm.perm_na", "asm.perm_fast_store", "asm.perm_i_chunk", "asm.perm_compact", "asm.perm_lds_rows", "asm.big1", "asm.perm2", "asm.perm2_min_n", "asm.perm2_min_p", "asm.perm2_split", "asm.perm2_post", "asm.perm2_ed", "asm.perm2_es", "asm.perm2_direct", "asm.perm2_chunk", "asm.perm2_i_chunk", "asm.perm2_debug",
-    "gemm.debug", "gemm.trace", "gemm.persist", "gemm.n64", "nys.trsm_left", "nys.syrk_split", "gemm.fill_tiles", "predict.wide_pad", "gemm.nt_c", "gemm.lds16", "chol.nb", "chol.block", "chol.block_f", "chol.small_update", "pcg.gemv_plain", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
+    "gemm.debug", "gemm.trace", "gemm.persist", "gemm.n64", "nys.trsm_left", "nys.syrk_split", "gemm.fill_tiles", "predict.wide_pad", "predict.tn_fill", "gemm.nt_c", "gemm.lds16", "chol.nb", "chol.block", "chol.block_f", "chol.small_update", "pcg.gemv_plain", "chol.lookahead", "chol.panel_fused", "chol.panel_kernel", "chol.fused_diag",
     "chol.fused_min_rows", "chol.outer", "chol.outer_min_rows", "chol.merge_gemm1", "chol.tail_lookahead", "trsm.debug",
     "trsv.persist", "predict.wave_only", "predict.mfma", "predict.fill", "predict.mfma_wide", "predict.fused", "predict.fused_rows", "predict.fused_spin",
     "lu.nb", "comm.force_collectives", "nys.force_qr", "nys.force_fail", "dist.nb", "dist.lookahead", "dist.force_panels", "pcg.depth", "pcg.precon_form", "pcg.f32_rows_per", "pcg.f32_rw", "pcg.f32_min_pivot", "pcg.f32_last_min_pivot", "pcg.f32_gram_rows", "pcg.f32_inplace"};

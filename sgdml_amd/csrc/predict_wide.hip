@@ -356,6 +356,19 @@ int predict_wide_device(gdml_ctx* ctx, const double* d_xq, int64_t B, double* pa
       if (nz > 32) nz = 32;
       if ((int64_t)nz * 64 > nt) nz = (int)(nt / 64);  // at least 64 k-tiles per split
       if (nz < 1) nz = 1;
+      if (ctx_opt_i(ctx, "predict.tn_fill", 1) != 0) {
+        // (round 6, late) among the admissible split counts from there up, the one whose units fill whole rounds of the chip's
+        // 512 slots best: configs[3] has 112 tiles -- 14 splits are 1568 units = 3.06 rounds, i.e. four rounds for three
+        // rounds' worth of work (0.77); 32 splits are exactly seven.  A split more costs bc x D doubles of partial sums.
+        int best = nz;
+        double best_score = -1.0;
+        for (int z = nz; z <= 32 && (int64_t)z * 64 <= nt && (int64_t)z * bc * D * 8 <= ((int64_t)1 << 30); ++z) {
+          const int64_t units = tiles * z, rounds = (units + 511) / 512;
+          const double score = (double)units / (double)(rounds * 512) - 0.002 * (z - nz);
+          if (score > best_score) { best_score = score; best = z; }
+        }
+        nz = best;
+      }
       double* Pp;
       GDML_TRY(ctx_slot(ctx, 9, (int64_t)nz * bc * D * 8, &Pp));
       dim3 grid((unsigned)ceil_div(D, WT), (unsigned)ceil_div(bc, WT), (unsigned)nz);
