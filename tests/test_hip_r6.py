@@ -622,3 +622,60 @@ def test_two_level_factorisation_solves_the_same_system(ctx, W, f):
         r = ctx.kernel_matvec(1e-10, False, -sols[blk]) + y
         assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(y)
     assert np.linalg.norm(sols[W] - sols[0]) <= 1e-6 * np.linalg.norm(sols[0])
+
+
+def test_fill_aware_split_counts_change_nothing_but_the_order_of_sums(ctx):
+    """Round 6, late: two launches whose unit count is chosen by how well it fills the chip's 512 workgroup slots.
+    (a) predict.tn_fill -- the split count of the prediction back contraction (D > 256): configs[3]-like shape, 2000 x 27 table
+    rows, 1000 queries: forces / energies against round 5's rule at 1e-12 (another partition of the same sum) and against the
+    oracle on a few queries.  (b) nys.syrk_split -- the Gram matrix K_nm^T K_nm of the Nystroem build cut along the rows: the
+    factor L^-1 K_mn (all rows, host copy), its leverage scores and one preconditioner application against the one-pass Gram
+    matrix on the same system (lam = 1e-8: both are the same numbers up to cond x eps)."""
+    import bench
+    from sgdml_amd.utils.desc import Desc
+
+    N = 42
+    perms = bench.perm_group(N, 'c3x3')
+    tril = np.array([Desc.perm(p_) for p_ in perms])
+    rs = np.random.RandomState(5)
+    M, B = 2000, 1000
+    R, _, _ = bench.synth_trajectory(N, M, seed=3, n_modes=8, amp=0.15, noise=0.01)
+    xd, gd = ctx.desc_from_R(R.reshape(M, -1), N)
+    JA = Desc(N).d_desc_dot_vec(gd, rs.normal(size=(M, 3 * N)))
+    ctx.predict_upload_model(xd, JA, tril, 60.0, None)
+    Rq = R.reshape(M, -1)[rs.randint(0, M, size=B)] + 0.02 * rs.normal(size=(B, 3 * N))
+    E1, F1 = ctx.predict(Rq, None)
+    ctx.set_option('predict.tn_fill', 0)
+    try:
+        E0, F0 = ctx.predict(Rq, None)
+    finally:
+        ctx.set_option('predict.tn_fill', 1)
+    assert np.abs(F1 - F0).max() <= 1e-12 * np.abs(F0).max() and np.abs(E1 - E0).max() <= 1e-12 * np.abs(E0).max()
+    xq, gq = orc.desc_from_R(Rq[:3])
+    Eo, Fo = orc.predict_from_desc(xq, gq, xd, JA, tril, 60.0)
+    assert np.abs(F1[:3] - Fo).max() <= 1e-10 * np.abs(Fo).max() and np.abs(E1[:3] - Eo).max() <= 1e-10 * np.abs(Eo).max()
+
+    # (b) 21 atoms, 700 points (n = 44 100 rows), 1200 inducing columns: 10 x 11 / 2 = 55 Gram tiles -> 8 row ranges
+    N, M, lam = 21, 700, 1e-8
+    R, _, _ = bench.synth_trajectory(N, M, seed=4, n_modes=8, amp=0.15, noise=0.01)
+    tp = np.arange(N * (N - 1) // 2, dtype=np.int64)[None]
+    xd, gd = ctx.desc_from_R(R.reshape(M, -1), N)
+    ctx.train_upload(xd, gd, tp)
+    idx = np.sort(rs.choice(M * 3 * N, 1200, replace=False))
+    v = rs.normal(size=M * 3 * N)
+    out = {}
+    try:
+        for split in (1, 0):
+            ctx.set_option('nys.syrk_split', split)
+            ctx.set_option('pcg.precon_form', 0)
+            ctx.assemble_K(20.0, False, idx=idx, alloc_extra_rows=len(idx))
+            lev, fac, info = ctx.nystroem_factor(lam, idx, want_factor=True, want_lev=True)
+            out[split] = (lev, fac, ctx.precon_apply(lam, v), info)
+    finally:
+        ctx.set_option('nys.syrk_split', 1)
+        ctx.set_option('pcg.precon_form', 2)
+    (l1, f1, z1, i1), (l0, f0, z0, i0) = out[1], out[0]
+    assert i1 == i0
+    assert np.abs(l1 - l0).max() <= 1e-6 * np.abs(l0).max()
+    assert np.abs(f1 - f0).max() <= 1e-6 * np.abs(f0).max()
+    assert np.abs(z1 - z0).max() <= 1e-5 * np.abs(z0).max()
