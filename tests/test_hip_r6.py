@@ -679,3 +679,67 @@ def test_fill_aware_split_counts_change_nothing_but_the_order_of_sums(ctx):
     assert np.abs(l1 - l0).max() <= 1e-6 * np.abs(l0).max()
     assert np.abs(f1 - f0).max() <= 1e-6 * np.abs(f0).max()
     assert np.abs(z1 - z0).max() <= 1e-5 * np.abs(z0).max()
+
+
+def test_iterative_solver_with_energy_constraints_vs_reference():
+    """The reference's Iterative.solve WITH energy constraints (fixture pcg_ecstr_n9_p6_m150, make_golden_r6.py: N = 9, P = 6,
+    M = 150, n = 4200, lam = 1e-8, k = 3 inducing points it drew itself, four of the 81 inducing columns are energy columns): our
+    K_nm for its columns equals the one it assembled -- force and energy rows -- (1e-12), gdml_pcg on that preconditioner follows
+    scipy's residual history (first 8 steps 1e-5, level crossings), converges in the same number of iterations (+-10 %), both
+    coefficient vectors predict alike; then the drop-in path (GDMLTrain.train -> Iterative under the reference's seed: the same
+    inducing columns) against the reference's predictions."""
+    from sgdml_amd import _lib
+    from sgdml_amd.predict import GDMLPredict
+    from sgdml_amd.train import GDMLTrain
+
+    g = load('pcg_ecstr_n9_p6_m150')
+    M, N = g['R_train'].shape[:2]
+    n_ff = 3 * N * M
+    sig, lam, y = float(g['sig']), float(g['lam']), g['y']
+    idx = g['inducing_pts_idxs']
+    tp = orc.tril_perms_from_atom_perms(g['perms'])
+    c = _lib.Context()
+    try:
+        xd, gd = c.desc_from_R(g['R_train'].reshape(M, -1), N)
+        c.train_upload(xd, gd, tp)
+        K_nm = c.assemble_K(sig, True, idx=idx, to_host=True)
+        assert np.abs(K_nm[g['K_nm_rows']] - g['K_nm_sample']).max() <= 1e-12 * float(g['K_nm_absmax'])
+        assert abs(np.linalg.norm(K_nm) - float(g['K_nm_fro'])) <= 1e-11 * float(g['K_nm_fro'])
+        c.set_option('pcg.precon_form', 0)  # the reference's operator
+        c.assemble_K(sig, True, idx=idx, alloc_extra_rows=len(idx))
+        c.nystroem_factor(lam, idx)
+        c.predict_upload_model(xd, np.zeros_like(xd), tp, sig, np.zeros(M))
+        hist = []
+        x, info, iters, resid = c.pcg(lam, True, y, rtol=1e-4, maxiter=20000,
+                                      callback=lambda it, r, fetch_x: hist.append(r) or False)
+        assert info == 0
+        n_ref = int(g['n_iters'])
+        assert abs(iters - n_ref) <= max(2, n_ref // 10), (iters, n_ref)
+        ref, ours = g['resid_hist'], np.array(hist)
+        np.testing.assert_allclose(ours[:8], ref[:8], rtol=1e-5)
+        assert_same_convergence(ours, ref, np.linalg.norm(y))
+        a_ref = g['alphas']
+        assert np.linalg.norm(-x - a_ref) <= 5e-2 * np.linalg.norm(a_ref)  # two solves to tol = 1e-4 of a system with cond ~ 1e8
+    finally:
+        c.close()
+    task = {
+        'type': 't', 'code_version': '1.0.3', 'dataset_name': np.array('synth'), 'dataset_theory': np.array('pair'),
+        'z': g['z'], 'R_train': g['R_train'], 'F_train': g['F_train'], 'E_train': g['E_train'],
+        'idxs_train': np.arange(M), 'md5_train': 'x', 'idxs_valid': np.arange(0), 'md5_valid': 'x',
+        'sig': int(sig), 'lam': lam, 'use_E': True, 'use_E_cstr': True, 'use_sym': True, 'perms': g['perms'],
+    }
+    tr = GDMLTrain()
+    try:
+        tr._force_solver = 'cg'
+        tr._force_n_inducing_pts = int(g['k'])
+        tr.emulate_reference_rng = True
+        np.random.seed(int(g['seed']))
+        model = tr.train(task)
+    finally:
+        tr.__del__()
+    assert np.array_equal(model['inducing_pts_idxs'], idx)
+    assert model['solver_resid'] <= model['solver_tol'] * model['norm_y_train']
+    assert abs(int(model['solver_iters']) - n_ref) <= max(3, n_ref // 5)
+    nt = len(g['R_test'])
+    E, F = GDMLPredict(model).predict(g['R_test'].reshape(nt, -1))
+    assert np.abs(F - g['F_test']).max() <= 2e-2 * np.abs(g['F_test']).max()

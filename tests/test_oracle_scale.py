@@ -191,6 +191,36 @@ def test_pcg_with_permutation_group_matches_reference():
     assert_same_convergence(ours, ref, np.linalg.norm(y))
 
 
+def test_pcg_with_energy_constraints_matches_reference():
+    """Round 6: the reference's Iterative.solve WITH energy constraints (fixture pcg_ecstr_n9_p6_m150, make_golden_r6.py: the
+    (3N + 1) M system of train.py:235-300, N = 9, P = 6, M = 150, lam = 1e-8, k = 3 inducing points, four of its 81 inducing columns
+    are energy columns, 74 iterations): the oracle reproduces the K_nm it assembled -- force AND energy rows -- and, preconditioned
+    with it, its residual history and iteration count."""
+    g = load('pcg_ecstr_n9_p6_m150')
+    M, N, xd, gd, tp, lin = setup_case(g)
+    sig, lam, y, idx = float(g['sig']), float(g['lam']), g['y'], g['inducing_pts_idxs']
+    n_ff = M * 3 * N
+    assert len(y) == n_ff + M and (idx >= n_ff).sum() == 4 and (g['K_nm_rows'] >= n_ff).sum() == 16
+    K_nm = orc.assemble_K(xd, gd, lin, sig, True, col_idxs=idx)
+    assert np.abs(K_nm[g['K_nm_rows']] - g['K_nm_sample']).max() <= 1e-12 * float(g['K_nm_absmax'])
+    assert abs(np.linalg.norm(K_nm) - float(g['K_nm_fro'])) <= 1e-11 * float(g['K_nm_fro'])
+    fac = orc.nystroem_factor(xd, gd, lin, sig, lam, idx, use_E_cstr=True)
+    K = orc.assemble_K(xd, gd, lin, sig, True)
+    probe = np.random.RandomState(0).normal(size=K.shape[0])
+    mf = orc.kernel_matvec(xd, gd, tp, sig, lam, probe, True)
+    assert np.abs(mf - (K @ probe - lam * probe)).max() <= 1e-12 * np.abs(mf).max()
+    r_hist = []
+    x, info, iters, resid = orc.pcg(lambda v: -(K @ v - lam * v), y,
+                                    M_mv=lambda r: (r_hist.append(np.linalg.norm(r)), orc.precon_apply(fac, lam, r))[1],
+                                    rtol=1e-4, maxiter=5000)
+    assert info == 0
+    n_ref = int(g['n_iters'])
+    assert abs(iters - n_ref) <= max(2, n_ref // 10), (iters, n_ref)
+    ours, ref = np.array(r_hist[1:] + [resid]), g['resid_hist']
+    np.testing.assert_allclose(ours[:8], ref[:8], rtol=1e-6)
+    assert_same_convergence(ours, ref, np.linalg.norm(y))
+
+
 def test_fixed_entry_split_of_the_perm_summed_block_matches_the_oracle():
     """Groundwork for the permutation-group assembly redesign: descriptor entries fixed by every
     permutation of the group contribute once per (i, j), the others once per permutation -- same K to rounding
