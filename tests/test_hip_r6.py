@@ -743,3 +743,33 @@ def test_iterative_solver_with_energy_constraints_vs_reference():
     nt = len(g['R_test'])
     E, F = GDMLPredict(model).predict(g['R_test'].reshape(nt, -1))
     assert np.abs(F - g['F_test']).max() <= 2e-2 * np.abs(g['F_test']).max()
+
+
+@pytest.mark.parametrize('N,M,B', [(26, 30, 200), (26, 30, 3), (50, 12, 150), (50, 12, 2), (100, 6, 130)])
+def test_energy_constraint_coefficients_beyond_256_descriptor_entries(ctx, N, M, B):
+    """alphas_E (the energy-constraint term of predict.py:226-245) in the prediction paths for D > 256 -- the GEMM pipeline of
+    csrc/predict_wide.hip for batches, predict_big_kernel for a few geometries -- and in the matrix-free operator with energy
+    constraints there (kernel_matvec, use_E_cstr): against the oracle with a two-element group, 1e-10."""
+    swp = list(range(N))
+    swp[3], swp[4] = 4, 3
+    perms = np.array([list(range(N)), swp])
+    tp = orc.tril_perms_from_atom_perms(perms)
+    ds = orc.synth_dataset(N, M + B, seed=71, jitter=0.3)
+    rs = np.random.RandomState(8)
+    xd, gd = orc.desc_from_R(ds['R'][:M].reshape(M, -1))
+    alphas, aE = rs.normal(size=(M, 3 * N)), rs.normal(size=M)
+    JA = orc.d_desc_dot_vec(gd, alphas)
+    ctx.predict_upload_model(xd, JA, tp, 40.0, aE)
+    Rq = ds['R'][M:].reshape(B, -1)
+    E, F = ctx.predict(Rq, None)
+    xq, gq = orc.desc_from_R(Rq)
+    Eo, Fo = orc.predict_from_desc(xq, gq, xd, JA, tp, 40.0, alphas_E=aE)
+    assert np.abs(F - Fo).max() <= 1e-10 * np.abs(Fo).max()
+    assert np.abs(E - Eo).max() <= 1e-10 * max(1.0, np.abs(Eo).max())
+    if B > 100:  # the operator of the iterative solver on the same training set
+        ctx.train_upload(xd, gd, tp)
+        ctx.predict_upload_model(xd, np.zeros_like(xd), tp, 40.0, np.zeros(M))
+        v = rs.normal(size=M * 3 * N + M)
+        Kv = ctx.kernel_matvec(1e-10, True, v)
+        Kv0 = orc.kernel_matvec(xd, gd, tp, 40.0, 1e-10, v, True)
+        assert np.abs(Kv - Kv0).max() <= 1e-11 * np.abs(Kv0).max()
