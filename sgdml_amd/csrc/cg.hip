@@ -231,13 +231,18 @@ static int gram_tn(gdml_ctx* ctx, const double* X, int64_t ldx, int64_t n, int64
     while (S > 1 && n / S < 8192) --S;                             // every range long enough to be worth a tile's prologue
     while (S > 1 && (int64_t)S * m * ldc * 8 > ((int64_t)2 << 30)) --S;  // at most 2 GiB of partial images (measured: no gain beyond)
   }
+  void* parts = nullptr;
+  // (no room for the images: the one-pass form -- in a sharded build a rank that failed here would leave its peers in the
+  //  all-reduce that follows)
+  if (S > 1 && ctx_alloc(ctx, &parts, (int64_t)S * m * ldc * 8) != GDML_OK) {
+    parts = nullptr;
+    S = 1;
+  }
   if (S <= 1) {
     hipLaunchKernelGGL(syrk_tn_kernel, dim3((unsigned)T), dim3(256), 0, ctx->stream, X, ldx, n, m, Cout, ldc, tiles, 0);
     HIP_CHECK(ctx, hipGetLastError());
     return GDML_OK;
   }
-  void* parts = nullptr;
-  GDML_TRY(ctx_alloc(ctx, &parts, (int64_t)S * m * ldc * 8));
   const int64_t rows_per = ((n + S - 1) / S + TBK - 1) / TBK * TBK;
   hipLaunchKernelGGL(syrk_tn_split_kernel, dim3((unsigned)(T * S)), dim3(256), 0, ctx->stream, X, ldx, n, m, (double*)parts, ldc,
                      tiles, T, rows_per, m * ldc);

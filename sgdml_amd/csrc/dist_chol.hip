@@ -363,6 +363,9 @@ extern "C" int gdml_dist_chol_solve(gdml_ctx* ctx, double sig, double lam, const
     return GDML_OK;
   };
   rc = body();
+  // a LOCAL failure outside the factorisation loop (a launch error or an allocation that only this rank could not get, in the
+  // assembly or the substitution): the peers are or will be inside a collective this rank never joins
+  if (rc == GDML_ERR_HIP || rc == GDML_ERR_OOM) comm_abort(ctx);
   int rc2 = ctx_free(ctx, tmp);
   if (rc != GDML_OK) return rc;
   if (rc2 != GDML_OK) return rc2;
